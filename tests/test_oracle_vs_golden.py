@@ -1,0 +1,160 @@
+"""Pins the CPU oracle (oracle/gpet_oracle.py) against the golden vectors produced by the
+unmodified reference (tests/golden/make_fixtures.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import gpet_oracle as orc
+
+STAGES = ["stage_rbf64", "stage_mat128", "stage_mat15_96", "stage_rbf500"]
+CTOR = {
+    "stage_rbf64": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1,
+                        N_samples=128, score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=1,
+                        fix_endpoints=True),
+    "stage_mat128": dict(kernel_options=(1, 3, 3), noise_y=0.5, N_samples=256, score_thresh=0.9, delta_x=8,
+                         keep_ratio=0.125, pixel_thresh=4, seed=7, fix_endpoints=False),
+    "stage_mat15_96": dict(kernel_options=(2, 2, 2), noise_y=1, N_samples=200, score_thresh=1, delta_x=6,
+                           keep_ratio=0.1, pixel_thresh=2, seed=3, fix_endpoints=True),
+    "stage_rbf500": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1,
+                         N_samples=1000, score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1,
+                         fix_endpoints=True),
+}
+TRACES = {"trace_rbf64": "stage_rbf64", "trace_mat128": "stage_mat128", "trace_rbf500": "stage_rbf500"}
+
+
+def test_rng_stream_matches_numpy_legacy():
+    for seed, cnt in [(1, 7), (42, 20001), (2**32 - 1, 1000)]:
+        assert np.array_equal(np.random.RandomState(seed).standard_normal(cnt), orc.legacy_standard_normal(seed, cnt))
+        assert np.array_equal(np.random.RandomState(seed).random_sample(33), orc.legacy_uniform(seed, 33))
+
+
+def test_rng_matches_fixture_Z(golden):
+    for name in STAGES:
+        g = golden(name)
+        N = int(g["ref_scalars"][8])
+        Z = orc.legacy_standard_normal(int(g["in_gp_seed"]), 8 * N).reshape(8, N)
+        assert np.array_equal(Z, g["ref_Z_head"])
+
+
+def test_kernels(golden):
+    g = golden("kernels")
+    for tag, (kt, nu) in dict(rbf=("RBF", 2.5), m05=("Matern", 0.5), m15=("Matern", 1.5), m25=("Matern", 2.5),
+                              m35=("Matern", 3.5)).items():
+        Kxx = 3.25 * orc.corr_matrix(kt, nu, g["in_x"], g["in_x"], 7.5)
+        np.fill_diagonal(Kxx, 3.25)
+        Kqx = 3.25 * orc.corr_matrix(kt, nu, g["in_xq"], g["in_x"], 7.5)
+        np.testing.assert_allclose(Kxx, g["ref_Kxx_" + tag], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(Kqx, g["ref_Kqx_" + tag], rtol=1e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_mat128", "stage_mat15_96"])
+def test_conv_bit_exact(golden, name):
+    g = golden(name)
+    assert np.array_equal(orc.kernel_builder((11, 5)), g["in_kernel"])
+    out = orc.comp_grad_img(g["in_img"], g["in_kernel"])
+    assert out.dtype == np.float32
+    assert np.array_equal(out, g["ref_grad"])
+
+
+def test_synth_image_recipe_is_stable(golden):
+    g = golden("stage_rbf64")
+    img, edge = orc.synth_sinusoid_image(64, int(g["in_img_seed"]))
+    assert np.array_equal(img, g["in_img"]) and np.array_equal(edge, g["in_true_edge"])
+    g = golden("stage_rbf500")
+    img, edge = orc.synth_sinusoid_image(500, 1)
+    assert np.array_equal(orc.comp_grad_img(img, orc.kernel_builder((11, 5))), g["ref_grad"])
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_ctor_params(golden, name):
+    g = golden(name)
+    p = orc.resolve_params(g["in_init"], g["ref_grad"], **CTOR[name])
+    got = [p["x_st"], p["x_en"], p["N_samples"], p["N_keep"], p["N_subints"], p["algo_thresh"], p["delta_x"],
+           p["pixel_thresh"], p["edge_length"]]
+    assert got == list(g["ref_scalars"])
+    assert [p["sigma_f"], p["length_scale"], p["nu"], p["keep_ratio"]] == list(g["ref_sigma"])
+    assert p["kernel_type"] == str(g["ref_kernel_type"])
+    grad64 = orc.normalise(g["ref_grad"], (0, 1), np.float64)
+    assert np.array_equal(grad64, g["ref_grad64"].astype(np.float64))
+    assert np.array_equal(orc.kde_of_gradient(grad64), g["ref_grad_kde"].astype(np.float64))
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_gp_iteration(golden, name):
+    g = golden(name)
+    p = orc.resolve_params(g["in_init"], g["ref_grad"], **CTOR[name])
+    Y, info = orc.fit_predict_samples(p["init"], g["in_obs"], p, int(g["in_gp_seed"]), want_all=True)
+    fit, pred = info["fit"], info["pred"]
+    assert np.array_equal(fit["x"], g["ref_X_train"])
+    np.testing.assert_allclose(fit["K"], g["ref_K"], rtol=1e-14)
+    np.testing.assert_allclose(fit["L"], g["ref_L"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(fit["alpha"], g["ref_alpha"], rtol=1e-9)
+    assert fit["amp"] == float(g["ref_amp"])
+    np.testing.assert_allclose(pred["mean"], g["ref_mean"], rtol=1e-12)
+    np.testing.assert_allclose(pred["std"], g["ref_std"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.diag(pred["cov"]), g["ref_cov_diag"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(pred["cov"][0], g["ref_cov_row0"], rtol=1e-9, atol=1e-10)
+    ns = g["ref_samples_head"].shape[1]
+    # same numpy/LAPACK build => identical SVD signs => identical samples
+    np.testing.assert_allclose(Y[:, :ns], g["ref_samples_head"], rtol=1e-9, atol=1e-7)
+    if "ref_factor" in g:  # T2: injected factor reproduces the reference samples exactly
+        Y2 = orc.fit_predict_samples(p["init"], g["in_obs"], p, int(g["in_gp_seed"]), factor=g["ref_factor"])
+        np.testing.assert_allclose(Y2[:, :ns], g["ref_samples_head"], rtol=1e-12, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_scoring(golden, name):
+    g = golden(name)
+    p = orc.resolve_params(g["in_init"], g["ref_grad"], **CTOR[name])
+    grad64 = g["ref_grad64"].astype(np.float64)
+    Y = g["ref_samples_head"]
+    ns = Y.shape[1]
+    costs = orc.costs_batch(grad64, p["x_grid"], Y)
+    np.testing.assert_allclose(costs, g["ref_costs"][:ns], rtol=1e-13)
+    loop = np.array([orc.cost_funct(grad64, p["x_grid"].astype(float), Y[:, i]) for i in range(min(ns, 16))])
+    assert np.array_equal(loop, g["ref_costs"][:len(loop)])
+    if ns == g["ref_costs"].shape[0]:
+        bc, bcost, bidx, _ = orc.get_best_curves(grad64, p["x_grid"], Y, p["N_keep"])
+        assert np.array_equal(bidx, g["ref_best_idxs"])
+        np.testing.assert_allclose(bcost, g["ref_best_costs"], rtol=1e-13)
+        assert np.array_equal(bc[:, 0, :], g["ref_best_curve0"])
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_pixel_selection(golden, name):
+    g = golden(name)
+    p = orc.resolve_params(g["in_init"], g["ref_grad"], **CTOR[name])
+    kde = g["ref_kde_arr"].astype(np.float64)
+    state = dict(score_thresh=float(g["in_score_thresh"]), pixel_thresh=p["pixel_thresh"],
+                 algo_thresh=p["algo_thresh"], x_st=p["x_st"], delta_x=p["delta_x"])
+    fobs, _ = orc.get_best_pixels(None, None, g["in_obs"][:, [1, 0]].reshape(-1, 2),
+                                  g["ref_grad_kde"].astype(np.float64), p["M"], p["N"], state,
+                                  p["fix_endpoints"], p["x_st"], p["x_en"], kde_arr=kde)
+    assert np.array_equal(fobs, g["ref_fobs"])
+    assert state["score_thresh"] == float(g["ref_score_thresh_out"])
+
+
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_mat128"])
+def test_full_trace_small(golden, name):
+    g = golden(name)
+    rec = []
+    kw = dict(CTOR[TRACES[name]])
+    et, ci, info = orc.trace(g["in_init"], g["ref_grad"], record=rec, **kw)
+    assert info["n_iter"] == int(g["ref_n_iter"])
+    for i, r in enumerate(rec):
+        assert np.array_equal(r["obs_out"], g["ref_obs_%02d" % (i + 1)])
+    assert np.array_equal(et, g["ref_edge_trace"])
+    np.testing.assert_allclose(ci[0], g["ref_ci_lower"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ci[1], g["ref_ci_upper"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(info["final"]["theta"], g["ref_final_theta"], rtol=1e-6, atol=1e-8)
+
+
+def test_full_trace_readme_500(golden):
+    g = golden("trace_rbf500")
+    grad = golden("stage_rbf500")["ref_grad"]
+    rec = []
+    et, ci, info = orc.trace(g["in_init"], grad, record=rec, **CTOR["stage_rbf500"])
+    assert info["n_iter"] == int(g["ref_n_iter"]) == 14
+    for i, r in enumerate(rec):
+        assert np.array_equal(r["obs_out"], g["ref_obs_%02d" % (i + 1)])
+    assert np.array_equal(et, g["ref_edge_trace"])
+    np.testing.assert_allclose(ci[0], g["ref_ci_lower"], rtol=1e-6, atol=1e-6)
