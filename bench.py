@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-traces/sec of the MI355X GP edge tracer (BASELINE.json metric).
+
+One "step" = every rank traces its batch of independent 500x500 edges to completion
+(device-resident GP loop: fit -> factor -> normals -> sample GEMM -> scoring -> KDE -> pixel
+selection, then the final hyper-parameter fit), inputs (gradient image, inits) resident in HBM.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+README_KW = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, N_samples=1000,
+                 score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "curve_kde"]
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak (spec)
+
+
+def synth_image(N, seed):
+    """Sinusoidal step edge + gaps + Gaussian noise (recipe of gpet_utils.py:163-253)."""
+    from gaussian_process_edge_trace_amd import gpet_utils
+    return gpet_utils.construct_test_img((N, N), 200 if N == 500 else int(0.4 * N), 4, 0.05, 'sinusoidal', 0.3,
+                                         gaps=True, seed=seed)
+
+
+def cpu_baseline(N, img_seed, n_traces, per_curve=True):
+    """The CPU oracle (NumPy/SciPy port of the reference algorithm, SVD sampling + per-curve
+    Simpson scoring) timed on this host.  Checker code used as the timed baseline only."""
+    from oracle import gpet_oracle as orc
+    img, edge = orc.synth_sinusoid_image(N, img_seed)
+    grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+    init = edge[[0, -1], :][:, [1, 0]]
+    t0 = time.time()
+    iters = []
+    for k in range(n_traces):
+        _, _, info = orc.trace(init, grad, per_curve=per_curve, seed=1 + k, **README_KW)
+        iters.append(info["n_iter"])
+    dt = time.time() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        nt = [d.get("num_threads", 1) for d in threadpool_info()]
+        threads = max(nt) if nt else threads
+    except Exception:
+        pass
+    return dict(value=n_traces / dt, unit="edge-traces/s", cores=int(threads), kind="port",
+                sample="%d full traces of the 500x500 README edge (RBF sf=75 l=20, S=1000, dx=5, pixel_thresh=5), "
+                       "%s iterations, oracle/gpet_oracle.py per-curve scoring + LAPACK SVD sampling" % (n_traces, iters),
+                seconds=dt)
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--edges", type=int, default=32, help="independent edges per GPU (config 4: 256 over 8 GPUs)")
+    ap.add_argument("--size", type=int, default=500)
+    ap.add_argument("--fit-workers", type=int, default=int(os.environ.get("GPET_FIT_WORKERS", "12")))
+    ap.add_argument("--cpu-traces", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    # worker processes for the host-side final fits: forked BEFORE anything touches the GPU
+    from gaussian_process_edge_trace_amd.gpet import make_fit_pool
+    pool = make_fit_pool(args.fit_workers) if args.fit_workers > 1 else None
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import gaussian_process_edge_trace_amd as pkg
+    L = pkg._lib
+    ctx = L.Context(local_rank)
+
+    # ---- inputs: one shared gradient image, produced on rank 0's GPU, broadcast over RCCL/xGMI
+    N = args.size
+    img, truth = synth_image(N, 3)
+    init = truth[[0, -1], :][:, [1, 0]]
+    t_b = 0.0
+    if world > 1:
+        g = torch.empty((N, N), dtype=torch.float32, device="cuda")
+        if rank == 0:
+            g.copy_(torch.from_numpy(pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)))
+        torch.cuda.synchronize()
+        tb0 = time.time()
+        dist.broadcast(g, src=0)
+        torch.cuda.synchronize()
+        t_b = time.time() - tb0
+        grad = g.cpu().numpy()
+    else:
+        grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+
+    E = args.edges
+    seeds = [1 + rank * E + e for e in range(E)]  # independent edges: distinct RNG streams
+    tracer = pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx,
+                                       fit_pool=pool)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    log("rank %d: batch of %d edges ready" % (rank, E))
+    for _ in range(args.warmup):
+        tracer.reset()
+        tracer()
+        log("warmup step done: %s" % {k: (round(v, 3) if isinstance(v, float) else v[:4]) for k, v in tracer.timings.items()})
+    barrier()
+    t0 = time.time()
+    loop_s = fit_s = 0.0
+    iters = []
+    for _ in range(args.steps):
+        tracer.reset()
+        traces = tracer()
+        loop_s += tracer.timings["loop_s"]
+        fit_s += tracer.timings["final_fit_s"]
+        iters = tracer.timings["iters"]
+        log("timed step done: loop %.3fs final fit %.3fs" % (tracer.timings["loop_s"], tracer.timings["final_fit_s"]))
+    barrier()
+    elapsed = time.time() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_traces = E * world * args.steps
+    value = total_traces / elapsed
+
+    if rank != 0:
+        if pool is not None:
+            pool.terminate()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- quality of this rank's traces vs ground truth (sanity band, not the metric)
+    mse = float(np.mean([pkg.gpet_utils.trace_MSE(tr, truth) for tr in traces]))
+
+    # ---- per-stage device time at a mid-trace state (batch of E edges, ~7 iterations in)
+    tracer.reset()
+    tracer._batch.iterate(seeds, 7)
+    n_mid = tracer._batch.scalars(0).n
+    rank_mid = tracer._batch.scalars(0).rank
+    stage_ms = {name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}
+    # single edge (BASELINE config 2): latency view
+    one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **README_KW, _ctx=ctx)
+    one(); one.reset()
+    ts = time.time(); one(); single_s = time.time() - ts
+    one.reset(); one._batch.iterate([1], 7)
+    one_ms = {name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}
+
+    # ---- roofline of the dominant kernel group: algorithmic bytes / flops per launch
+    S, Lg, nk = README_KW["N_samples"], N, int(README_KW["keep_ratio"] * README_KW["N_samples"])
+    alg = {
+        # fp64 flops per edge per launch
+        "sample_gemm": dict(flops=2.0 * S * Lg * rank_mid, bytes=8.0 * (S * rank_mid + rank_mid * Lg + S * Lg)),
+        "score_topk": dict(flops=40.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * N * N),
+        "fit_predict_cov": dict(flops=n_mid ** 3 / 3.0 + n_mid ** 2 * Lg + 2.0 * Lg * Lg * n_mid,
+                                bytes=8.0 * (Lg * Lg + n_mid * Lg + n_mid * n_mid)),
+        "factor": dict(flops=Lg * rank_mid ** 2 * 3.0, bytes=8.0 * (Lg * Lg + 2 * rank_mid * Lg)),
+        "normals": dict(flops=30.0 * S * Lg, bytes=8.0 * S * min(Lg, 128)),
+        "curve_kde": dict(flops=40.0 * (N + 2) * (N + 2), bytes=8.0 * 3 * (N + 2) * (N + 2) + 4.0 * N * N * 2),
+    }
+    dom = max(stage_ms, key=stage_ms.get)
+    d_ms = stage_ms[dom]
+    a_bytes = alg[dom]["bytes"] * E
+    a_flops = alg[dom]["flops"] * E
+    gbs = a_bytes / (d_ms * 1e-3) / 1e9
+    tfl = a_flops / (d_ms * 1e-3) / 1e12
+    # bound: whichever roof the algorithmic intensity puts closer
+    use_flops = (tfl / FP64_PEAK_TFLOPS) > (gbs / HBM_PEAK_GBS)
+    roofline = dict(kernel=dom, bound="mfma" if use_flops else "hbm",
+                    achieved=tfl if use_flops else gbs, peak=FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS,
+                    unit="TFLOP/s" if use_flops else "GB/s",
+                    frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=None,
+                    launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops)
+
+    log("stage profile done; dominant stage %s %.3f ms" % (dom, d_ms))
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, 3, args.cpu_traces)
+
+    out = {
+        "metric": "edge-traces/sec on 500x500 synthetic images; GP-iter ms (Cholesky+sample)",
+        "value": value, "unit": "edge-traces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2 edge (500x500 sinusoidal image, RBF sigma_f=75 l=20, N_samples=1000, "
+                               "delta_x=5, pixel_thresh=5) x %d independent edges per GPU (config 4's per-GPU share), "
+                               "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
+                   "edges_per_gpu": E, "image": [N, N], "iterations_per_trace": iters[:4],
+                   "final_fit": "host scipy L-BFGS-B x13 starts, %d worker processes" % args.fit_workers},
+        "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
+                       "single_edge": sum(one_ms[k] for k in STAGES[:4])},
+        "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
+        "time_split_s": {"device_loop": loop_s, "final_fit_host": fit_s, "elapsed": elapsed},
+        "single_edge": {"traces_per_s": 1.0 / single_s, "ms_per_trace": 1e3 * single_s},
+        "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b,
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_port"] = value / cpu["value"]
+    print(json.dumps(out))
+    if pool is not None:
+        pool.terminate()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Converged final fit of ``fit_predict_GP`` (gpet.py:232-248, 262-266) -- SURVEY 8(f) row 2.
+
+Host side for now: the reference runs scipy's L-BFGS-B (1 + 12 starts) over the log marginal
+likelihood of the <= ~100-point training set (sklearn_gpr.py:254-295, 475-607).  The optimiser
+is the reference's own third-party dependency and stays on the host; the objective is restated
+here in NumPy and is scheduled to move into libgpet_hip.so ("what comes next").
+This is NOT on the per-iteration hot path and is not a fallback for it.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.linalg
+import scipy.optimize
+
+
+def _corr_and_grad(kernel_type, nu, xs, ell):
+    a = xs / ell
+    diff = a[:, None] - a[None, :]
+    D = diff * diff
+    if kernel_type == "RBF":
+        R = np.exp(-0.5 * D)
+        return R, R * D
+    d = np.sqrt(D)
+    if nu == 0.5:
+        R = np.exp(-d)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            G = np.where(d > 0, R * D / np.where(d > 0, d, 1.0), 0.0)
+        return R, G
+    if nu == 1.5:
+        k = d * math.sqrt(3)
+        return (1.0 + k) * np.exp(-k), 3 * D * np.exp(-np.sqrt(3 * D))
+    if nu == 2.5:
+        k = d * math.sqrt(5)
+        tmp = np.sqrt(5 * D)
+        return (1.0 + k + k ** 2 / 3.0) * np.exp(-k), 5.0 / 3.0 * D * (tmp + 1) * np.exp(-tmp)
+    raise NotImplementedError("Matern nu must be 0.5, 1.5 or 2.5")
+
+
+def _corr(kernel_type, nu, xa, xb, ell):
+    diff = (xa / ell)[:, None] - (xb / ell)[None, :]
+    D = diff * diff
+    if kernel_type == "RBF":
+        return np.exp(-0.5 * D)
+    d = np.sqrt(D)
+    if nu == 0.5:
+        return np.exp(-d)
+    if nu == 1.5:
+        k = d * math.sqrt(3)
+        return (1.0 + k) * np.exp(-k)
+    k = d * math.sqrt(5)
+    return (1.0 + k + k ** 2 / 3.0) * np.exp(-k)
+
+
+def lml_and_grad(theta, xs, ys, w, kernel_type, nu, jitter=1e-6):
+    """Log marginal likelihood and its gradient wrt theta = log(c, l, noise) (sklearn_gpr.py:512-585)."""
+    c, ell, nl = np.exp(theta)
+    R, dR = _corr_and_grad(kernel_type, nu, xs, ell)
+    n = xs.shape[0]
+    K = c * R + np.diag(nl * w)
+    K[np.diag_indices(n)] += jitter
+    try:
+        L = scipy.linalg.cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError:
+        return -np.inf, np.zeros_like(theta)
+    alpha = scipy.linalg.cho_solve((L, True), ys, check_finite=False)
+    lml = -0.5 * ys @ alpha - np.log(np.diag(L)).sum() - n / 2 * np.log(2 * np.pi)
+    Kinv = scipy.linalg.cho_solve((L, True), np.eye(n), check_finite=False)
+    inner = np.outer(alpha, alpha) - Kinv
+    g = np.array([0.5 * np.einsum("ij,ji->", inner, Gk) for Gk in (c * R, c * dR, np.diag(nl * w))])
+    return lml, g
+
+
+def converged_fit_predict(init_sorted, obs_xy, x_grid, kernel_type, nu, noise_y, fix_endpoints, seed,
+                          n_restarts=12):
+    """Returns (y_mean in pixels, y_std in standardised units -- the reference does not rescale
+    it, gpet.py:266 --, theta)."""
+    pts = np.concatenate([np.asarray(init_sorted).reshape(-1, 2), np.asarray(obs_xy).reshape(-1, 2)], axis=0)
+    w = np.concatenate([np.full(len(init_sorted), 1e-7 if fix_endpoints else 0.5), np.ones(len(obs_xy))])
+    order = np.argsort(pts[:, 0])
+    pts, w = pts[order], w[order]
+    x = pts[:, 0].astype(np.float64)
+    y = pts[:, 1].astype(np.float64)
+    y_m, y_s = np.mean(y), np.std(y)
+    ys = (y - y_m) / y_s
+    X_m, X_s = np.mean(x), np.std(x)
+    xs = (x - X_m) / X_s
+    xg = np.asarray(x_grid, dtype=np.float64)
+    if xs.shape[0] == xg.shape[0]:  # sklearn_gpr.py:673-677
+        w = np.zeros_like(w)
+    m2, s2 = float(np.mean(ys)), float(np.std(ys))  # normalize_y=False standardises (sklearn_gpr.py:229-234)
+    s2 = 1.0 if s2 == 0.0 else s2
+    yt = (ys - m2) / s2
+    bounds = np.log(np.array([[0.01, 1e3], [0.1, 100.0], [1e-18, 1.0]]))  # gpet.py:246-248
+    theta0 = np.log(np.array([5.0, 5.0, float(noise_y)]))  # gpet.py:244-245
+
+    def obj(th):
+        lml, g = lml_and_grad(th, xs, yt, w, kernel_type, nu)
+        return -lml, -g
+
+    def run(th0):
+        r = scipy.optimize.minimize(obj, th0, method="L-BFGS-B", jac=True, bounds=bounds)
+        return r.x, r.fun
+
+    optima = [run(theta0)]
+    if n_restarts > 0:
+        u = np.random.RandomState(seed).uniform(size=(n_restarts, 3))  # sklearn_gpr.py:205,285
+        for r in range(n_restarts):
+            optima.append(run(bounds[:, 0] + (bounds[:, 1] - bounds[:, 0]) * u[r]))
+    theta = optima[int(np.argmin([o[1] for o in optima]))][0]
+    c, ell, nl = np.exp(theta)
+    n = xs.shape[0]
+    K = c * _corr(kernel_type, nu, xs, xs, ell) + np.diag(nl * w)
+    K[np.diag_indices(n)] += 1e-6
+    L = scipy.linalg.cholesky(K, lower=True, check_finite=False)
+    alpha = scipy.linalg.cho_solve((L, True), yt, check_finite=False)
+    xq = (xg - X_m) / X_s
+    Kt = c * _corr(kernel_type, nu, xq, xs, ell)
+    mean = s2 * (Kt @ alpha) + m2
+    V = scipy.linalg.solve_triangular(L, Kt.T, lower=True, check_finite=False)
+    var = np.full(xq.shape[0], c) - np.einsum("ij,ji->i", V.T, V)
+    var[var < 0] = 0.0
+    return y_s * mean + y_m, np.sqrt(var * s2 ** 2), theta

@@ -1,0 +1,268 @@
+"""ctypes binding of libgpet_hip.so (include/gpet_hip.h).
+
+The HIP library is the product's only compute path: if it is missing or fails to load this
+module raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpet_hip.so")
+
+# status codes (gpet_status)
+OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_ITER_CAP, ERR_RANK_CAP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_STATE = range(9)
+
+# gpet_buf
+(BUF_X_TRAIN, BUF_Y_TRAIN, BUF_CHOL, BUF_ALPHA, BUF_MEAN, BUF_STD, BUF_COV, BUF_FACTOR, BUF_EIGVALS, BUF_NORMALS,
+ BUF_SAMPLES, BUF_COSTS, BUF_BEST_IDX, BUF_BEST_COSTS, BUF_SCALARS, BUF_OBS, BUF_KDE, BUF_GRAD_KDE, BUF_GRAD,
+ BUF_NOISE_W) = range(20)
+
+KERNEL_RBF, KERNEL_MATERN = 0, 1
+
+
+class GpetParams(C.Structure):
+    _fields_ = [("kernel_type", C.c_int32), ("nu", C.c_double), ("sigma_f", C.c_double),
+                ("length_scale", C.c_double), ("noise_y", C.c_double), ("n_samples", C.c_int32),
+                ("n_keep", C.c_int32), ("delta_x", C.c_int32), ("pixel_thresh", C.c_int32),
+                ("score_thresh", C.c_double), ("fix_endpoints", C.c_int32), ("x_st", C.c_int32),
+                ("x_en", C.c_int32), ("n_init", C.c_int32), ("obs_cap", C.c_int32), ("factor_cap", C.c_int32),
+                ("z_cols", C.c_int32), ("jitter", C.c_double)]
+
+
+class GpetScalars(C.Structure):
+    _fields_ = [("y_s", C.c_double), ("amp", C.c_double), ("y_mean", C.c_double), ("y_std", C.c_double),
+                ("score_thresh", C.c_double), ("lml", C.c_double), ("n", C.c_int32), ("n_obs", C.c_int32),
+                ("rank", C.c_int32), ("status", C.c_int32), ("iter", C.c_int32), ("done", C.c_int32),
+                ("n_removed", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GpetError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgpet_hip status {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/gpet_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "gpet_abi_version": (C.c_int, []),
+    "gpet_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "gpet_ctx_destroy": (None, [_P]),
+    "gpet_last_error": (C.c_char_p, [_P]),
+    "gpet_sync": (C.c_int, [_P]),
+    "gpet_ctx_stream": (_P, [_P]),
+    "gpet_timer_start": (C.c_int, [_P]),
+    "gpet_timer_stop_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "gpet_grad_image": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "gpet_normalise_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gpet_batch_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int,
+                                    C.POINTER(GpetParams), C.POINTER(_P), C.POINTER(_P)]),
+    "gpet_batch_destroy": (None, [_P]),
+    "gpet_batch_size": (C.c_int, [_P]),
+    "gpet_batch_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int]),
+    "gpet_batch_reset": (C.c_int, [_P]),
+    "gpet_profile_stage": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "gpet_batch_set_obs": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "gpet_batch_read": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    "gpet_batch_write": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
+    "gpet_batch_clear_injected_factor": (C.c_int, [_P, C.c_int]),
+    "gpet_gp_fit_predict": (C.c_int, [_P, C.c_int]),
+    "gpet_gp_factor": (C.c_int, [_P]),
+    "gpet_gp_normals": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "gpet_gp_sample": (C.c_int, [_P]),
+    "gpet_score_curves": (C.c_int, [_P]),
+    "gpet_select_pixels": (C.c_int, [_P]),
+    "gpet_select_pixels_only": (C.c_int, [_P]),
+    "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgpet_hip.so (once).  Raises if it is absent: the product has no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  gaussian_process_edge_trace_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gpet_abi_version() != 1:
+        raise ImportError("libgpet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class Context:
+    """gpet_ctx: one device + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.gpet_ctx_create(int(device), _P(stream) if stream else None, C.byref(h))
+        if rc == ERR_NO_DEVICE:
+            raise GpetError(rc, "no HIP device visible (this package needs an MI355X; there is no CPU fallback)")
+        if rc != OK:
+            raise GpetError(rc, "gpet_ctx_create failed")
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != OK:
+            raise GpetError(rc, (self.lib.gpet_last_error(self.h) or b"").decode())
+
+    def sync(self):
+        self.check(self.lib.gpet_sync(self.h))
+
+    def timer_start(self):
+        self.check(self.lib.gpet_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.gpet_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def grad_image(self, img, kernel):
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+        out = np.empty(img.shape, dtype=np.float32)
+        self.check(self.lib.gpet_grad_image(self.h, img.ctypes.data, img.shape[0], img.shape[1], kernel.ctypes.data,
+                                            kernel.shape[0], kernel.shape[1], out.ctypes.data))
+        return out
+
+    def normalise_f32(self, img):
+        a = np.ascontiguousarray(img, dtype=np.float32)
+        out = np.empty_like(a)
+        self.check(self.lib.gpet_normalise_f32(self.h, a.ctypes.data, a.size, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpet_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DT = {BUF_X_TRAIN: np.float64, BUF_Y_TRAIN: np.float64, BUF_CHOL: np.float64, BUF_ALPHA: np.float64,
+       BUF_MEAN: np.float64, BUF_STD: np.float64, BUF_COV: np.float64, BUF_FACTOR: np.float64,
+       BUF_EIGVALS: np.float64, BUF_NORMALS: np.float64, BUF_SAMPLES: np.float64, BUF_COSTS: np.float64,
+       BUF_BEST_IDX: np.int32, BUF_BEST_COSTS: np.float64, BUF_OBS: np.int64, BUF_KDE: np.float32,
+       BUF_GRAD_KDE: np.float32, BUF_GRAD: np.float32, BUF_NOISE_W: np.float64}
+
+
+class Batch:
+    """gpet_batch: B independent edges processed together."""
+
+    def __init__(self, ctx: Context, grads, params, inits, share_image=False):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        B = len(params)
+        grads = [np.ascontiguousarray(g, dtype=np.float32) for g in grads]
+        self.M, self.N = grads[0].shape
+        inits = [np.ascontiguousarray(i, dtype=np.int64) for i in inits]
+        gp = (_P * len(grads))(*[g.ctypes.data for g in grads])
+        ip = (_P * B)(*[i.ctypes.data for i in inits])
+        pa = (GpetParams * B)(*params)
+        h = _P()
+        ctx.check(self.lib.gpet_batch_create(ctx.h, B, self.M, self.N, gp, 1 if share_image else 0, pa, ip,
+                                             C.byref(h)))
+        self.h = h
+        self.B = B
+        self._keep = (grads, inits)
+
+    def info(self, e=0):
+        v = (C.c_int32 * 10)()
+        self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 10))
+        keys = ["Lg", "S", "n_keep", "n_cap", "factor_cap", "z_cols", "factor_rows_cap", "n_bins", "obs_cap",
+                "algo_thresh"]
+        return dict(zip(keys, list(v)))
+
+    def scalars(self, e=0) -> GpetScalars:
+        s = GpetScalars()
+        self.ctx.check(self.lib.gpet_batch_read(self.h, e, BUF_SCALARS, C.byref(s), C.sizeof(s)))
+        return s
+
+    def set_obs(self, e, obs_xy):
+        o = np.ascontiguousarray(np.asarray(obs_xy).reshape(-1, 2), dtype=np.int64)
+        self.ctx.check(self.lib.gpet_batch_set_obs(self.h, e, o.ctypes.data if o.size else None, o.shape[0]))
+
+    def read(self, which, e=0):
+        inf = self.info(e)
+        s = self.scalars(e)
+        Lg, S = inf["Lg"], inf["S"]
+        shape = {BUF_X_TRAIN: (s.n,), BUF_Y_TRAIN: (s.n,), BUF_NOISE_W: (s.n,), BUF_ALPHA: (s.n,),
+                 BUF_CHOL: (s.n, s.n), BUF_MEAN: (Lg,), BUF_STD: (Lg,), BUF_COV: (Lg, Lg),
+                 BUF_FACTOR: (s.rank, Lg), BUF_EIGVALS: (s.rank,), BUF_NORMALS: (S, inf["z_cols"]),
+                 BUF_SAMPLES: (S, Lg), BUF_COSTS: (S,), BUF_BEST_IDX: (inf["n_keep"],),
+                 BUF_BEST_COSTS: (inf["n_keep"],), BUF_OBS: (s.n_obs, 2), BUF_KDE: (self.M, self.N),
+                 BUF_GRAD_KDE: (self.M, self.N), BUF_GRAD: (self.M, self.N)}[which]
+        out = np.zeros(shape, dtype=_DT[which])
+        if out.size:
+            self.ctx.check(self.lib.gpet_batch_read(self.h, e, which, out.ctypes.data, out.nbytes))
+        return out
+
+    def write(self, which, arr, e=0, rows=0):
+        a = np.ascontiguousarray(arr, dtype=_DT[which])
+        self.ctx.check(self.lib.gpet_batch_write(self.h, e, which, a.ctypes.data, a.nbytes, int(rows)))
+
+    def clear_injected_factor(self, e=0):
+        self.ctx.check(self.lib.gpet_batch_clear_injected_factor(self.h, e))
+
+    def fit_predict(self, want_cov=True):
+        self.ctx.check(self.lib.gpet_gp_fit_predict(self.h, 1 if want_cov else 0))
+
+    def factor(self):
+        self.ctx.check(self.lib.gpet_gp_factor(self.h))
+
+    def normals(self, seeds):
+        s = (C.c_uint32 * self.B)(*[int(v) & 0xFFFFFFFF for v in seeds])
+        self.ctx.check(self.lib.gpet_gp_normals(self.h, s))
+
+    def sample(self):
+        self.ctx.check(self.lib.gpet_gp_sample(self.h))
+
+    def score(self):
+        self.ctx.check(self.lib.gpet_score_curves(self.h))
+
+    def reset(self):
+        self.ctx.check(self.lib.gpet_batch_reset(self.h))
+
+    def profile_stage(self, stage, reps=10):
+        ms = C.c_float()
+        self.ctx.check(self.lib.gpet_profile_stage(self.h, int(stage), int(reps), C.byref(ms)))
+        return ms.value
+
+    def select_pixels(self):
+        self.ctx.check(self.lib.gpet_select_pixels(self.h))
+
+    def iterate(self, base_seeds, max_iters):
+        s = (C.c_uint32 * self.B)(*[int(v) & 0xFFFFFFFF for v in base_seeds])
+        n = C.c_int()
+        self.ctx.check(self.lib.gpet_trace_iterate(self.h, s, int(max_iters), C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpet_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

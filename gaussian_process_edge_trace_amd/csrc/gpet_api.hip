@@ -1,0 +1,705 @@
+// C ABI of libgpet_hip.so (see include/gpet_hip.h).  Host-side plumbing only: contexts,
+// batches, workspace carving, launches, copies.  All arithmetic lives in gpet_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gpet_kernels.h"
+
+using namespace gpet;
+
+struct gpet_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+struct gpet_batch {
+  gpet_ctx* ctx = nullptr;
+  int B = 0;
+  BatchDims bd{};
+  std::vector<EdgeDev> h_edges;
+  std::vector<gpet_params> params;
+  EdgeDev* d_edges = nullptr;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  unsigned int* d_seeds = nullptr;
+  unsigned int* d_minmax = nullptr;
+  int share_image = 0;
+  bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
+};
+
+static int fail(gpet_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail((ctx), GPET_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+namespace {
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  template <typename T>
+  T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+int nu_to_code(double nu) {
+  if (nu == 0.5) return 0;
+  if (nu == 1.5) return 1;
+  if (nu == 2.5) return 2;
+  return -1;
+}
+
+// lays out one edge's buffers; with base == nullptr only measures
+void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
+  const size_t Lg = E.Lg, nc = E.n_cap, rc = E.r_cap, S = E.S;
+  const size_t px = (size_t)E.M * E.N, gpx = (size_t)(E.M + 2) * (E.N + 2);
+  E.sc = cv.take<gpet_scalars>(1);
+  E.init_xy = cv.take<long long>(2 * (size_t)E.n_init);
+  E.obs_xy = cv.take<long long>(2 * (size_t)E.obs_cap);
+  E.obs_new = cv.take<long long>(2 * (size_t)E.obs_cap);
+  E.xt = cv.take<double>(nc);
+  E.yt = cv.take<double>(nc);
+  E.wt = cv.take<double>(nc);
+  E.alpha = cv.take<double>(nc);
+  E.K = cv.take<double>(nc * nc);
+  E.V = cv.take<double>(nc * Lg);
+  E.mean = cv.take<double>(Lg);
+  E.std = cv.take<double>(Lg);
+  E.cov = cv.take<double>(Lg * Lg);
+  E.G = cv.take<double>(rc * Lg);
+  E.perm = cv.take<int>(rc);
+  E.C = cv.take<double>(rc * rc);
+  E.W = cv.take<double>(rc * rc);
+  E.theta = cv.take<double>(rc);
+  E.order = cv.take<int>(rc);
+  E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
+  E.Z = cv.take<double>(S * (size_t)E.z_cols);
+  E.Y = cv.take<double>(S * Lg);
+  E.costs = cv.take<double>(S);
+  E.best_costs = cv.take<double>((size_t)E.n_keep + 1);
+  E.best_idx = cv.take<int>((size_t)E.n_keep + 1);
+  E.bins = cv.take<double>(gpx);
+  E.tmpk = cv.take<double>(gpx);
+  E.kde = cv.take<float>(px);
+  E.colsum = cv.take<double>((size_t)E.N);
+  E.colbest = cv.take<double>((size_t)E.N);
+  E.colbest_y = cv.take<int>((size_t)E.N);
+  E.mm = cv.take<unsigned int>(4);
+  E.binbest = cv.take<unsigned long long>((size_t)E.n_bins);
+  E.binarg = cv.take<long long>((size_t)E.n_bins);
+  if (own_image) {
+    E.grad = cv.take<float>(px);
+    E.grad_kde = cv.take<float>(px);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int gpet_abi_version(void) { return GPET_ABI_VERSION; }
+
+int gpet_ctx_create(int device, void* stream, gpet_ctx** out) {
+  if (!out) return GPET_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPET_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = new (std::nothrow) gpet_ctx();
+  if (!c) return GPET_ERR_HIP;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete c;
+    return GPET_ERR_HIP;
+  }
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return GPET_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+  *out = c;
+  return GPET_OK;
+}
+
+void gpet_ctx_destroy(gpet_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* gpet_last_error(const gpet_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gpet_sync(gpet_ctx* c) {
+  if (!c) return GPET_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+void* gpet_ctx_stream(gpet_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gpet_timer_start(gpet_ctx* c) {
+  if (!c) return GPET_ERR_BAD_ARG;
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  return GPET_OK;
+}
+
+int gpet_timer_stop_ms(gpet_ctx* c, float* ms) {
+  if (!c || !ms) return GPET_ERR_BAD_ARG;
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return GPET_OK;
+}
+
+// ---- a1 -------------------------------------------------------------------------------
+int gpet_grad_image(gpet_ctx* c, const double* img, int M, int N, const double* kern, int kh, int kw, float* out) {
+  if (!c || !img || !kern || !out || M <= 0 || N <= 0 || kh <= 0 || kw <= 0) return fail(c, GPET_ERR_BAD_ARG, "gpet_grad_image: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t px = (size_t)M * N;
+  // scipy.ndimage.convolve == correlate with the flipped kernel; even extents shift the origin
+  std::vector<double> wf((size_t)kh * kw);
+  for (int a = 0; a < kh; ++a)
+    for (int b = 0; b < kw; ++b) wf[(size_t)a * kw + b] = kern[(size_t)(kh - 1 - a) * kw + (kw - 1 - b)];
+  const int oy = kh / 2 - ((kh % 2 == 0) ? 1 : 0), ox = kw / 2 - ((kw % 2 == 0) ? 1 : 0);
+  double *d_img = nullptr, *d_wf = nullptr;
+  float *d_tmp = nullptr, *d_out = nullptr;
+  unsigned int* d_mm = nullptr;
+  HIPCHK(c, hipMalloc(&d_img, px * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_wf, wf.size() * sizeof(double)));
+  HIPCHK(c, hipMalloc(&d_tmp, px * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_out, px * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_mm, 2 * sizeof(unsigned int)));
+  const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
+  HIPCHK(c, hipMemcpyAsync(d_img, img, px * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_wf, wf.data(), wf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_mm, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_conv(c->stream, d_img, M, N, d_wf, kh, kw, oy, ox, d_tmp, d_mm));
+  HIPCHK(c, launch_normalise(c->stream, d_tmp, px, d_mm, d_out));
+  HIPCHK(c, hipMemcpyAsync(out, d_out, px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_img);
+  (void)hipFree(d_wf);
+  (void)hipFree(d_tmp);
+  (void)hipFree(d_out);
+  (void)hipFree(d_mm);
+  return GPET_OK;
+}
+
+int gpet_normalise_f32(gpet_ctx* c, const float* img, size_t count, float* out) {
+  if (!c || !img || !out || count == 0) return fail(c, GPET_ERR_BAD_ARG, "gpet_normalise_f32: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  unsigned int* d_mm = nullptr;
+  HIPCHK(c, hipMalloc(&d_in, count * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_out, count * sizeof(float)));
+  HIPCHK(c, hipMalloc(&d_mm, 2 * sizeof(unsigned int)));
+  const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
+  HIPCHK(c, hipMemcpyAsync(d_in, img, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_mm, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_minmax(c->stream, d_in, count, d_mm));
+  HIPCHK(c, launch_normalise(c->stream, d_in, count, d_mm, d_out));
+  HIPCHK(c, hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  (void)hipFree(d_mm);
+  return GPET_OK;
+}
+
+// ---- batch ----------------------------------------------------------------------------
+
+int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad, int share_image,
+                      const gpet_params* params, const int64_t* const* init_xy, gpet_batch** out) {
+  if (!c || !out || B <= 0 || M < 2 || N < 2 || !grad || !params || !init_xy)
+    return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_create: bad argument");
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  gpet_batch* b = new (std::nothrow) gpet_batch();
+  if (!b) return fail(c, GPET_ERR_HIP, "out of host memory");
+  b->ctx = c;
+  b->B = B;
+  b->share_image = share_image ? 1 : 0;
+  b->h_edges.resize(B);
+  b->params.assign(params, params + B);
+  BatchDims bd{};
+  bd.M = M;
+  bd.N = N;
+  for (int e = 0; e < B; ++e) {
+    const gpet_params& p = params[e];
+    EdgeDev& E = b->h_edges[e];
+    memset(&E, 0, sizeof E);
+    const int Lg = p.x_en - p.x_st + 1;
+    if (p.x_st < 0 || p.x_en >= N || Lg < 4 || p.n_init < 1 || p.n_samples < 1 || p.n_keep < 0 ||
+        p.n_keep > p.n_samples || p.delta_x < 1 || p.length_scale <= 0) {
+      delete b;
+      return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_create: edge %d has inconsistent parameters", e);
+    }
+    if (p.kernel_type == GPET_KERNEL_MATERN && nu_to_code(p.nu) < 0) {
+      delete b;
+      return fail(c, GPET_ERR_UNSUPPORTED, "Matern nu=%g not supported (0.5, 1.5, 2.5 only)", p.nu);
+    }
+    E.M = M;
+    E.N = N;
+    E.x_st = p.x_st;
+    E.x_en = p.x_en;
+    E.Lg = Lg;
+    E.S = p.n_samples;
+    E.n_keep = p.n_keep;
+    E.n_init = p.n_init;
+    // bins of np.round((x - x_st)/delta_x) over every image column (gpet.py:605-606)
+    E.bin_lo = (int)rint((double)(0 - p.x_st) / (double)p.delta_x);
+    E.n_bins = (int)rint((double)(N - 1 - p.x_st) / (double)p.delta_x) - E.bin_lo + 2;
+    E.obs_cap = p.obs_cap > E.n_bins ? p.obs_cap : E.n_bins;
+    E.n_cap = E.n_init + E.obs_cap;
+    E.r_cap = p.factor_cap > 0 ? p.factor_cap : 128;
+    if (E.r_cap > Lg) E.r_cap = Lg;
+    E.z_cols = p.z_cols > 0 ? p.z_cols : E.r_cap;
+    if (E.z_cols > Lg) E.z_cols = Lg;
+    if (E.z_cols < E.r_cap) E.r_cap = E.z_cols;
+    E.a_rows_cap = (E.z_cols >= Lg) ? Lg : E.r_cap;
+    E.kernel_type = p.kernel_type;
+    E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
+    E.fix_endpoints = p.fix_endpoints;
+    E.delta_x = p.delta_x;
+    E.pixel_thresh = p.pixel_thresh;
+    E.algo_thresh = Lg / p.delta_x - (p.pixel_thresh - 1);  // gpet.py:117-119
+    E.sigma_f = p.sigma_f;
+    E.length_scale = p.length_scale;
+    E.noise_y = p.noise_y;
+    E.jitter = p.jitter;
+    if (Lg > bd.Lg) bd.Lg = Lg;
+    if (E.S > bd.S) bd.S = E.S;
+    if (E.n_keep > bd.n_keep) bd.n_keep = E.n_keep;
+    if (E.z_cols > bd.z_cols) bd.z_cols = E.z_cols;
+    if (E.r_cap > bd.r_cap) bd.r_cap = E.r_cap;
+    if (E.n_cap > bd.n_cap) bd.n_cap = E.n_cap;
+    if (E.n_bins > bd.n_bins) bd.n_bins = E.n_bins;
+    if (E.obs_cap > bd.obs_cap) bd.obs_cap = E.obs_cap;
+  }
+  b->bd = bd;
+  // measure, allocate, carve
+  const size_t px = (size_t)M * N;
+  Carver meas;
+  std::vector<EdgeDev> tmp = b->h_edges;
+  float* shared_grad = nullptr;
+  float* shared_kde = nullptr;
+  if (b->share_image) {
+    shared_grad = meas.take<float>(px);
+    shared_kde = meas.take<float>(px);
+  }
+  for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image);
+  (void)shared_grad;
+  (void)shared_kde;
+  b->arena_bytes = meas.off + 256;
+  hipError_t he = hipMalloc(&b->arena, b->arena_bytes);
+  if (he != hipSuccess) {
+    delete b;
+    return fail(c, GPET_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", b->arena_bytes, hipGetErrorString(he));
+  }
+  HIPCHK(c, hipMemsetAsync(b->arena, 0, b->arena_bytes, c->stream));
+  Carver cv;
+  cv.base = b->arena;
+  if (b->share_image) {
+    shared_grad = cv.take<float>(px);
+    shared_kde = cv.take<float>(px);
+  }
+  for (int e = 0; e < B; ++e) {
+    EdgeDev& E = b->h_edges[e];
+    carve_edge(cv, E, !b->share_image);
+    if (b->share_image) {
+      E.grad = shared_grad;
+      E.grad_kde = shared_kde;
+    }
+  }
+  HIPCHK(c, hipMalloc(&b->d_edges, sizeof(EdgeDev) * B));
+  HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
+  HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
+  // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
+  float* d_raw = nullptr;
+  HIPCHK(c, hipMalloc(&d_raw, px * sizeof(float)));
+  const int n_img = b->share_image ? 1 : B;
+  for (int g = 0; g < n_img; ++g) {
+    const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
+    HIPCHK(c, hipMemcpyAsync(d_raw, grad[g], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d_minmax, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_minmax(c->stream, d_raw, px, b->d_minmax));
+    HIPCHK(c, launch_normalise(c->stream, d_raw, px, b->d_minmax, (float*)b->h_edges[g].grad));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  (void)hipFree(d_raw);
+  for (int e = 0; e < B; ++e) {
+    EdgeDev& E = b->h_edges[e];
+    HIPCHK(c, hipMemcpyAsync((void*)E.init_xy, init_xy[e], sizeof(long long) * 2 * E.n_init, hipMemcpyHostToDevice,
+                             c->stream));
+    gpet_scalars s0;
+    memset(&s0, 0, sizeof s0);
+    s0.score_thresh = params[e].score_thresh;
+    s0.done = (0 >= E.algo_thresh) ? 1 : 0;  // gpet.py:829 with no observations yet
+    HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
+  // gradient KDE of every distinct image (gpet.py:127)
+  HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : B, b->bd, 1));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = b;
+  return GPET_OK;
+}
+
+void gpet_batch_destroy(gpet_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->arena) (void)hipFree(b->arena);
+  if (b->d_edges) (void)hipFree(b->d_edges);
+  if (b->d_seeds) (void)hipFree(b->d_seeds);
+  if (b->d_minmax) (void)hipFree(b->d_minmax);
+  delete b;
+}
+
+int gpet_batch_size(const gpet_batch* b) { return b ? b->B : 0; }
+
+int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count) {
+  if (!b || e < 0 || e >= b->B || !out) return GPET_ERR_BAD_ARG;
+  const EdgeDev& E = b->h_edges[e];
+  const int32_t v[10] = {E.Lg, E.S, E.n_keep, E.n_cap, E.r_cap, E.z_cols, E.a_rows_cap, E.n_bins, E.obs_cap, E.algo_thresh};
+  for (int i = 0; i < count && i < 10; ++i) out[i] = v[i];
+  return GPET_OK;
+}
+
+static int read_scalars(gpet_batch* b, int e, gpet_scalars* s) {
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipMemcpyAsync(s, b->h_edges[e].sc, sizeof *s, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+static int check_device_status(gpet_batch* b) {
+  gpet_ctx* c = b->ctx;
+  for (int e = 0; e < b->B; ++e) {
+    gpet_scalars s;
+    int rc = read_scalars(b, e, &s);
+    if (rc) return rc;
+    if (s.status == GPET_ERR_NOT_PD)
+      return fail(c, GPET_ERR_NOT_PD, "edge %d: the kernel matrix is not positive definite (n=%d)", e, s.n);
+    if (s.status == GPET_ERR_RANK_CAP)
+      return fail(c, GPET_ERR_RANK_CAP, "edge %d: posterior covariance rank exceeds factor_cap=%d", e, b->h_edges[e].r_cap);
+    if (s.status != GPET_OK) return fail(c, s.status, "edge %d: device status %d", e, s.status);
+  }
+  return GPET_OK;
+}
+
+int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
+  if (!b || e < 0 || e >= b->B || n_obs < 0 || (n_obs > 0 && !obs_xy)) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  EdgeDev& E = b->h_edges[e];
+  if (n_obs > E.obs_cap) return fail(c, GPET_ERR_BAD_ARG, "n_obs=%d exceeds obs_cap=%d", n_obs, E.obs_cap);
+  HIPCHK(c, hipSetDevice(c->device));
+  gpet_scalars s;
+  int rc = read_scalars(b, e, &s);
+  if (rc) return rc;
+  s.n_obs = n_obs;
+  s.done = (n_obs >= E.algo_thresh) ? 1 : 0;
+  s.status = GPET_OK;
+  if (n_obs > 0)
+    HIPCHK(c, hipMemcpyAsync(E.obs_xy, obs_xy, sizeof(long long) * 2 * n_obs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(E.sc, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
+  if (!b || e < 0 || e >= b->B || !dst) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  const EdgeDev& E = b->h_edges[e];
+  gpet_scalars s;
+  int rc = read_scalars(b, e, &s);
+  if (rc) return rc;
+  const void* src = nullptr;
+  size_t avail = 0;
+  const size_t Lg = E.Lg, n = s.n, px = (size_t)E.M * E.N;
+  switch (which) {
+    case GPET_BUF_X_TRAIN: src = E.xt; avail = n * 8; break;
+    case GPET_BUF_Y_TRAIN: src = E.yt; avail = n * 8; break;
+    case GPET_BUF_NOISE_W: src = E.wt; avail = n * 8; break;
+    case GPET_BUF_ALPHA: src = E.alpha; avail = n * 8; break;
+    case GPET_BUF_MEAN: src = E.mean; avail = Lg * 8; break;
+    case GPET_BUF_STD: src = E.std; avail = Lg * 8; break;
+    case GPET_BUF_COV: src = E.cov; avail = Lg * Lg * 8; break;
+    case GPET_BUF_FACTOR: src = E.A; avail = (size_t)s.rank * Lg * 8; break;
+    case GPET_BUF_EIGVALS: src = E.theta; avail = (size_t)s.rank * 8; break;
+    case GPET_BUF_NORMALS: src = E.Z; avail = (size_t)E.S * E.z_cols * 8; break;
+    case GPET_BUF_SAMPLES: src = E.Y; avail = (size_t)E.S * Lg * 8; break;
+    case GPET_BUF_COSTS: src = E.costs; avail = (size_t)E.S * 8; break;
+    case GPET_BUF_BEST_IDX: src = E.best_idx; avail = (size_t)E.n_keep * 4; break;
+    case GPET_BUF_BEST_COSTS: src = E.best_costs; avail = (size_t)E.n_keep * 8; break;
+    case GPET_BUF_OBS: src = E.obs_xy; avail = (size_t)s.n_obs * 16; break;
+    case GPET_BUF_KDE: src = E.kde; avail = px * 4; break;
+    case GPET_BUF_GRAD_KDE: src = E.grad_kde; avail = px * 4; break;
+    case GPET_BUF_GRAD: src = E.grad; avail = px * 4; break;
+    case GPET_BUF_SCALARS:
+      memcpy(dst, &s, bytes < sizeof s ? bytes : sizeof s);
+      return GPET_OK;
+    case GPET_BUF_CHOL: {
+      // compact n x n lower-triangular copy (upper part zeroed)
+      if (bytes < n * n * 8) return fail(c, GPET_ERR_BAD_ARG, "CHOL read needs %zu bytes", n * n * 8);
+      std::vector<double> full((size_t)E.n_cap * E.n_cap);
+      HIPCHK(c, hipMemcpyAsync(full.data(), E.K, full.size() * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      double* o = (double*)dst;
+      for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) o[i * n + j] = (j <= i) ? full[i * E.n_cap + j] : 0.0;
+      return GPET_OK;
+    }
+    default:
+      return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_read: unknown buffer %d", which);
+  }
+  if (bytes > avail) bytes = avail;
+  if (which == GPET_BUF_EIGVALS) {
+    std::vector<double> th(s.rank);
+    std::vector<int> ord(s.rank);
+    if (s.rank > 0) {
+      HIPCHK(c, hipMemcpyAsync(th.data(), E.theta, (size_t)s.rank * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(ord.data(), E.order, (size_t)s.rank * 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    double* o = (double*)dst;
+    for (size_t k = 0; k < bytes / 8; ++k) o[k] = th[ord[k]];
+    return GPET_OK;
+  }
+  if (bytes) {
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return GPET_OK;
+}
+
+int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t bytes, int rows) {
+  if (!b || e < 0 || e >= b->B || !src) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  EdgeDev& E = b->h_edges[e];
+  const size_t Lg = E.Lg, px = (size_t)E.M * E.N;
+  void* dst = nullptr;
+  size_t cap = 0;
+  switch (which) {
+    case GPET_BUF_FACTOR: {
+      if (rows < 0 || rows > E.a_rows_cap || rows > E.z_cols)
+        return fail(c, GPET_ERR_BAD_ARG, "factor rows=%d exceeds capacity (a_rows_cap=%d, z_cols=%d); create the batch with z_cols=Lg", rows, E.a_rows_cap, E.z_cols);
+      dst = E.A;
+      cap = (size_t)rows * Lg * 8;
+      if (bytes != cap) return fail(c, GPET_ERR_BAD_ARG, "factor write: expected %zu bytes", cap);
+      gpet_scalars s;
+      int rc = read_scalars(b, e, &s);
+      if (rc) return rc;
+      s.rank = rows;
+      HIPCHK(c, hipMemcpyAsync(E.sc, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+      E.factor_injected = 1;
+      HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
+      b->have_factor = true;
+      break;
+    }
+    case GPET_BUF_NORMALS: dst = E.Z; cap = (size_t)E.S * E.z_cols * 8; b->have_normals = true; break;
+    case GPET_BUF_SAMPLES: dst = E.Y; cap = (size_t)E.S * Lg * 8; b->have_samples = true; break;
+    case GPET_BUF_GRAD_KDE: dst = (void*)E.grad_kde; cap = px * 4; break;
+    case GPET_BUF_KDE: dst = E.kde; cap = px * 4; break;
+    case GPET_BUF_COSTS: dst = E.costs; cap = (size_t)E.S * 8; break;
+    case GPET_BUF_SCALARS: dst = E.sc; cap = sizeof(gpet_scalars); break;
+    default:
+      return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: buffer %d is not writable", which);
+  }
+  if (bytes > cap) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cap);
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
+  if (!b || e < 0 || e >= b->B) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  EdgeDev& E = b->h_edges[e];
+  E.factor_injected = 0;
+  HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+// ---- stages ---------------------------------------------------------------------------
+int gpet_gp_fit_predict(gpet_batch* b, int want_cov) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, want_cov));
+  b->have_fit = true;
+  return check_device_status(b);
+}
+
+int gpet_gp_factor(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  if (!b->have_fit) return fail(c, GPET_ERR_STATE, "gpet_gp_factor before gpet_gp_fit_predict");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+  b->have_factor = true;
+  return check_device_status(b);
+}
+
+int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
+  if (!b || !seeds) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(b->d_seeds, seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->have_normals = true;
+  return GPET_OK;
+}
+
+int gpet_gp_sample(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  if (!b->have_fit || !b->have_factor || !b->have_normals)
+    return fail(c, GPET_ERR_STATE, "gpet_gp_sample needs fit, factor and normals first");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
+  b->have_samples = true;
+  return GPET_OK;
+}
+
+int gpet_score_curves(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  if (!b->have_samples) return fail(c, GPET_ERR_STATE, "gpet_score_curves before samples exist");
+  for (int e = 0; e < b->B; ++e)
+    if (b->h_edges[e].Lg % 2 != 0)
+      return fail(c, GPET_ERR_UNSUPPORTED, "edge %d: odd edge_length=%d (Simpson on an even sample count is scipy-version dependent)", e, b->h_edges[e].Lg);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
+  b->have_scores = true;
+  return GPET_OK;
+}
+
+int gpet_select_pixels(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  if (!b->have_scores) return fail(c, GPET_ERR_STATE, "gpet_select_pixels before gpet_score_curves");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
+  HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  return check_device_status(b);
+}
+
+int gpet_batch_reset(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int e = 0; e < b->B; ++e) {
+    gpet_scalars s0;
+    memset(&s0, 0, sizeof s0);
+    s0.score_thresh = b->params[e].score_thresh;
+    s0.done = (0 >= b->h_edges[e].algo_thresh) ? 1 : 0;
+    HIPCHK(c, hipMemcpyAsync(b->h_edges[e].sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
+  if (!b || !ms_per_rep || reps < 1) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int r = 0; r < reps; ++r) {
+    switch (stage) {
+      case 0: HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1)); break;
+      case 1: HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1)); break;
+      case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0)); break;
+      default: return fail(c, GPET_ERR_BAD_ARG, "gpet_profile_stage: unknown stage %d", stage);
+    }
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_per_rep = ms / (float)reps;
+  return check_device_status(b);
+}
+
+int gpet_select_pixels_only(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  return check_device_status(b);
+}
+
+int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active) {
+  if (!b || !base_seeds || !n_active || max_iters < 0) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  for (int e = 0; e < b->B; ++e)
+    if (b->h_edges[e].Lg % 2 != 0)
+      return fail(c, GPET_ERR_UNSUPPORTED, "edge %d: odd edge_length=%d", e, b->h_edges[e].Lg);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
+  for (int it = 0; it < max_iters; ++it) {
+    // every kernel skips edges whose `done` flag is set, so finished edges cost nothing
+    HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
+    HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1));
+    HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
+    HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  }
+  b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = (max_iters > 0) || b->have_fit;
+  int rc = check_device_status(b);
+  if (rc) return rc;
+  int active = 0;
+  for (int e = 0; e < b->B; ++e) {
+    gpet_scalars s;
+    rc = read_scalars(b, e, &s);
+    if (rc) return rc;
+    active += s.done ? 0 : 1;
+  }
+  *n_active = active;
+  return GPET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Device-side view of one edge of a batch (internal; not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gpet_hip.h"
+
+namespace gpet {
+
+// One entry per edge, stored in a device array; kernels index it with blockIdx.y.
+struct EdgeDev {
+  // geometry / clamped ctor parameters (gpet.py:95-158)
+  int M, N, x_st, x_en, Lg, S, n_keep, z_cols, r_cap, n_cap, obs_cap, n_init;
+  int kernel_type, nu_code;  // nu_code: 0 -> 0.5, 1 -> 1.5, 2 -> 2.5
+  int fix_endpoints, delta_x, pixel_thresh, algo_thresh, n_bins, a_rows_cap;
+  int factor_injected, pad0;
+  double sigma_f, length_scale, noise_y, jitter;
+  // inputs
+  const float* grad;      // [M*N] normalised gradient image (values are f32-exact, gpet.py:97)
+  const float* grad_kde;  // [M*N] normalised gradient KDE (gpet.py:127)
+  const long long* init_xy;  // [n_init*2] sorted by x
+  long long* obs_xy;         // [obs_cap*2]
+  long long* obs_new;        // [obs_cap*2] scratch for the next observation set
+  gpet_scalars* sc;
+  // GP workspaces
+  double *xt, *yt, *wt;  // [n_cap]
+  double* K;             // [n_cap*n_cap] row-major; lower triangle becomes L
+  double* alpha;         // [n_cap]
+  double* V;             // [n_cap*Lg]  L^-1 K_*^T
+  double *mean, *std;    // [Lg]
+  double* cov;           // [Lg*Lg]
+  double* G;             // [r_cap*Lg] pivoted-Cholesky columns (row t = column t)
+  int* perm;             // [r_cap]
+  double *C, *W, *theta; // [r_cap*r_cap], [r_cap*r_cap], [r_cap]
+  int* order;            // [r_cap] eigenvalue order (descending)
+  double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
+  double* Z;             // [S*z_cols]
+  double* Y;             // [S*Lg]
+  double* costs;         // [S]
+  double* best_costs;    // [n_keep]
+  int* best_idx;         // [n_keep]
+  // pixel-selection workspaces (f1)
+  double* bins;          // [(N+2)*(M+2)] linear-binning grid, x-major
+  double* tmpk;          // [(N+2)*(M+2)] separable-convolution scratch
+  float* kde;            // [M*N] normalised curve KDE
+  double* colsum;        // [N] kept weight per column
+  double* colbest;       // [N] best new-pixel score per column
+  int* colbest_y;        // [N] row of that pixel
+  unsigned int* mm;      // [4] ordered-uint min/max of the raw KDE
+  unsigned long long* binbest;  // [n_bins] bits of the best score per bin (scores are >= 0)
+  long long* binarg;     // [n_bins] order key of the best candidate per bin
+  int bin_lo, pad1;      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
+};
+
+}  // namespace gpet

@@ -1,0 +1,25 @@
+// Kernel launchers (internal).
+#pragma once
+#include "gpet_dev.h"
+
+namespace gpet {
+
+struct BatchDims {
+  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap;
+};
+
+hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,
+                       int ox, float* d_tmp, unsigned int* d_minmax);
+hipError_t launch_minmax(hipStream_t st, const float* d_in, size_t count, unsigned int* d_minmax);
+hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, const unsigned int* d_minmax,
+                            float* d_out);
+hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov);
+hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter);
+hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode);
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+
+}  // namespace gpet

@@ -1,0 +1,1255 @@
+// Hand-written gfx950 kernels for the GP edge-tracing hot path.
+// Wavefront = 64 lanes everywhere.  blockIdx.y selects the edge of the batch.
+#include "gpet_kernels.h"
+
+#include <math.h>
+
+namespace gpet {
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// Sum over the whole workgroup; result returned to every thread.  sh: >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+
+// sklearn kernels.py RBF / Matern on pre-scaled 1-D inputs a = x_i / l, b = x_j / l.
+__device__ __forceinline__ double corr_fn(int kernel_type, int nu_code, double a, double b) {
+  const double d = a - b;
+  const double d2 = d * d;
+  if (kernel_type == GPET_KERNEL_RBF) return exp(-0.5 * d2);
+  const double r = sqrt(d2);
+  if (nu_code == 0) return exp(-r);
+  if (nu_code == 1) {
+    const double k = r * 1.7320508075688772;  // math.sqrt(3)
+    return (1.0 + k) * exp(-k);
+  }
+  const double k = r * 2.23606797749979;  // math.sqrt(5)
+  return (1.0 + k + k * k / 3.0) * exp(-k);
+}
+
+// ---------------------------------------------------------------------------------------
+// a1  conv (scipy.ndimage.convolve mode='nearest') + clamp + f32 cast + min/max
+//     gpet_utils.py:112-113.  Bit-exact: taps in scipy's order, no FMA contraction.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int f32_order_key(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_key(unsigned int k) {
+  unsigned int u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ void k_conv_relu(const double* __restrict__ img, int M, int N, const double* __restrict__ wf,
+                            int kh, int kw, int oy, int ox, float* __restrict__ out, unsigned int* minmax) {
+#pragma clang fp contract(off)
+  extern __shared__ double s_w[];
+  for (int i = threadIdx.x + threadIdx.y * blockDim.x; i < kh * kw; i += blockDim.x * blockDim.y) s_w[i] = wf[i];
+  __syncthreads();
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  float v = 0.f;
+  const bool in = (x < N) && (y < M);
+  if (in) {
+    double acc = 0.0;
+    for (int a = 0; a < kh; ++a) {
+      int ry = y + a - oy;
+      ry = ry < 0 ? 0 : (ry > M - 1 ? M - 1 : ry);
+      const double* row = img + (size_t)ry * N;
+      for (int b = 0; b < kw; ++b) {
+        const double w = s_w[a * kw + b];
+        if (w == 0.0) continue;
+        int rx = x + b - ox;
+        rx = rx < 0 ? 0 : (rx > N - 1 ? N - 1 : rx);
+        acc = acc + row[rx] * w;
+      }
+    }
+    if (acc < 0.0) acc = 0.0;
+    v = (float)acc;
+    out[(size_t)y * N + x] = v;
+  }
+  // workgroup min/max -> one atomic pair per wave
+  unsigned int kmin = in ? f32_order_key(v) : 0xFFFFFFFFu;
+  unsigned int kmax = in ? f32_order_key(v) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
+    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
+  }
+  if (((threadIdx.x + threadIdx.y * blockDim.x) & 63) == 0) {
+    atomicMin(&minmax[0], kmin);
+    atomicMax(&minmax[1], kmax);
+  }
+}
+
+__global__ void k_minmax_f32(const float* __restrict__ in, size_t count, unsigned int* minmax) {
+  unsigned int kmin = 0xFFFFFFFFu, kmax = 0u;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned int k = f32_order_key(in[i]);
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
+    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&minmax[0], kmin);
+    atomicMax(&minmax[1], kmax);
+  }
+}
+
+// gpet_utils.py:84-89 in float32:  a = x - min;  a /= max(a);  (x1, +0 are no-ops)
+__global__ void k_normalise_f32(const float* __restrict__ in, size_t count, const unsigned int* minmax,
+                                float* __restrict__ out) {
+  const float mn = f32_from_key(minmax[0]);
+  const float mx = f32_from_key(minmax[1]);
+  const float span = mx - mn;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = in[i] - mn;
+    out[i] = a / span;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// a2-a4  training-set assembly + K_obs + Cholesky + alpha   (one workgroup per edge)
+//        gpet.py:209-231, sklearn_gpr.py:221-227, 304-320
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  extern __shared__ double s_dyn[];  // [n_cap] solve vector
+  __shared__ double s_red[16];
+  __shared__ double s_diag;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int n_obs = sc->n_obs;
+  const int n = E.n_init + n_obs;
+  const int ld = E.n_cap;
+  double* K = E.K;
+
+  // 1. gather + stable rank sort by x (np.argsort, gpet.py:212)
+  const double w_init = E.fix_endpoints ? 1e-7 : 0.5;  // gpet.py:161
+  for (int i = tid; i < n; i += bs) {
+    const long long* pi = (i < E.n_init) ? (E.init_xy + 2 * i) : (E.obs_xy + 2 * (i - E.n_init));
+    const long long xi = pi[0], yi = pi[1];
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+      const long long xj = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+      r += (xj < xi) || (xj == xi && j < i);
+    }
+    E.xt[r] = (double)xi;
+    E.yt[r] = (double)yi;
+    E.wt[r] = (i < E.n_init) ? w_init : 1.0;
+  }
+  __syncthreads();
+
+  // 2. y scaling (gpet.py:228-230) then centring (sklearn_gpr.py:222-227)
+  double part = 0.0;
+  for (int i = tid; i < n; i += bs) part += E.yt[i];
+  const double m1 = block_sum(part, s_red) / n;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double d = E.yt[i] - m1;
+    part += d * d;
+  }
+  const double y_s = sqrt(block_sum(part, s_red) / n) + 1.0;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double v = E.yt[i] / y_s;
+    E.yt[i] = v;
+    part += v;
+  }
+  const double m2 = block_sum(part, s_red) / n;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double d = E.yt[i] - m2;
+    part += d * d;
+  }
+  double sd2 = sqrt(block_sum(part, s_red) / n);
+  if (sd2 == 0.0) sd2 = 1.0;  // _handle_zeros_in_scale scalar path
+  for (int i = tid; i < n; i += bs) E.yt[i] -= m2;
+  const double amp = E.sigma_f * E.sigma_f / (y_s * y_s);
+  if (tid == 0) {
+    sc->y_s = y_s;
+    sc->amp = amp;
+    sc->y_mean = m2;
+    sc->y_std = sd2;
+    sc->n = n;
+  }
+  __syncthreads();
+
+  // 3. K = amp * rho + diag(noise_y * w) + jitter     (lower triangle only)
+  //    inputs are divided by l exactly as sklearn does (X / length_scale)
+  const bool zero_noise = (n == E.Lg);  // sklearn_gpr.py:673-677
+  for (int idx = tid; idx < n * n; idx += bs) {
+    const int i = idx / n, j = idx - i * n;
+    if (j > i) continue;
+    double v;
+    if (i == j) {
+      v = amp;
+      v = v + (zero_noise ? 0.0 : E.noise_y * E.wt[i]);
+      v = v + E.jitter;
+    } else {
+      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / E.length_scale, E.xt[j] / E.length_scale);
+    }
+    K[(size_t)i * ld + j] = v;
+  }
+  __syncthreads();
+
+  // 4. left-looking Cholesky, in place
+  bool bad = false;
+  for (int j = 0; j < n; ++j) {
+    const double* rj = K + (size_t)j * ld;
+    for (int i = j + tid; i < n; i += bs) {
+      const double* ri = K + (size_t)i * ld;
+      double s = ri[j];
+      for (int t = 0; t < j; ++t) s -= ri[t] * rj[t];
+      if (i == j) s_diag = s; else K[(size_t)i * ld + j] = s;
+    }
+    __syncthreads();
+    const double d = s_diag;
+    if (!(d > 0.0)) {
+      bad = true;
+      break;
+    }
+    const double dj = sqrt(d);
+    for (int i = j + tid; i < n; i += bs) {
+      if (i == j) K[(size_t)i * ld + j] = dj; else K[(size_t)i * ld + j] = K[(size_t)i * ld + j] / dj;
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) sc->status = GPET_ERR_NOT_PD;
+    return;
+  }
+
+  // 5. alpha = L^-T L^-1 y   (single wave, no barriers; z lives in LDS)
+  if (tid < WAVE) {
+    double* z = s_dyn;
+    const int lane = tid;
+    for (int j = 0; j < n; ++j) {
+      const double* rj = K + (size_t)j * ld;
+      double p = 0.0;
+      for (int t = lane; t < j; t += WAVE) p += rj[t] * z[t];
+      p = wave_sum(p);
+      if (lane == 0) z[j] = (E.yt[j] - p) / rj[j];
+    }
+    for (int j = n - 1; j >= 0; --j) {
+      double p = 0.0;
+      for (int t = j + 1 + lane; t < n; t += WAVE) p += K[(size_t)t * ld + j] * z[t];
+      p = wave_sum(p);
+      if (lane == 0) z[j] = (z[j] - p) / K[(size_t)j * ld + j];
+    }
+    for (int i = lane; i < n; i += WAVE) E.alpha[i] = z[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// a5  predict: K_* on the fly, mean, V = L^-1 K_*^T, std          (thread per grid point)
+//     sklearn_gpr.py:381-394, 414-436
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_predict(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= E.Lg) return;
+  const int n = sc->n, ld = E.n_cap, Lg = E.Lg;
+  const double amp = sc->amp;
+  const double xq = (double)(E.x_st + j) / E.length_scale;
+  double msum = 0.0, vsum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / E.length_scale);
+    const double* ri = E.K + (size_t)i * ld;
+    double acc = ki;
+    for (int t = 0; t < i; ++t) acc -= ri[t] * E.V[(size_t)t * Lg + j];
+    const double v = acc / ri[i];
+    E.V[(size_t)i * Lg + j] = v;
+    msum += ki * E.alpha[i];
+    vsum += v * v;
+  }
+  E.mean[j] = sc->y_std * msum + sc->y_mean;
+  double var = amp - vsum;
+  if (var < 0.0) var = 0.0;
+  E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
+}
+
+// cov = (amp*rho(x*,x*) - V^T V) * y_std^2        sklearn_gpr.py:398-403
+// 32x32 output tile per workgroup (16x16 threads, 2x2 each); symmetric: only bx >= by tiles.
+__global__ void __launch_bounds__(256) k_cov(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int Lg = E.Lg;
+  if (bx * 32 >= Lg || by * 32 >= Lg) return;
+  __shared__ double sa[32][33];
+  __shared__ double sb[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = sc->n;
+  double acc[2][2] = {{0, 0}, {0, 0}};
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+      const int ii = e >> 5, jj = e & 31;
+      const int i = i0 + ii;
+      const int ja = by * 32 + jj, jb = bx * 32 + jj;
+      sa[ii][jj] = (i < n && ja < Lg) ? E.V[(size_t)i * Lg + ja] : 0.0;
+      sb[ii][jj] = (i < n && jb < Lg) ? E.V[(size_t)i * Lg + jb] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int ii = 0; ii < 32; ++ii) {
+      const double a0 = sa[ii][ty], a1 = sa[ii][ty + 16];
+      const double b0 = sb[ii][tx], b1 = sb[ii][tx + 16];
+      acc[0][0] += a0 * b0;
+      acc[0][1] += a0 * b1;
+      acc[1][0] += a1 * b0;
+      acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+  const double amp = sc->amp, s2 = sc->y_std * sc->y_std;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int r = by * 32 + ty + 16 * u, c = bx * 32 + tx + 16 * v;
+      if (r < Lg && c < Lg) {
+        const double k = (r == c) ? amp
+                                  : amp * corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + r) / E.length_scale,
+                                                  (double)(E.x_st + c) / E.length_scale);
+        const double val = (k - acc[u][v]) * s2;
+        E.cov[(size_t)r * Lg + c] = val;
+        E.cov[(size_t)c * Lg + r] = val;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a6  factor of the posterior covariance (what numpy's SVD-based multivariate_normal builds)
+//     step 1: pivoted Cholesky  cov ~= G^T G  (G rows = columns of the factor), rank-revealing
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_pchol(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  extern __shared__ double s_d[];  // [Lg] remaining diagonal
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ double s_piv;
+  __shared__ int s_pidx;
+  const int tid = threadIdx.x, bs = blockDim.x, Lg = E.Lg;
+  const int lane = tid & 63, w = tid >> 6, nw = bs >> 6;
+  for (int i = tid; i < Lg; i += bs) s_d[i] = E.cov[(size_t)i * Lg + i];
+  __syncthreads();
+  double tol = 0.0;
+  int k = 0;
+  for (; k < E.r_cap; ++k) {
+    // argmax of the remaining diagonal (ties -> smallest index)
+    double bv = -1.0;
+    int bi = 0x7FFFFFFF;
+    for (int i = tid; i < Lg; i += bs) {
+      const double v = s_d[i];
+      if (v > bv) {
+        bv = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, WAVE);
+      const int oi = __shfl_xor(bi, o, WAVE);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[w] = bv;
+      s_idx[w] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_val[0];
+      int ix = s_idx[0];
+      for (int q = 1; q < nw; ++q)
+        if (s_val[q] > v || (s_val[q] == v && s_idx[q] < ix)) {
+          v = s_val[q];
+          ix = s_idx[q];
+        }
+      s_piv = v;
+      s_pidx = ix;
+    }
+    __syncthreads();
+    const double dp = s_piv;
+    const int p = s_pidx;
+    if (k == 0) tol = dp * 1e-14;
+    if (!(dp > tol) || !(dp > 0.0)) break;
+    const double sq = sqrt(dp);
+    if (tid == 0) E.perm[k] = p;
+    for (int i = tid; i < Lg; i += bs) {
+      double g = 0.0;
+      if (s_d[i] >= 0.0) {  // not yet pivoted
+        g = E.cov[(size_t)i * Lg + p];
+        for (int t = 0; t < k; ++t) g -= E.G[(size_t)t * Lg + i] * E.G[(size_t)t * Lg + p];
+        g = g / sq;
+      }
+      E.G[(size_t)k * Lg + i] = g;
+    }
+    __syncthreads();  // all reads of s_d / G row p done before the diagonal is downdated
+    for (int i = tid; i < Lg; i += bs) {
+      if (i == p) {
+        s_d[i] = -1.0;  // mark as used
+      } else if (s_d[i] >= 0.0) {
+        const double g = E.G[(size_t)k * Lg + i];
+        double nd = s_d[i] - g * g;
+        s_d[i] = nd > 0.0 ? nd : 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sc->rank = k;
+    if (k == E.r_cap) {
+      // capacity reached: check what is left
+      double rem = 0.0;
+      for (int i = 0; i < Lg; ++i) rem = s_d[i] > rem ? s_d[i] : rem;
+      if (rem > tol * 1e4) sc->status = GPET_ERR_RANK_CAP;
+    }
+  }
+}
+
+// step 2: Gram matrix C = G G^T (rank x rank)
+__global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = sc->rank, Lg = E.Lg;
+  const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+  if (a0 >= r || b0 >= r || b0 > a0) return;
+  __shared__ double sa[16][65];
+  __shared__ double sb[16][65];
+  const int ta = threadIdx.x >> 4, tb = threadIdx.x & 15;
+  double acc = 0.0;
+  for (int i0 = 0; i0 < Lg; i0 += 64) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int rr = e >> 6, ii = e & 63;
+      const int i = i0 + ii;
+      sa[rr][ii] = (a0 + rr < r && i < Lg) ? E.G[(size_t)(a0 + rr) * Lg + i] : 0.0;
+      sb[rr][ii] = (b0 + rr < r && i < Lg) ? E.G[(size_t)(b0 + rr) * Lg + i] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int ii = 0; ii < 64; ++ii) acc += sa[ta][ii] * sb[tb][ii];
+    __syncthreads();
+  }
+  const int a = a0 + ta, b = b0 + tb;
+  if (a < r && b < r) {
+    E.C[(size_t)a * E.r_cap + b] = acc;
+    E.C[(size_t)b * E.r_cap + a] = acc;
+  }
+}
+
+// step 3: cyclic two-sided Jacobi (round-robin ordering) of the rank x rank Gram matrix.
+// C and the accumulated rotations W live in global memory (L2-resident, <= r_cap^2 doubles).
+__global__ void __launch_bounds__(1024) k_jacobi(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  extern __shared__ double s_mem[];  // [2*m] rotations (c, s), then scratch
+  __shared__ double s_red[16];
+  const int r = sc->rank, ld = E.r_cap;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  double* A = E.C;
+  double* W = E.W;
+  for (int e = tid; e < r * r; e += bs) {
+    const int i = e / r, j = e - i * r;
+    W[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int m = (r + 1) & ~1;  // even number of players; index m-1 may be a bye (== r)
+  const int half = m >> 1;
+  double* s_c = s_mem;
+  double* s_s = s_mem + half;
+  int* s_p = (int*)(s_mem + 2 * half);
+  int* s_q = s_p + half;
+  if (r >= 2) {
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      // convergence: off(A)^2 <= eps^2 * diag(A)^2
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < r * r; e += bs) {
+        const int i = e / r, j = e - i * r;
+        const double v = A[(size_t)i * ld + j];
+        if (i == j) dg += v * v; else off += v * v;
+      }
+      off = block_sum(off, s_red);
+      dg = block_sum(dg, s_red);
+      if (off <= 1e-30 * dg || off == 0.0) break;
+      for (int round = 0; round < m - 1; ++round) {
+        // rotation parameters for this round's disjoint pairs
+        if (tid < half) {
+          int p, q;
+          if (tid == 0) {
+            p = m - 1;
+            q = round;
+          } else {
+            p = (round + tid) % (m - 1);
+            q = (round - tid + (m - 1)) % (m - 1);
+          }
+          if (p > q) {
+            const int t = p;
+            p = q;
+            q = t;
+          }
+          double c = 1.0, s = 0.0;
+          if (q < r) {
+            const double apq = A[(size_t)p * ld + q];
+            const double app = A[(size_t)p * ld + p], aqq = A[(size_t)q * ld + q];
+            if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
+              const double tau = (aqq - app) / (2.0 * apq);
+              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              c = 1.0 / sqrt(1.0 + t * t);
+              s = t * c;
+            }
+          } else {
+            q = -1;  // bye
+          }
+          s_c[tid] = c;
+          s_s[tid] = s;
+          s_p[tid] = p;
+          s_q[tid] = q;
+        }
+        __syncthreads();
+        // column rotations on A and W: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)
+        for (int e = tid; e < half * r; e += bs) {
+          const int k = e / r, i = e - k * r;
+          const int p = s_p[k], q = s_q[k];
+          if (q < 0) continue;
+          const double c = s_c[k], s = s_s[k];
+          if (s == 0.0) continue;
+          const double ap = A[(size_t)i * ld + p], aq = A[(size_t)i * ld + q];
+          A[(size_t)i * ld + p] = c * ap - s * aq;
+          A[(size_t)i * ld + q] = s * ap + c * aq;
+          const double wp = W[(size_t)i * ld + p], wq = W[(size_t)i * ld + q];
+          W[(size_t)i * ld + p] = c * wp - s * wq;
+          W[(size_t)i * ld + q] = s * wp + c * wq;
+        }
+        __syncthreads();
+        // row rotations on A
+        for (int e = tid; e < half * r; e += bs) {
+          const int k = e / r, j = e - k * r;
+          const int p = s_p[k], q = s_q[k];
+          if (q < 0) continue;
+          const double c = s_c[k], s = s_s[k];
+          if (s == 0.0) continue;
+          const double ap = A[(size_t)p * ld + j], aq = A[(size_t)q * ld + j];
+          A[(size_t)p * ld + j] = c * ap - s * aq;
+          A[(size_t)q * ld + j] = s * ap + c * aq;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // eigenvalues + descending order (rank by counting; ties -> lower index first)
+  for (int k = tid; k < r; k += bs) E.theta[k] = A[(size_t)k * ld + k];
+  __syncthreads();
+  for (int k = tid; k < r; k += bs) {
+    const double v = E.theta[k];
+    int pos = 0;
+    for (int j = 0; j < r; ++j) {
+      const double u = E.theta[j];
+      pos += (u > v) || (u == v && j < k);
+    }
+    E.order[pos] = k;
+  }
+}
+
+// step 4: factor rows  A[k, :] = sum_t W[t, order[k]] * G[t, :]  (= sqrt(s_k) v_k up to sign).
+// Sign convention (LAPACK's is implementation-defined): sum_j A[k, j] / (j + 1) >= 0.
+__global__ void __launch_bounds__(256) k_factor_rows(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = sc->rank, Lg = E.Lg, k = blockIdx.x;
+  if (k >= r) return;
+  __shared__ double s_red[16];
+  extern __shared__ double s_w[];  // [r]
+  const int col = E.order[k];
+  for (int t = threadIdx.x; t < r; t += blockDim.x) s_w[t] = E.W[(size_t)t * E.r_cap + col];
+  __syncthreads();
+  double part = 0.0;
+  for (int j = threadIdx.x; j < Lg; j += blockDim.x) {
+    double acc = 0.0;
+    for (int t = 0; t < r; ++t) acc += s_w[t] * E.G[(size_t)t * Lg + j];
+    E.A[(size_t)k * Lg + j] = acc;
+    part += acc / (double)(j + 1);
+  }
+  const double dot = block_sum(part, s_red);
+  if (dot < 0.0)
+    for (int j = threadIdx.x; j < Lg; j += blockDim.x) E.A[(size_t)k * Lg + j] = -E.A[(size_t)k * Lg + j];
+}
+
+// ---------------------------------------------------------------------------------------
+// K5  numpy legacy RandomState stream on the device: MT19937 (init_genrand) + legacy_gauss.
+//     One workgroup per edge; 624-word blocks = 156 polar attempts (4 words each).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int mt_temper(unsigned int y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9D2C5680u;
+  y ^= (y << 15) & 0xEFC60000u;
+  y ^= y >> 18;
+  return y;
+}
+__device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, unsigned int far) {
+  const unsigned int y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+
+__global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter) {
+#pragma clang fp contract(off)
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  __shared__ unsigned int s_mt[2][624];
+  __shared__ int s_cnt[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    // seed of iteration k (0-based) = base + k + 1 (gpet.py:839)
+    unsigned int p = seeds[blockIdx.y] + (add_iter ? (unsigned int)(sc->iter + 1) : 0u);
+    s_mt[0][0] = p;
+    for (int i = 1; i < 624; ++i) {
+      p = 1812433253u * (p ^ (p >> 30)) + (unsigned int)i;
+      s_mt[0][i] = p;
+    }
+  }
+  __syncthreads();
+  const long long total = (long long)E.S * E.Lg;
+  const long long need_pairs = (total + 1) / 2;
+  long long done_pairs = 0;
+  int cur = 0, it = 0;
+  while (done_pairs < need_pairs) {
+    unsigned int* o = s_mt[cur];
+    unsigned int* nw = s_mt[cur ^ 1];
+    if (tid < 227) nw[tid] = mt_mix(o[tid], o[tid + 1], o[tid + 397]);
+    __syncthreads();
+    if (tid < 227) nw[227 + tid] = mt_mix(o[227 + tid], o[228 + tid], nw[tid]);
+    __syncthreads();
+    if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
+    if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+    __syncthreads();
+    // 156 polar attempts
+    bool ok = false;
+    double g0 = 0.0, g1 = 0.0;
+    if (tid < 156) {
+      const unsigned int a = mt_temper(nw[4 * tid]) >> 5, b = mt_temper(nw[4 * tid + 1]) >> 6;
+      const unsigned int c = mt_temper(nw[4 * tid + 2]) >> 5, d = mt_temper(nw[4 * tid + 3]) >> 6;
+      const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+      const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
+      const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+      const double r2 = x1 * x1 + x2 * x2;
+      ok = !(r2 >= 1.0 || r2 == 0.0);
+      if (ok) {
+        const double f = sqrt(-2.0 * log(r2) / r2);
+        g0 = f * x2;
+        g1 = f * x1;
+      }
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[it & 1][w] = __popcll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int q = 0; q < 4; ++q) {
+      const int cq = s_cnt[it & 1][q];
+      if (q < w) base += cq;
+      tot += cq;
+    }
+    if (ok) {
+      const long long pidx = done_pairs + base + before;
+      const long long q0 = 2 * pidx;
+      if (q0 < total) {
+        const long long srow = q0 / E.Lg;
+        const int colq = (int)(q0 - srow * E.Lg);
+        if (colq < E.z_cols) E.Z[(size_t)srow * E.z_cols + colq] = g0;
+      }
+      if (q0 + 1 < total) {
+        const long long srow = (q0 + 1) / E.Lg;
+        const int colq = (int)(q0 + 1 - srow * E.Lg);
+        if (colq < E.z_cols) E.Z[(size_t)srow * E.z_cols + colq] = g1;
+      }
+    }
+    done_pairs += tot;
+    cur ^= 1;
+    ++it;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K6  samples = y_s * (Z[:, :rows] @ A + mean)                 gpet.py:260-261
+//     64x64 output tile per workgroup, 16x16 threads, 4x4 outputs each.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int Lg = E.Lg, S = E.S, zc = E.z_cols;
+  const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (s0 >= S || j0 >= Lg) return;
+  const int rows = sc->rank;
+  __shared__ double sz[16][65];  // [k][s]
+  __shared__ double sa[16][65];  // [k][j]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+  for (int k0 = 0; k0 < rows; k0 += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int kk = e & 15, ss = e >> 4;  // Z is [s][k]: k fastest
+      const int k = k0 + kk, s = s0 + ss;
+      sz[kk][ss] = (k < rows && s < S) ? E.Z[(size_t)s * zc + k] : 0.0;
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int jj = e & 63, kk = e >> 6;
+      const int k = k0 + kk, j = j0 + jj;
+      sa[kk][jj] = (k < rows && j < Lg) ? E.A[(size_t)k * Lg + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double zv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) zv[u] = sz[kk][ty + 16 * u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) av[v] = sa[kk][tx + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] += zv[u] * av[v];
+    }
+    __syncthreads();
+  }
+  const double y_s = sc->y_s;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int s = s0 + ty + 16 * u, j = j0 + tx + 16 * v;
+      if (s < S && j < Lg) E.Y[(size_t)s * Lg + j] = (acc[u][v] + E.mean[j]) * y_s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a7  cost of every sampled curve (gpet.py:391-408): one wave per curve, Simpson pairs
+//     spread over the lanes.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double grad_at(const float* __restrict__ grad, int M, int N, double y, int x) {
+  // RectBivariateSpline(kx=ky=1)(y, x) with integer x: clamped linear interpolation along y
+  y = y < 0.0 ? 0.0 : (y > (double)(M - 1) ? (double)(M - 1) : y);
+  int iy = (int)floor(y);
+  if (iy > M - 2) iy = M - 2;
+  if (iy < 0) iy = 0;
+  const double w1 = y - (double)iy, w0 = ((double)iy + 1.0) - y;
+  const int iy1 = (iy + 1 < M) ? iy + 1 : M - 1;
+  return (double)grad[(size_t)iy * N + x] * w0 + (double)grad[(size_t)iy1 * N + x] * w1;
+}
+
+__global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= E.S) return;
+  const int Lg = E.Lg;
+  const double* __restrict__ row = E.Y + (size_t)s * Lg;
+  const int npair = (Lg - 2) / 2;  // Simpson over Lg-1 samples (odd count)
+  double al = 0.0, li = 0.0;
+  for (int i = lane; i < npair; i += WAVE) {
+    const int k = 2 * i;
+    const double y0 = row[k], y1 = row[k + 1], y2 = row[k + 2], y3 = row[k + 3];
+    const double d0 = y1 - y0, d1 = y2 - y1, d2 = y3 - y2;
+    const double l0 = sqrt(1.0 + d0 * d0), l1 = sqrt(1.0 + d1 * d1), l2 = sqrt(1.0 + d2 * d2);
+    al += (2.0 / 6.0) * (l0 + 4.0 * l1 + l2);
+    const double g0 = grad_at(E.grad, E.M, E.N, y0, E.x_st + k) + 1e-3;
+    const double g1 = grad_at(E.grad, E.M, E.N, y1, E.x_st + k + 1) + 1e-3;
+    const double g2 = grad_at(E.grad, E.M, E.N, y2, E.x_st + k + 2) + 1e-3;
+    const double h0 = l1, h1 = l2;
+    const double hsum = h0 + h1, hprod = h0 * h1, hdiv = h0 / h1;
+    li += hsum / 6.0 * (g0 * (2.0 - 1.0 / hdiv) + g1 * (hsum * (hsum / hprod)) + g2 * (2.0 - hdiv));
+  }
+  al = wave_sum(al);
+  li = wave_sum(li);
+  if (lane == 0) E.costs[s] = al / li;
+}
+
+// argsort(costs)[:n_keep] by rank counting (ties -> lower index first)       gpet.py:443
+__global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  __shared__ double s_c[1024];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double ci = (i < E.S) ? E.costs[i] : 0.0;
+  int rank = 0;
+  for (int j0 = 0; j0 < E.S; j0 += 1024) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) s_c[e] = (j0 + e < E.S) ? E.costs[j0 + e] : 0.0;
+    __syncthreads();
+    const int lim = (E.S - j0) < 1024 ? (E.S - j0) : 1024;
+    for (int e = 0; e < lim; ++e) {
+      const double cj = s_c[e];
+      rank += (cj < ci) || (cj == ci && (j0 + e) < i);
+    }
+  }
+  if (i < E.S && rank < E.n_keep) {
+    E.best_idx[rank] = i;
+    E.best_costs[rank] = ci;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// f1  KDE of the best curves + pixel scoring / binning / argmax        gpet.py:455-662
+//     KDEpy.FFTKDE restated: linear binning on the unit grid x=-1..N, y=-1..M, 9x9 Gaussian
+//     (bw=1, support 4), crop, float32 min-max.  (PARITY UNPINNED: KDEpy is not available.)
+//     Grid layout is x-major like KDEpy's: cell (gx, gy) at gx*(M+2)+gy.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kde_clear(EdgeDev* edges, int mode) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  const size_t cells = (size_t)(E.N + 2) * (E.M + 2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cells; i += (size_t)gridDim.x * blockDim.x)
+    E.bins[i] = 0.0;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      E.mm[0] = 0xFFFFFFFFu;
+      E.mm[1] = 0u;
+    }
+    for (int i = threadIdx.x; i < E.n_bins; i += blockDim.x) {
+      E.binbest[i] = 0ull;
+      E.binarg[i] = 0x7FFFFFFFFFFFFFFFll;
+    }
+    for (int i = threadIdx.x; i < E.N; i += blockDim.x) E.colsum[i] = 0.0;
+  }
+}
+
+// one thread per grid column: the column receives exactly one point per kept curve, binned in
+// curve order (the order KDEpy's sequential loop sees them, gpet.py:487).
+__global__ void __launch_bounds__(64) k_kde_bin_curves(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E.Lg) return;
+  double inv_sum = 0.0;
+  for (int b = 0; b < E.n_keep; ++b) inv_sum += 1.0 / E.best_costs[b];
+  const int gx = E.x_st + k + 1;
+  double* col = E.bins + (size_t)gx * (E.M + 2);
+  double wsum = 0.0;
+  int removed = 0;
+  const double ymax = (double)(E.M - 1);
+  for (int b = 0; b < E.n_keep; ++b) {
+    const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
+    if (y < 0.0 || y > ymax) {  // gpet.py:498-500
+      ++removed;
+      continue;
+    }
+    const double w = (1.0 / E.best_costs[b]) / inv_sum;
+    const double gy = y + 1.0;
+    const int iy = (int)floor(gy);
+    const double fy = gy - (double)iy;
+    col[iy] += (1.0 - fy) * w;
+    col[iy + 1] += fy * w;
+    wsum += w;
+  }
+  E.colsum[E.x_st + k] = wsum;
+  if (removed) atomicAdd(&sc->n_removed, removed);
+}
+
+// gradient KDE (ctor, gpet.py:505-509): points = pixels with grad > 1e-3, weight = grad
+__global__ void __launch_bounds__(256) k_kde_bin_gradient(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const int x = blockIdx.x;
+  if (x >= E.N) return;
+  __shared__ double s_red[16];
+  double part = 0.0;
+  for (int y = threadIdx.x; y < E.M; y += blockDim.x) {
+    const double g = (double)E.grad[(size_t)y * E.N + x];
+    if (g > 1e-3) {
+      E.bins[(size_t)(x + 1) * (E.M + 2) + (y + 1)] = g;
+      part += g;
+    }
+  }
+  part = block_sum(part, s_red);
+  if (threadIdx.x == 0) E.colsum[x] = part;
+}
+
+__constant__ double c_gauss9[9] = {3.3546262790251185e-04, 1.1108996538242306e-02, 1.3533528323661270e-01,
+                                   6.0653065971263342e-01, 1.0,
+                                   6.0653065971263342e-01, 1.3533528323661270e-01, 1.1108996538242306e-02,
+                                   3.3546262790251185e-04};  // exp(-t^2/2), t=-4..4
+
+// vertical pass (along y, contiguous): tmp = (bins / W) (*) g
+__global__ void __launch_bounds__(256) k_kde_conv_y(EdgeDev* edges, int mode) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  const int H = E.M + 2, Wd = E.N + 2;
+  const int gy = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gx = blockIdx.y;
+  if (gy >= H || gx >= Wd) return;
+  __shared__ double s_w;
+  if (threadIdx.x == 0) {
+    double w = 0.0;
+    for (int i = 0; i < E.N; ++i) w += E.colsum[i];
+    s_w = w;
+  }
+  __syncthreads();
+  const double* col = E.bins + (size_t)gx * H;
+  double acc = 0.0;
+#pragma unroll
+  for (int t = -4; t <= 4; ++t) {
+    const int yy = gy + t;
+    if (yy >= 0 && yy < H) acc += (col[yy] / s_w) * c_gauss9[t + 4];
+  }
+  E.tmpk[(size_t)gx * H + gy] = acc;
+}
+
+// horizontal pass + crop + transpose to (M, N) float32 + min/max
+__global__ void __launch_bounds__(256) k_kde_conv_x(EdgeDev* edges, int mode) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  const int H = E.M + 2, Wd = E.N + 2;
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;  // image row
+  const int x = blockIdx.y;                             // image column
+  float v = 0.f;
+  const bool in = (y < E.M) && (x < E.N);
+  if (in) {
+    const int gx = x + 1, gy = y + 1;
+    double acc = 0.0;
+#pragma unroll
+    for (int t = -4; t <= 4; ++t) {
+      const int xx = gx + t;
+      if (xx >= 0 && xx < Wd) acc += E.tmpk[(size_t)xx * H + gy] * c_gauss9[t + 4];
+    }
+    acc *= 0.15915494309189535;  // 1 / (2 pi): Gaussian pdf normalisation in 2-D
+    v = (float)acc;
+    float* dst = (mode == 0) ? E.kde : (float*)E.grad_kde;
+    dst[(size_t)y * E.N + x] = v;
+  }
+  unsigned int kmin = in ? f32_order_key(v) : 0xFFFFFFFFu;
+  unsigned int kmax = in ? f32_order_key(v) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
+    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&E.mm[0], kmin);
+    atomicMax(&E.mm[1], kmax);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  const float mn = f32_from_key(E.mm[0]);
+  const float span = f32_from_key(E.mm[1]) - mn;
+  float* a = (mode == 0) ? E.kde : (float*)E.grad_kde;
+  const size_t px = (size_t)E.M * E.N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < px; i += (size_t)gridDim.x * blockDim.x)
+    a[i] = (a[i] - mn) / span;
+}
+
+// pixel_scores = 1/3 * (i*g + i + g) with numpy's rounding order (gpet.py:582)
+__device__ __forceinline__ double pixel_score(double iv, double gv) {
+#pragma clang fp contract(off)
+  double t = iv * gv;
+  t = t + iv;
+  t = t + gv;
+  return (1.0 / 3.0) * t;
+}
+
+__device__ __forceinline__ int bin_of(const EdgeDev& E, int x) {
+  return (int)rint((double)(x - E.x_st) / (double)E.delta_x) - E.bin_lo;  // np.round = half-to-even
+}
+
+// best new candidate of every admissible column (first in row-major order among equals)
+__global__ void __launch_bounds__(64) k_pix_columns(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= E.N) return;
+  double best = -1.0;
+  int by = -1;
+  const bool admissible = E.fix_endpoints ? (x > E.x_st && x < E.x_en) : true;  // gpet.py:655-657
+  if (admissible) {
+    for (int y = 0; y < E.M; ++y) {
+      const double iv = (double)E.kde[(size_t)y * E.N + x];
+      if (iv > 1e-3) {  // gpet.py:651
+        const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
+        if (sv > best) {
+          best = sv;
+          by = y;
+        }
+      }
+    }
+  }
+  E.colbest[x] = best;
+  E.colbest_y[x] = by;
+  if (by >= 0) atomicMax(&E.binbest[bin_of(E, x)], (unsigned long long)__double_as_longlong(best));
+}
+
+// previously accepted observations are re-scored and compete first (gpet.py:568-579)
+__global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc->n_obs) return;
+  const long long x = E.obs_xy[2 * i], y = E.obs_xy[2 * i + 1];
+  const double iv = (double)E.kde[(size_t)y * E.N + x];
+  if (iv > 1e-3) {
+    const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
+    atomicMax(&E.binbest[bin_of(E, (int)x)], (unsigned long long)__double_as_longlong(sv));
+  }
+}
+
+// among the candidates that reach their bin's best score, the first in the reference's candidate
+// order wins (np.argmax): old observations in their order, then new pixels in row-major order.
+__global__ void __launch_bounds__(256) k_pix_argbest(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_obs = sc->n_obs;
+  if (t < n_obs) {
+    const long long x = E.obs_xy[2 * t], y = E.obs_xy[2 * t + 1];
+    const double iv = (double)E.kde[(size_t)y * E.N + x];
+    if (iv > 1e-3) {
+      const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
+      const int b = bin_of(E, (int)x);
+      if ((unsigned long long)__double_as_longlong(sv) == E.binbest[b])
+        atomicMin(&E.binarg[b], (long long)t - (long long)(1ll << 40));  // old: before every new pixel
+    }
+  }
+  if (t < E.N) {
+    const int by = E.colbest_y[t];
+    if (by >= 0) {
+      const int b = bin_of(E, t);
+      if ((unsigned long long)__double_as_longlong(E.colbest[t]) == E.binbest[b])
+        atomicMin(&E.binarg[b], (long long)by * E.N + t);
+    }
+  }
+}
+
+// adaptive threshold (gpet.py:589-609), one pixel per bin (gpet.py:613-616), loop bookkeeping
+// (gpet.py:861-865).  One wave per edge.
+__global__ void __launch_bounds__(64) k_pix_select(EdgeDev* edges) {
+#pragma clang fp contract(off)
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int lane = threadIdx.x;
+  const int n_pre = sc->n_obs;
+  double thresh = sc->score_thresh;
+  int n_pix = n_pre;
+  int it = 0;
+  bool stuck = false;
+  while ((n_pix - n_pre < E.pixel_thresh) && (n_pix < E.algo_thresh)) {
+    if (it > 0) {
+      if (thresh == 0.0) {  // the reference would spin forever here (latent hang 1)
+        stuck = true;
+        break;
+      }
+      thresh = thresh * 0.95;
+    }
+    int cnt = 0;
+    for (int b = lane; b < E.n_bins; b += WAVE) {
+      const unsigned long long bits = E.binbest[b];
+      cnt += (E.binarg[b] != 0x7FFFFFFFFFFFFFFFll) && (__longlong_as_double((long long)bits) >= thresh);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, WAVE);
+    n_pix = cnt;
+    ++it;
+  }
+  if (stuck) {
+    if (lane == 0) sc->status = GPET_ERR_ITER_CAP;
+    return;
+  }
+  // compact the winning pixels in ascending bin order (np.unique order)
+  int base = 0;
+  for (int b0 = 0; b0 < E.n_bins; b0 += WAVE) {
+    const int b = b0 + lane;
+    bool take = false;
+    long long key = 0;
+    if (b < E.n_bins) {
+      key = E.binarg[b];
+      take = (key != 0x7FFFFFFFFFFFFFFFll) && (__longlong_as_double((long long)E.binbest[b]) >= thresh);
+    }
+    const unsigned long long bal = __ballot(take);
+    if (take) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      long long x, y;
+      if (key < 0) {  // an old observation
+        const long long oi = key + (1ll << 40);
+        x = E.obs_xy[2 * oi];
+        y = E.obs_xy[2 * oi + 1];
+      } else {
+        y = key / E.N;
+        x = key - y * E.N;
+      }
+      E.obs_new[2 * pos] = x;
+      E.obs_new[2 * pos + 1] = y;
+    }
+    base += __popcll(bal);
+  }
+  // (same wave: obs_new fully written before it is copied back)
+  for (int i = lane; i < 2 * n_pix; i += WAVE) E.obs_xy[i] = E.obs_new[i];
+  if (lane == 0) {
+    sc->score_thresh = thresh;
+    sc->n_obs = n_pix;
+    sc->iter = sc->iter + 1;
+    sc->done = (n_pix >= E.algo_thresh) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,
+                       int ox, float* d_tmp, unsigned int* d_minmax) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  dim3 bs(64, 4), gs(cdiv(N, 64), cdiv(M, 4));
+  hipLaunchKernelGGL(k_conv_relu, gs, bs, (size_t)kh * kw * sizeof(double), st, d_img, M, N, d_wf, kh, kw, oy, ox,
+                     d_tmp, d_minmax);
+  return hipGetLastError();
+}
+hipError_t launch_minmax(hipStream_t st, const float* d_in, size_t count, unsigned int* d_minmax) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_minmax_f32, dim3(blocks), dim3(256), 0, st, d_in, count, d_minmax);
+  return hipGetLastError();
+}
+hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, const unsigned int* d_minmax,
+                            float* d_out) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_normalise_f32, dim3(blocks), dim3(256), 0, st, d_in, count, d_minmax, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_fit, dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  hipLaunchKernelGGL(k_predict, dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges);
+  if (want_cov) {
+    const int t = cdiv(bd.Lg, 32);
+    hipLaunchKernelGGL(k_cov, dim3(t, t, B), dim3(256), 0, st, d_edges);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  int pth = bd.Lg >= 1024 ? 1024 : (bd.Lg > 512 ? 1024 : (bd.Lg > 256 ? 512 : 256));
+  hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)bd.Lg * sizeof(double), st, d_edges);
+  const int t = cdiv(bd.r_cap, 16);
+  hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
+  const int half = (bd.r_cap + 2) / 2;
+  hipLaunchKernelGGL(k_jacobi, dim3(1, B), dim3(1024), (size_t)(2 * half) * sizeof(double) + 2 * half * sizeof(int),
+                     st, d_edges);
+  hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
+  return hipGetLastError();
+}
+
+hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_mt_normals, dim3(1, B), dim3(256), 0, st, d_edges, d_seeds, add_iter);
+  return hipGetLastError();
+}
+
+// mode 0: KDE of the best curves -> E.kde ; mode 1: KDE of the gradient image -> E.grad_kde
+hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_kde_clear, dim3(64, B), dim3(256), 0, st, d_edges, mode);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_kde_bin_curves, dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges);
+  else
+    hipLaunchKernelGGL(k_kde_bin_gradient, dim3(bd.N, B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_kde_conv_y, dim3(cdiv(bd.M + 2, 256), bd.N + 2, B), dim3(256), 0, st, d_edges, mode);
+  hipLaunchKernelGGL(k_kde_conv_x, dim3(cdiv(bd.M, 256), bd.N, B), dim3(256), 0, st, d_edges, mode);
+  hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_pix_reset(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  for (int i = threadIdx.x; i < E.n_bins; i += blockDim.x) {
+    E.binbest[i] = 0ull;
+    E.binarg[i] = 0x7FFFFFFFFFFFFFFFll;
+  }
+}
+
+hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  (void)bd;
+  hipLaunchKernelGGL(k_pix_reset, dim3(1, B), dim3(256), 0, st, d_edges);
+  return hipGetLastError();
+}
+
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 64), B), dim3(64), 0, st, d_edges);
+  const int nt = bd.N > bd.obs_cap ? bd.N : bd.obs_cap;
+  hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_pix_select, dim3(1, B), dim3(64), 0, st, d_edges);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_sample_gemm, dim3(cdiv(bd.Lg, 64), cdiv(bd.S, 64), B), dim3(256), 0, st, d_edges);
+  return hipGetLastError();
+}
+
+hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();  // drop stale errors: report only these launches
+  hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  return hipGetLastError();
+}
+
+}  // namespace gpet

@@ -1,0 +1,333 @@
+"""Drop-in ``GP_Edge_Tracing`` whose arithmetic runs in libgpet_hip.so on an MI355X.
+
+Mirrors the constructor / ``__call__`` surface of the reference
+(``gp_edge_tracing/gpet.py:22-35, 768-773``): same argument names, order, defaults, silent
+clamping (gpet.py:95-119) and return conventions (gpet.py:902-908).  The per-iteration
+stages keep the reference's method names -- ``fit_predict_GP`` (gpet.py:182),
+``get_best_curves`` (:414), ``cost_funct`` (:371), ``get_best_pixels`` (:622) -- and are thin
+calls into the C ABI (include/gpet_hip.h).  There is no CPU fallback: without the HIP
+library / a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import time as t
+
+import numpy as np
+
+from . import _lib
+from . import gpet_utils
+
+
+def resolve_params(init, grad_shape, kernel_options=(1, 3, 3), noise_y=1, obs=np.array([], dtype=np.int8),
+                   N_samples=500, score_thresh=1, delta_x=20, keep_ratio=0.1, pixel_thresh=5, seed=42,
+                   return_std=False, fix_endpoints=True):
+    """Host-side parameter clamping and derived sizes of the reference constructor
+    (gpet.py:95-151), including its quirks: x_st/x_en come from the UNSORTED ``init``
+    (gpet.py:96), ``N_keep`` uses the raw ``keep_ratio*N_samples`` (gpet.py:118), the 3-tuple
+    presets index with ``[opt-1]`` (gpet.py:146,150), the dict needs key 'kernel' (gpet.py:133)."""
+    init = np.asarray(init)
+    p = dict(noise_y=noise_y, seed=seed, return_std=return_std, fix_endpoints=fix_endpoints)
+    p["init"] = init[np.argsort(init[:, 0])].astype(int)
+    p["x_st"], p["x_en"] = int(init[0, 0]), int(init[-1, 0])
+    p["N_samples"] = int(N_samples) if N_samples > 100 else 1000
+    p["obs"] = np.asarray(obs).reshape(-1, 2).astype(np.int64)
+    p["keep_ratio"] = float(keep_ratio) if 0 < keep_ratio <= 1 else 0.1
+    p["pixel_thresh"] = int(pixel_thresh) if pixel_thresh >= 2 else 2
+    p["score_thresh"] = float(score_thresh) if 0 < score_thresh <= 1 else 1
+    p["delta_x"] = int(delta_x) if delta_x > 3 else 2
+    p["half_delta"] = p["delta_x"] // 2
+    p["N_inits"] = p["init"].shape[0]
+    p["M"], p["N"] = grad_shape
+    p["x_grid"] = p["x_st"] + np.arange(p["x_en"] - p["x_st"] + 1).astype(int)
+    p["edge_length"] = p["x_grid"].shape[0]
+    p["N_subints"] = int(p["edge_length"] // p["delta_x"])
+    p["N_keep"] = int(keep_ratio * N_samples)
+    p["algo_thresh"] = p["N_subints"] - (p["pixel_thresh"] - 1)
+    if type(kernel_options) == dict:
+        p["sigma_f"] = kernel_options["sigma_f"]
+        p["sigma_l"] = kernel_options["length_scale"]
+        p["kernel_type"] = kernel_options["kernel"]
+        p["kernel_nu"] = kernel_options["nu"] if kernel_options["kernel"] == "Matern" else 2.5
+    else:
+        rbf_matern, sigmaf_opt, sigmal_opt = kernel_options
+        p["kernel_type"] = ["RBF", "Matern"][int(rbf_matern > 0)]
+        p["kernel_nu"] = [2.5, 1.5][int(rbf_matern > 1)]
+        sf = [10, 8, 6, 4, 2, 1][sigmaf_opt - 1] if (sigmaf_opt >= 0) and (sigmaf_opt <= 5) else 1
+        p["sigma_f"] = p["M"] // sf
+        sl = [1, 4 / 3, 2, 4, 10][sigmal_opt - 1] if (sigmal_opt >= 0) and (sigmal_opt <= 4) else 10
+        p["sigma_l"] = p["edge_length"] // sl
+    return p
+
+
+def to_abi_params(p, obs_cap=None, factor_cap=0, z_cols=0):
+    """gpet_params (include/gpet_hip.h) from the resolved constructor state."""
+    q = _lib.GpetParams()
+    q.kernel_type = _lib.KERNEL_MATERN if p["kernel_type"] == "Matern" else _lib.KERNEL_RBF
+    q.nu = float(p["kernel_nu"])
+    q.sigma_f = float(p["sigma_f"])
+    q.length_scale = float(p["sigma_l"])
+    q.noise_y = float(p["noise_y"])
+    q.n_samples = int(p["N_samples"])
+    q.n_keep = int(p["N_keep"])
+    q.delta_x = int(p["delta_x"])
+    q.pixel_thresh = int(p["pixel_thresh"])
+    q.score_thresh = float(p["score_thresh"])
+    q.fix_endpoints = 1 if p["fix_endpoints"] else 0
+    q.x_st, q.x_en = int(p["x_st"]), int(p["x_en"])
+    q.n_init = int(p["N_inits"])
+    n_bins = (p["edge_length"] - 1) // p["delta_x"] + 3
+    q.obs_cap = int(obs_cap if obs_cap is not None else max(n_bins, p["obs"].shape[0] + 1))
+    q.factor_cap = int(factor_cap)
+    q.z_cols = int(z_cols)
+    q.jitter = 1e-6  # gpet.py:155
+    return q
+
+
+class GP_Edge_Tracing(object):
+    """Traces one edge with Gaussian-process regression on the GPU (gpet.py:17-35)."""
+
+    def __init__(self, init, grad_img, kernel_options=(1, 3, 3), noise_y=1, obs=np.array([], dtype=np.int8),
+                 N_samples=500, score_thresh=1, delta_x=20, keep_ratio=0.1, pixel_thresh=5, seed=42,
+                 return_std=False, fix_endpoints=True, *, device=0, stream=None, factor_cap=0, z_cols=0,
+                 _ctx=None):
+        p = resolve_params(init, np.asarray(grad_img).shape, kernel_options, noise_y, obs, N_samples, score_thresh,
+                           delta_x, keep_ratio, pixel_thresh, seed, return_std, fix_endpoints)
+        self._p = p
+        for k in ("init", "x_st", "x_en", "noise_y", "N_samples", "obs", "seed", "keep_ratio", "pixel_thresh",
+                  "score_thresh", "delta_x", "half_delta", "return_std", "fix_endpoints", "N_inits", "M", "N",
+                  "x_grid", "edge_length", "N_subints", "N_keep", "algo_thresh", "sigma_f", "sigma_l",
+                  "kernel_type", "kernel_nu"):
+            setattr(self, k, p[k])
+        self.kde_thresh = 1e-3
+        self.X = np.repeat(self.x_grid.reshape(-1, 1), self.N_samples, axis=-1)
+        self._ctx = _ctx if _ctx is not None else _lib.Context(device, stream)
+        # the library re-normalises the gradient image in float32 (gpet.py:97)
+        g32 = np.asarray(grad_img).astype(np.float32)
+        self._abi = to_abi_params(p, factor_cap=factor_cap, z_cols=z_cols)
+        self._batch = _lib.Batch(self._ctx, [g32], [self._abi], [p["init"]])
+        self.grad_img = self._batch.read(_lib.BUF_GRAD).astype(np.float64)
+        self._n_iter = 0
+
+    # ---- gpet.py:182-268 ---------------------------------------------------------------
+    def fit_predict_GP(self, obs, converged=False, seed=0):
+        """Not-converged branch: returns ``N_samples`` posterior curves, shape (N, N_samples),
+        exactly like the reference (a transposed view of the row-per-sample device buffer)."""
+        if converged:
+            raise NotImplementedError("converged fit runs through GP_Edge_Tracing.__call__")
+        b = self._batch
+        b.set_obs(0, obs)
+        b.fit_predict(want_cov=True)
+        b.factor()
+        b.normals([seed])
+        b.sample()
+        return b.read(_lib.BUF_SAMPLES).T
+
+    # ---- gpet.py:371-451 ---------------------------------------------------------------
+    def get_best_curves(self, y_samples=None):
+        """Scores the samples currently on the device (``y_samples`` given => they are
+        uploaded first) and returns (best_curves, best_costs, (optimal_curve, optimal_cost))."""
+        b = self._batch
+        if y_samples is not None:
+            b.write(_lib.BUF_SAMPLES, np.ascontiguousarray(np.asarray(y_samples, dtype=np.float64).T))
+        b.score()
+        idx = b.read(_lib.BUF_BEST_IDX)
+        costs = b.read(_lib.BUF_BEST_COSTS)
+        Y = b.read(_lib.BUF_SAMPLES)
+        curves = np.stack((np.repeat(self.x_grid.reshape(-1, 1), idx.shape[0], axis=-1).astype(np.float64),
+                           Y[idx].T), axis=-1)
+        return curves, costs, (curves[:, 0, :], costs[0])
+
+    def cost_funct(self, edge):
+        """Cost of one curve given as (N, 2) xy (gpet.py:371-410)."""
+        edge = np.asarray(edge, dtype=np.float64)
+        edge = edge[edge[:, 0].argsort(), :]
+        b = self._batch
+        Y = b.read(_lib.BUF_SAMPLES)
+        Y[0] = edge[:, 1]
+        b.write(_lib.BUF_SAMPLES, Y)
+        b.score()
+        return float(b.read(_lib.BUF_COSTS)[0])
+
+    # ---- gpet.py:622-662 ---------------------------------------------------------------
+    def get_best_pixels(self, best_curves=None, costs=None, pre_fobs=None):
+        """KDE of the best curves + pixel scoring / binning / non-max suppression on the device,
+        for the curves scored last.  Returns the new observation set (xy int64)."""
+        b = self._batch
+        b.select_pixels()
+        return b.read(_lib.BUF_OBS)
+
+    def __call__(self, print_final_diagnostics=False, show_init_post=False, show_post_iter=False, verbose=False,
+                 return_lines=False, max_iter=1000):
+        """Runs the trace (gpet.py:768-908).  The while-loop of the reference (gpet.py:829-870)
+        lives on the device; the host only polls the per-edge ``done`` flag."""
+        from ._final_fit import converged_fit_predict
+
+        all_samples, all_obs = [], [self.obs]
+        iter_optimal_curves, iter_optimal_costs = [], []
+        if show_init_post or show_post_iter or print_final_diagnostics:
+            import warnings
+            warnings.warn("plotting flags are accepted for API compatibility but ignored by the GPU tracer")
+        alg_st = t.time()
+        b = self._batch
+        b.set_obs(0, self.obs)
+        n_iter = 0
+        step = 1 if (return_lines or verbose) else 4
+        while not b.scalars().done:
+            st = t.time()
+            if verbose:
+                print('Fitting Gaussian process and computing next set of observations...')
+            b.iterate([self.seed], step)
+            s = b.scalars()
+            n_iter = s.iter
+            if return_lines:
+                all_samples.append(b.read(_lib.BUF_SAMPLES).T)
+                idx = b.read(_lib.BUF_BEST_IDX)
+                iter_optimal_curves.append(np.stack((self.x_grid.astype(np.float64), all_samples[-1][:, idx[0]]), -1))
+                iter_optimal_costs.append(b.read(_lib.BUF_BEST_COSTS)[0])
+                all_obs.append(b.read(_lib.BUF_OBS))
+            if verbose:
+                print(f'Number of observations: {s.n_obs}')
+                print(f'Iteration {n_iter + 1} - Time Elapsed: {round(t.time() - st, 4)}\n\n')
+            if n_iter >= max_iter:
+                raise _lib.GpetError(_lib.ERR_ITER_CAP, f"trace did not converge in {max_iter} iterations")
+        self._n_iter = n_iter
+        pre_fobs = b.read(_lib.BUF_OBS)
+        self.score_thresh = b.scalars().score_thresh
+        # final hyper-parameter-optimised fit (gpet.py:874-876), seed = seed + N_iter
+        y_mean_optim, y_std, self._theta = converged_fit_predict(
+            self.init, pre_fobs, self.x_grid, self.kernel_type, self.kernel_nu, self.noise_y, self.fix_endpoints,
+            self.seed + n_iter)
+        cred_interval = (y_mean_optim - 1.96 * y_std, y_mean_optim + 1.96 * y_std)
+        all_samples.append(y_mean_optim)
+        all_obs.append(pre_fobs)
+        optim_mean_curve = np.concatenate([self.x_grid[:, np.newaxis], y_mean_optim[:, np.newaxis]], axis=1)
+        edge_trace = np.rint(optim_mean_curve[:, [1, 0]]).astype(int)
+        iter_optimal_curves.append(edge_trace[:, [1, 0]])
+        if verbose:
+            print(f'Time elapsed before algorithm converged: {round(t.time() - alg_st, 3)}')
+        if self.return_std:
+            return edge_trace, cred_interval
+        if not return_lines:
+            return edge_trace
+        return edge_trace, (all_samples, all_obs, iter_optimal_curves)
+
+
+def _final_fit_job(args):
+    from ._final_fit import converged_fit_predict
+    return converged_fit_predict(*args)
+
+
+class GP_Edge_Tracing_Batch(object):
+    """B independent edges traced together on one GPU (BASELINE config 4's per-GPU share).
+
+    Not in the reference (which traces one edge per object); it is the batched form of the same
+    algorithm: every kernel takes the edge index from blockIdx, finished edges are skipped, and
+    edge e's result equals what ``GP_Edge_Tracing`` returns for the same arguments.
+
+    ``inits``: list of (n_init, 2) xy arrays; ``grad_imgs``: one (M, N) image shared by all edges
+    or a list with one image per edge; ``seeds``: per-edge RNG seed (gpet.py:33,839).
+    Remaining keyword arguments are the reference constructor's (gpet.py:22-35), common to all edges.
+    """
+
+    def __init__(self, inits, grad_imgs, seeds, kernel_options=(1, 3, 3), noise_y=1, N_samples=500, score_thresh=1,
+                 delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, device=0,
+                 stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None):
+        share = not isinstance(grad_imgs, (list, tuple))
+        imgs = [grad_imgs] if share else list(grad_imgs)
+        B = len(inits)
+        assert len(seeds) == B and (share or len(imgs) == B)
+        self._ps = [resolve_params(inits[e], np.asarray(imgs[0 if share else e]).shape, kernel_options, noise_y,
+                                   np.array([]), N_samples, score_thresh, delta_x, keep_ratio, pixel_thresh,
+                                   int(seeds[e]), return_std, fix_endpoints) for e in range(B)]
+        self._ctx = _ctx if _ctx is not None else _lib.Context(device, stream)
+        g32 = [np.asarray(g).astype(np.float32) for g in imgs]
+        abi = [to_abi_params(p, factor_cap=factor_cap, z_cols=z_cols) for p in self._ps]
+        self._batch = _lib.Batch(self._ctx, g32, abi, [p["init"] for p in self._ps], share_image=share)
+        self.B = B
+        self.return_std = return_std
+        self.seeds = [int(s) for s in seeds]
+        self.timings = {}
+        # optional multiprocessing pool for the host-side final fits; create it BEFORE the process
+        # touches the GPU (make_fit_pool) -- never fork/spawn after HIP is initialised
+        self._pool = fit_pool
+
+    def reset(self):
+        self._batch.reset()
+
+    def run_loop(self, max_iter=1000, chunk=4):
+        """The device-resident while-loops of all edges (gpet.py:829-870); returns iterations per edge."""
+        b = self._batch
+        n_active = self.B
+        done_iters = 0
+        while n_active > 0:
+            n_active = b.iterate(self.seeds, chunk)
+            done_iters += chunk
+            if done_iters >= max_iter and n_active > 0:
+                raise _lib.GpetError(_lib.ERR_ITER_CAP, f"{n_active} edges did not converge in {max_iter} iterations")
+        return [b.scalars(e).iter for e in range(self.B)]
+
+    def final_fits(self, iters):
+        jobs = []
+        b = self._batch
+        for e, p in enumerate(self._ps):
+            obs = b.read(_lib.BUF_OBS, e)
+            jobs.append((p["init"], obs, p["x_grid"], p["kernel_type"], p["kernel_nu"], p["noise_y"],
+                         p["fix_endpoints"], p["seed"] + iters[e]))
+        if self._pool is not None and len(jobs) > 1:
+            return self._pool.map(_final_fit_job, jobs)
+        return [_final_fit_job(j) for j in jobs]
+
+    def __call__(self, max_iter=1000):
+        t0 = t.time()
+        iters = self.run_loop(max_iter)
+        t1 = t.time()
+        fits = self.final_fits(iters)
+        t2 = t.time()
+        self.timings = dict(loop_s=t1 - t0, final_fit_s=t2 - t1, iters=iters)
+        out = []
+        for p, (mean, std, theta) in zip(self._ps, fits):
+            curve = np.concatenate([p["x_grid"][:, None], mean[:, None]], axis=1)
+            et = np.rint(curve[:, [1, 0]]).astype(int)
+            out.append((et, (mean - 1.96 * std, mean + 1.96 * std)) if self.return_std else et)
+        return out
+
+
+
+def make_fit_pool(workers):
+    """Worker processes for the host-side final fits.  Call before anything initialises HIP: the
+    fork server is exec'ed here, and later workers are forked from it (a GPU-free process).
+    Workers run single-threaded BLAS (the matrices are ~100x100; oversubscription is fatal)."""
+    import multiprocessing as mp
+    import os
+    saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["numpy", "scipy.optimize", "scipy.linalg"])
+        pool = ctx.Pool(workers, initializer=_limit_blas_threads)
+        pool.map(_noop, range(workers))  # make sure every worker exists before HIP is initialised
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return pool
+
+
+def _noop(x):
+    return x
+
+
+_BLAS_LIMITER = None
+
+
+def _limit_blas_threads():
+    """Worker initialiser: one BLAS thread per worker (tiny matrices; oversubscription is fatal)."""
+    global _BLAS_LIMITER
+    try:
+        from threadpoolctl import threadpool_limits
+        _BLAS_LIMITER = threadpool_limits(limits=1)  # kept alive: limits hold while it exists
+    except Exception:
+        pass

@@ -1,0 +1,198 @@
+/*
+ * gpet_hip.h -- C ABI of libgpet_hip.so: the MI355X (gfx950) implementation of the
+ * GP posterior-update + posterior-sampling + curve-scoring hot path of
+ * gp_edge_tracing.gpet.GP_Edge_Tracing (reference: jaburke166/gaussian_process_edge_trace).
+ *
+ * The reference is pure Python and has no FFI; each entry point below names the reference
+ * interface (file:line under /root/reference) whose arithmetic it replaces.  The Python host
+ * (gaussian_process_edge_trace_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C, POD only, no exceptions; every call returns a gpet_status (0 = ok);
+ *     gpet_last_error(ctx) gives the message of the last failure on that context.
+ *   - M rows (y), N columns (x) image; Lg = edge_length = x_en - x_st + 1 grid points;
+ *     n = training points (inits + observations); S = posterior samples.
+ *   - a "batch" holds B independent edges that are processed together (blockIdx.y = edge).
+ *     A single edge is a batch of 1.
+ *   - host pointers unless a parameter says "device".  All work is enqueued on the
+ *     context's HIP stream; calls that return data to the host synchronise that stream.
+ *   - handles are not thread-safe individually; distinct contexts may be used from
+ *     distinct host threads.
+ */
+#ifndef GPET_HIP_H
+#define GPET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPET_ABI_VERSION 1
+
+typedef enum gpet_status {
+  GPET_OK = 0,
+  GPET_ERR_BAD_ARG = 1,
+  GPET_ERR_HIP = 2,          /* a HIP runtime call failed (message has the HIP error) */
+  GPET_ERR_NOT_PD = 3,       /* Cholesky met a non-positive pivot (sklearn_gpr.py:306-314 LinAlgError) */
+  GPET_ERR_ITER_CAP = 4,     /* trace did not converge within the iteration cap */
+  GPET_ERR_RANK_CAP = 5,     /* posterior covariance rank exceeded the factor capacity */
+  GPET_ERR_UNSUPPORTED = 6,  /* e.g. Matern nu outside {0.5, 1.5, 2.5} */
+  GPET_ERR_NO_DEVICE = 7,
+  GPET_ERR_STATE = 8         /* call sequence error (stage input not produced yet) */
+} gpet_status;
+
+typedef enum gpet_kernel_type { GPET_KERNEL_RBF = 0, GPET_KERNEL_MATERN = 1 } gpet_kernel_type;
+
+/* Clamped constructor arguments of GP_Edge_Tracing.__init__ (gpet.py:95-158), resolved by the host. */
+typedef struct gpet_params {
+  int32_t kernel_type;   /* gpet_kernel_type                  gpet.py:133,142 */
+  double nu;             /* Matern smoothness (0.5/1.5/2.5)   gpet.py:134,143 */
+  double sigma_f;        /* amplitude                         gpet.py:131,147 */
+  double length_scale;   /*                                   gpet.py:132,151 */
+  double noise_y;        /*                                   gpet.py:98 */
+  int32_t n_samples;     /* S (already clamped)               gpet.py:99 */
+  int32_t n_keep;        /* int(keep_ratio*N_samples) raw     gpet.py:118 */
+  int32_t delta_x;       /* clamped                           gpet.py:105 */
+  int32_t pixel_thresh;  /* clamped                           gpet.py:103 */
+  double score_thresh;   /* clamped initial value             gpet.py:104 */
+  int32_t fix_endpoints; /*                                   gpet.py:108,161 */
+  int32_t x_st, x_en;    /* from the UNSORTED init            gpet.py:96 */
+  int32_t n_init;        /* rows of init                      gpet.py:112 */
+  int32_t obs_cap;       /* capacity for observations (>= any obs set passed later) */
+  int32_t factor_cap;    /* max rank kept by the eigen-factor sampler (0 = library default) */
+  int32_t z_cols;        /* normal columns stored per sample (0 = default: factor_cap; Lg = full stream) */
+  double jitter;         /* GPR alpha, 1e-6                    gpet.py:155 */
+} gpet_params;
+
+/* Named per-edge device buffers readable/writable through gpet_batch_read/_write (tests, injection). */
+typedef enum gpet_buf {
+  GPET_BUF_X_TRAIN = 0,   /* f64 [n]        sorted training x             gpet.py:212-223 */
+  GPET_BUF_Y_TRAIN = 1,   /* f64 [n]        y/y_s - mean                  sklearn_gpr.py:227 */
+  GPET_BUF_CHOL = 2,      /* f64 [n_cap*n_cap] row-major, lower = L       sklearn_gpr.py:307 */
+  GPET_BUF_ALPHA = 3,     /* f64 [n]                                       sklearn_gpr.py:316 */
+  GPET_BUF_MEAN = 4,      /* f64 [Lg]       posterior mean (scaled units)  sklearn_gpr.py:382-385 */
+  GPET_BUF_STD = 5,       /* f64 [Lg]                                      sklearn_gpr.py:414-436 */
+  GPET_BUF_COV = 6,       /* f64 [Lg*Lg]                                   sklearn_gpr.py:398-403 */
+  GPET_BUF_FACTOR = 7,    /* f64 [rows*Lg]  rows of sqrt(s)*v              numpy mvn via sklearn_gpr.py:464 */
+  GPET_BUF_EIGVALS = 8,   /* f64 [factor rows]                             */
+  GPET_BUF_NORMALS = 9,   /* f64 [S*z_cols] standard normals, row = sample sklearn_gpr.py:464 */
+  GPET_BUF_SAMPLES = 10,  /* f64 [S*Lg]     row = sample, pixel units      gpet.py:260-261 */
+  GPET_BUF_COSTS = 11,    /* f64 [S]                                       gpet.py:438-440 */
+  GPET_BUF_BEST_IDX = 12, /* i32 [n_keep]                                  gpet.py:443 */
+  GPET_BUF_BEST_COSTS = 13, /* f64 [n_keep]                                gpet.py:445 */
+  GPET_BUF_SCALARS = 14,  /* gpet_scalars                                  */
+  GPET_BUF_OBS = 15,      /* i64 [n_obs*2] xy                              gpet.py:857 */
+  GPET_BUF_KDE = 16,      /* f32 [M*N]      normalised curve KDE           gpet.py:648 */
+  GPET_BUF_GRAD_KDE = 17, /* f32 [M*N]      normalised gradient KDE        gpet.py:127 */
+  GPET_BUF_GRAD = 18,     /* f32 [M*N]      normalised gradient image      gpet.py:97 */
+  GPET_BUF_NOISE_W = 19   /* f64 [n]        per-point noise weights        gpet.py:209-213 */
+} gpet_buf;
+
+/* Per-edge scalar state kept on the device (GPET_BUF_SCALARS). */
+typedef struct gpet_scalars {
+  double y_s;          /* std(y)+1                              gpet.py:228 */
+  double amp;          /* sigma_f^2 / y_s^2                     gpet.py:230 */
+  double y_mean;       /* _y_train_mean                         sklearn_gpr.py:222 */
+  double y_std;        /* _y_train_std                          sklearn_gpr.py:223 */
+  double score_thresh; /* persists across iterations            gpet.py:595 */
+  double lml;          /* reserved */
+  int32_t n;           /* training points of the last fit */
+  int32_t n_obs;       /* current observation count */
+  int32_t rank;        /* rows of the factor */
+  int32_t status;      /* gpet_status raised on the device */
+  int32_t iter;        /* iterations done                       gpet.py:865 */
+  int32_t done;        /* n_obs >= algo_thresh                  gpet.py:829 */
+  int32_t n_removed;   /* curve points outside the image        gpet.py:498-500 */
+  int32_t reserved;
+} gpet_scalars;
+
+typedef struct gpet_ctx gpet_ctx;
+typedef struct gpet_batch gpet_batch;
+
+/* ---- context ------------------------------------------------------------------------ */
+int gpet_abi_version(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the library create its own. */
+int gpet_ctx_create(int device, void* stream, gpet_ctx** out);
+void gpet_ctx_destroy(gpet_ctx* ctx);
+const char* gpet_last_error(const gpet_ctx* ctx);
+int gpet_sync(gpet_ctx* ctx);
+void* gpet_ctx_stream(gpet_ctx* ctx);
+/* hipEvent timing on the context's stream (bench.py roofline leg). */
+int gpet_timer_start(gpet_ctx* ctx);
+int gpet_timer_stop_ms(gpet_ctx* ctx, float* ms);
+
+/* ---- a1: gpet_utils.comp_grad_img + normalise (gpet_utils.py:65-119) ------------------ */
+/* img f64 [M*N], kern f64 [kh*kw] (host); out f32 [M*N] (host).  True convolution with
+ * clamp-to-edge padding, negatives -> 0, float32 min-max normalisation. */
+int gpet_grad_image(gpet_ctx* ctx, const double* img, int M, int N, const double* kern, int kh, int kw,
+                    float* out);
+/* gpet_utils.normalise(img, (0,1)) for an f32 image (gpet.py:97): out f32 [count] (host). */
+int gpet_normalise_f32(gpet_ctx* ctx, const float* img, size_t count, float* out);
+
+/* ---- batch of edges (GP_Edge_Tracing.__init__, gpet.py:95-178) ------------------------- */
+/* grad: B pointers (host memory) to f32 [M*N] gradient images as the user passes them; the
+ * library re-normalises them (gpet.py:97).  If share_image != 0 only grad[0] is used for all
+ * edges.  params: B structs.  init_xy: B pointers to i64 [n_init*2], already sorted by x. */
+int gpet_batch_create(gpet_ctx* ctx, int B, int M, int N, const float* const* grad, int share_image,
+                      const gpet_params* params, const int64_t* const* init_xy, gpet_batch** out);
+void gpet_batch_destroy(gpet_batch* b);
+int gpet_batch_size(const gpet_batch* b);
+/* out[0..count): Lg, S, n_keep, n_cap, factor_cap, z_cols, factor_rows_cap, n_bins, obs_cap, algo_thresh */
+int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count);
+
+/* Back to the state right after gpet_batch_create: no observations, initial score threshold,
+ * iteration counter 0 (a GP_Edge_Tracing instance is single-use in the reference; benches re-run). */
+int gpet_batch_reset(gpet_batch* b);
+
+/* set / get the observation set (xy int64) of edge e (gpet.py:100,820,857). */
+int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs);
+int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes);
+/* Writable: FACTOR (rows = factor rows; marks the factor as injected so gpet_gp_factor leaves
+ * it alone), NORMALS, SAMPLES, COSTS, KDE, GRAD_KDE, SCALARS. */
+int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t bytes, int rows);
+int gpet_batch_clear_injected_factor(gpet_batch* b, int e);
+
+/* ---- a2-a5: fit_predict_GP not-converged, deterministic part -------------------------- */
+/* gpet.py:209-231 + sklearn_gpr.py:221-227,304-320 (fit) + :381-436 (predict mean/std/cov).
+ * want_cov: also materialise the Lg x Lg covariance. */
+int gpet_gp_fit_predict(gpet_batch* b, int want_cov);
+
+/* ---- a6: sample_y (sklearn_gpr.py:440-473) --------------------------------------------- */
+/* Factor the posterior covariance into rows sqrt(s_k) v_k (k by descending s_k), the object
+ * numpy's legacy multivariate_normal builds from LAPACK SVD.  Eigenvector signs follow the
+ * library convention: sum_j row[j] / (j + 1) >= 0 (LAPACK's are implementation-defined). */
+int gpet_gp_factor(gpet_batch* b);
+/* Fill the normals with RandomState(seed[e]).standard_normal((S, Lg)) (first z_cols columns
+ * of every row are stored).  seeds: B values. */
+int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds);
+/* samples[s, :] = y_s * (Z[s, :rows] @ factor + mean)            (gpet.py:260-261) */
+int gpet_gp_sample(gpet_batch* b);
+
+/* ---- a7: get_best_curves / cost_funct (gpet.py:371-451) -------------------------------- */
+int gpet_score_curves(gpet_batch* b);
+
+/* ---- f1: get_best_pixels (gpet.py:455-662) --------------------------------------------- */
+int gpet_select_pixels(gpet_batch* b);
+/* Pixel scoring / threshold decay / per-bin argmax only (gpet.py:532-618), on whatever curve KDE
+ * is currently in GPET_BUF_KDE (tests inject the reference's). */
+int gpet_select_pixels_only(gpet_batch* b);
+
+/* ---- a8: the outer loop (gpet.py:829-870) ---------------------------------------------- */
+/* Runs up to max_iters iterations of fit->factor->normals->sample->score->pixels for every
+ * edge that is not done; seed of iteration k (0-based) of edge e is base_seed[e] + k + 1
+ * (gpet.py:839).  Returns the number of edges still not done in *n_active. */
+int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Enqueue one stage `reps` times between two hipEvents on the context's stream and return the
+ * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
+ * GEMM, 4 scoring+top-k, 5 curve KDE.  (bench.py's roofline leg; leaves the state as-is.) */
+int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPET_HIP_H */

@@ -1,0 +1,114 @@
+"""GPU parity of pixel selection (f1) and of the whole device-resident loop (a8) vs the
+CPU oracle and the reference-generated fixtures."""
+import numpy as np
+import pytest
+
+from oracle import gpet_oracle as orc
+from tests.test_oracle_vs_golden import CTOR, STAGES, TRACES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gaussian_process_edge_trace_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def ctx(amd):
+    return amd._lib.Context(0)
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_gradient_kde(amd, ctx, golden, name):
+    """ctor gradient KDE (gpet.py:127): float32-normalised map vs the reference (stand-in KDE)."""
+    g = golden(name)
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx)
+    gk = tr._batch.read(amd._lib.BUF_GRAD_KDE)
+    ref = g["ref_grad_kde"]
+    # direct 9x9 convolution vs the oracle's scipy.signal.convolve: a few float32 ulps
+    np.testing.assert_allclose(gk, ref, rtol=0, atol=4e-7)
+    assert np.mean(gk != ref) < 0.02
+
+
+@pytest.mark.parametrize("name", STAGES)
+def test_curve_kde_and_pixel_selection(amd, ctx, golden, name):
+    """Reference samples in -> device scoring, KDE, thresholding, binning, argmax ->
+    the reference's new observation set, bit-exact, and its decayed score threshold."""
+    g = golden(name)
+    L = amd._lib
+    ref = g["ref_samples_head"]
+    if ref.shape[1] != int(g["ref_scalars"][2]):
+        pytest.skip("fixture keeps only a head of the samples")
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, g["in_obs"])
+    b.write(L.BUF_GRAD_KDE, g["ref_grad_kde"])  # pin the gradient KDE to the reference's
+    b.write(L.BUF_SAMPLES, np.ascontiguousarray(ref.T))
+    b.score()
+    b.select_pixels()
+    kde = b.read(L.BUF_KDE)
+    np.testing.assert_allclose(kde, g["ref_kde_arr"], rtol=0, atol=4e-7)
+    fobs = b.read(L.BUF_OBS)
+    assert np.array_equal(fobs, g["ref_fobs"])
+    s = b.scalars()
+    assert s.score_thresh == float(g["ref_score_thresh_out"])
+    assert s.iter == 1
+
+
+def test_pixel_selection_500_from_reference_kde(amd, ctx, golden):
+    """500x500: inject the reference's KDE array and previous observations; the device's
+    scoring / threshold decay / per-bin argmax must reproduce the reference's 55 pixels."""
+    g = golden("stage_rbf500")
+    L = amd._lib
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR["stage_rbf500"], _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, g["in_obs"])
+    b.write(L.BUF_GRAD_KDE, g["ref_grad_kde"])
+    b.write(L.BUF_KDE, g["ref_kde_arr"])
+    # run only the pixel stage on the injected KDE
+    rc = b.lib.gpet_select_pixels_only(b.h)
+    b.ctx.check(rc)
+    assert np.array_equal(b.read(L.BUF_OBS), g["ref_fobs"])
+    assert b.scalars().score_thresh == float(g["ref_score_thresh_out"])
+
+
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_mat128", "trace_rbf500"])
+def test_full_trace_vs_oracle(amd, ctx, golden, name):
+    """Whole trace on the device vs the oracle run with the library's eigenvector sign
+    convention: observation sets per iteration, iteration count and edge trace bit-exact."""
+    g = golden(name)
+    stage = TRACES[name]
+    grad = golden(stage)["ref_grad"]
+    kw = dict(CTOR[stage])
+    rec = []
+    et_o, ci_o, info = orc.trace(g["in_init"], grad, record=rec, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, _ctx=ctx)
+    et, (all_samples, all_obs, curves) = tr(return_lines=True)
+    assert tr._n_iter == info["n_iter"]
+    for i, r in enumerate(rec):
+        assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
+    assert np.array_equal(et, et_o)
+    assert et.shape == g["ref_edge_trace"].shape and et.dtype == g["ref_edge_trace"].dtype
+    kw["return_std"] = True
+    tr2 = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, _ctx=ctx)
+    et2, ci = tr2()
+    assert np.array_equal(et2, et)
+    np.testing.assert_allclose(ci[0], ci_o[0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ci[1], ci_o[1], rtol=1e-6, atol=1e-6)
+
+
+def test_trace_quality_band(amd, ctx):
+    """Trace quality vs ground truth on a synthetic image where the reference algorithm itself is
+    stable across random draws (image seed 3: oracle MSE 39-52 over sign conventions and seeds;
+    image seed 1 swings between 692 and 8443 in the reference too, so it is no quality gate)."""
+    img, truth = orc.synth_sinusoid_image(500, 3)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    tr = amd.GP_Edge_Tracing(init, grad, **CTOR["stage_rbf500"], _ctx=ctx)
+    et = tr()
+    assert np.array_equal(et[:, 1], np.arange(500))
+    assert amd.gpet_utils.trace_MSE(et, truth) < 150.0
+    assert amd.gpet_utils.trace_dicecoef(et, truth) > 0.97
+    assert 8 <= tr._n_iter <= 40
