@@ -72,6 +72,57 @@ def lml_and_grad(theta, xs, ys, w, kernel_type, nu, jitter=1e-6):
     return lml, g
 
 
+BOUNDS = np.log(np.array([[0.01, 1e3], [0.1, 100.0], [1e-18, 1.0]]))  # gpet.py:246-248
+
+
+def prepare(init_sorted, obs_xy, x_grid, fix_endpoints):
+    """Training set of the converged branch: sorted, standardised twice (gpet.py:235-238 then
+    sklearn_gpr.py:229-234), with the transforms needed to map predictions back."""
+    pts = np.concatenate([np.asarray(init_sorted).reshape(-1, 2), np.asarray(obs_xy).reshape(-1, 2)], axis=0)
+    w = np.concatenate([np.full(len(init_sorted), 1e-7 if fix_endpoints else 0.5), np.ones(len(obs_xy))])
+    order = np.argsort(pts[:, 0])
+    pts, w = pts[order], w[order]
+    x = pts[:, 0].astype(np.float64)
+    y = pts[:, 1].astype(np.float64)
+    y_m, y_s = np.mean(y), np.std(y)
+    ys = (y - y_m) / y_s
+    X_m, X_s = np.mean(x), np.std(x)
+    xs = (x - X_m) / X_s
+    xg = np.asarray(x_grid, dtype=np.float64)
+    if xs.shape[0] == xg.shape[0]:  # sklearn_gpr.py:673-677
+        w = np.zeros_like(w)
+    m2, s2 = float(np.mean(ys)), float(np.std(ys))
+    s2 = 1.0 if s2 == 0.0 else s2
+    return dict(xs=xs, yt=(ys - m2) / s2, w=w, y_m=y_m, y_s=y_s, X_m=X_m, X_s=X_s, m2=m2, s2=s2, xg=xg)
+
+
+def start_points(noise_y, seed, n_restarts=12):
+    """theta of the kernel (gpet.py:244-245) + log-uniform restarts (sklearn_gpr.py:283-288)."""
+    th = [np.log(np.array([5.0, 5.0, float(noise_y)]))]
+    if n_restarts > 0:
+        u = np.random.RandomState(seed).uniform(size=(n_restarts, 3))
+        th += [BOUNDS[:, 0] + (BOUNDS[:, 1] - BOUNDS[:, 0]) * u[r] for r in range(n_restarts)]
+    return th
+
+
+def finish(prep, theta, kernel_type, nu):
+    """Posterior mean (pixels) and std (standardised units, gpet.py:266) at the optimum."""
+    c, ell, nl = np.exp(theta)
+    xs, yt, w = prep["xs"], prep["yt"], prep["w"]
+    n = xs.shape[0]
+    K = c * _corr(kernel_type, nu, xs, xs, ell) + np.diag(nl * w)
+    K[np.diag_indices(n)] += 1e-6
+    L = scipy.linalg.cholesky(K, lower=True, check_finite=False)
+    alpha = scipy.linalg.cho_solve((L, True), yt, check_finite=False)
+    xq = (prep["xg"] - prep["X_m"]) / prep["X_s"]
+    Kt = c * _corr(kernel_type, nu, xq, xs, ell)
+    mean = prep["s2"] * (Kt @ alpha) + prep["m2"]
+    V = scipy.linalg.solve_triangular(L, Kt.T, lower=True, check_finite=False)
+    var = np.full(xq.shape[0], c) - np.einsum("ij,ji->i", V.T, V)
+    var[var < 0] = 0.0
+    return prep["y_s"] * mean + prep["y_m"], np.sqrt(var * prep["s2"] ** 2)
+
+
 def converged_fit_predict(init_sorted, obs_xy, x_grid, kernel_type, nu, noise_y, fix_endpoints, seed,
                           n_restarts=12):
     """Returns (y_mean in pixels, y_std in standardised units -- the reference does not rescale

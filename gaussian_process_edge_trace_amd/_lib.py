@@ -77,6 +77,8 @@ SYMBOLS = {
     "gpet_score_curves": (C.c_int, [_P]),
     "gpet_select_pixels": (C.c_int, [_P]),
     "gpet_select_pixels_only": (C.c_int, [_P]),
+    "gpet_final_set_training": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
+    "gpet_lml_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -246,6 +248,21 @@ class Batch:
         ms = C.c_float()
         self.ctx.check(self.lib.gpet_profile_stage(self.h, int(stage), int(reps), C.byref(ms)))
         return ms.value
+
+    def final_set_training(self, e, xs, ys, w):
+        xs, ys, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (xs, ys, w))
+        self.ctx.check(self.lib.gpet_final_set_training(self.h, e, xs.ctypes.data, ys.ctypes.data, w.ctypes.data,
+                                                        xs.shape[0]))
+
+    def lml_batch(self, edge_of, theta):
+        edge_of = np.ascontiguousarray(edge_of, dtype=np.int32)
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, 3)
+        P = theta.shape[0]
+        f = np.empty(P)
+        g = np.empty((P, 3))
+        self.ctx.check(self.lib.gpet_lml_batch(self.h, P, edge_of.ctypes.data, theta.ctypes.data, f.ctypes.data,
+                                               g.ctypes.data))
+        return f, g
 
     def select_pixels(self):
         self.ctx.check(self.lib.gpet_select_pixels(self.h))

@@ -34,6 +34,10 @@ struct gpet_batch {
   unsigned int* d_seeds = nullptr;
   unsigned int* d_minmax = nullptr;
   int share_image = 0;
+  // converged-fit scratch (grown on demand)
+  int lml_cap = 0;
+  int* d_edge_of = nullptr;
+  double *d_theta = nullptr, *d_f = nullptr, *d_g = nullptr;
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
@@ -98,7 +102,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.theta = cv.take<double>(rc);
   E.order = cv.take<int>(rc);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
-  E.Z = cv.take<double>(S * (size_t)E.z_cols);
+  E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
   E.Y = cv.take<double>(S * Lg);
   E.costs = cv.take<double>(S);
   E.best_costs = cv.take<double>((size_t)E.n_keep + 1);
@@ -112,6 +116,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.mm = cv.take<unsigned int>(4);
   E.binbest = cv.take<unsigned long long>((size_t)E.n_bins);
   E.binarg = cv.take<long long>((size_t)E.n_bins);
+  E.fin_x = cv.take<double>(nc);
+  E.fin_y = cv.take<double>(nc);
+  E.fin_w = cv.take<double>(nc);
   if (own_image) {
     E.grad = cv.take<float>(px);
     E.grad_kde = cv.take<float>(px);
@@ -284,12 +291,14 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     E.n_bins = (int)rint((double)(N - 1 - p.x_st) / (double)p.delta_x) - E.bin_lo + 2;
     E.obs_cap = p.obs_cap > E.n_bins ? p.obs_cap : E.n_bins;
     E.n_cap = E.n_init + E.obs_cap;
-    E.r_cap = p.factor_cap > 0 ? p.factor_cap : 128;
+    E.r_cap = p.factor_cap > 0 ? p.factor_cap : 96;  // <= 96: the LDS-resident Jacobi path
     if (E.r_cap > Lg) E.r_cap = Lg;
     E.z_cols = p.z_cols > 0 ? p.z_cols : E.r_cap;
     if (E.z_cols > Lg) E.z_cols = Lg;
     if (E.z_cols < E.r_cap) E.r_cap = E.z_cols;
     E.a_rows_cap = (E.z_cols >= Lg) ? Lg : E.r_cap;
+    // ring of pre-generated normals; full-stream mode (z_cols == Lg) is for tests: keep it small
+    E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : 16;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
     E.fix_endpoints = p.fix_endpoints;
@@ -308,6 +317,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     if (E.n_cap > bd.n_cap) bd.n_cap = E.n_cap;
     if (E.n_bins > bd.n_bins) bd.n_bins = E.n_bins;
     if (E.obs_cap > bd.obs_cap) bd.obs_cap = E.obs_cap;
+    if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
   }
   b->bd = bd;
   // measure, allocate, carve
@@ -386,6 +396,10 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_edges) (void)hipFree(b->d_edges);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->d_edge_of) (void)hipFree(b->d_edge_of);
+  if (b->d_theta) (void)hipFree(b->d_theta);
+  if (b->d_f) (void)hipFree(b->d_f);
+  if (b->d_g) (void)hipFree(b->d_g);
   delete b;
 }
 
@@ -461,7 +475,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
     case GPET_BUF_COV: src = E.cov; avail = Lg * Lg * 8; break;
     case GPET_BUF_FACTOR: src = E.A; avail = (size_t)s.rank * Lg * 8; break;
     case GPET_BUF_EIGVALS: src = E.theta; avail = (size_t)s.rank * 8; break;
-    case GPET_BUF_NORMALS: src = E.Z; avail = (size_t)E.S * E.z_cols * 8; break;
+    case GPET_BUF_NORMALS: src = E.Z + (size_t)(s.iter % E.z_ring) * E.S * E.z_cols; avail = (size_t)E.S * E.z_cols * 8; break;
     case GPET_BUF_SAMPLES: src = E.Y; avail = (size_t)E.S * Lg * 8; break;
     case GPET_BUF_COSTS: src = E.costs; avail = (size_t)E.S * 8; break;
     case GPET_BUF_BEST_IDX: src = E.best_idx; avail = (size_t)E.n_keep * 4; break;
@@ -532,7 +546,15 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
       b->have_factor = true;
       break;
     }
-    case GPET_BUF_NORMALS: dst = E.Z; cap = (size_t)E.S * E.z_cols * 8; b->have_normals = true; break;
+    case GPET_BUF_NORMALS: {
+      gpet_scalars s;
+      int rc = read_scalars(b, e, &s);
+      if (rc) return rc;
+      dst = E.Z + (size_t)(s.iter % E.z_ring) * E.S * E.z_cols;
+      cap = (size_t)E.S * E.z_cols * 8;
+      b->have_normals = true;
+      break;
+    }
     case GPET_BUF_SAMPLES: dst = E.Y; cap = (size_t)E.S * Lg * 8; b->have_samples = true; break;
     case GPET_BUF_GRAD_KDE: dst = (void*)E.grad_kde; cap = px * 4; break;
     case GPET_BUF_KDE: dst = E.kde; cap = px * 4; break;
@@ -582,7 +604,7 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0));
+  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, 1));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->have_normals = true;
   return GPET_OK;
@@ -646,7 +668,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
     switch (stage) {
       case 0: HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1)); break;
       case 1: HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd)); break;
-      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1)); break;
+      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, b->bd.z_ring)); break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0)); break;
@@ -659,6 +681,54 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *ms_per_rep = ms / (float)reps;
   return check_device_status(b);
+}
+
+int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n) {
+  if (!b || e < 0 || e >= b->B || !xs || !ys || !w || n < 1) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  EdgeDev& E = b->h_edges[e];
+  if (n > E.n_cap) return fail(c, GPET_ERR_BAD_ARG, "final fit: n=%d exceeds n_cap=%d", n, E.n_cap);
+  if (n > 128) return fail(c, GPET_ERR_UNSUPPORTED, "final fit on the device needs n <= 128 (got %d)", n);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(E.fin_x, xs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(E.fin_y, ys, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(E.fin_w, w, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  E.fin_n = n;
+  HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out) {
+  if (!b || P < 1 || !edge_of || !theta || !f_out || !g_out) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n_max = 0;
+  for (int i = 0; i < P; ++i) {
+    if (edge_of[i] < 0 || edge_of[i] >= b->B) return fail(c, GPET_ERR_BAD_ARG, "gpet_lml_batch: bad edge index");
+    const int n = b->h_edges[edge_of[i]].fin_n;
+    if (n < 1) return fail(c, GPET_ERR_STATE, "gpet_lml_batch before gpet_final_set_training (edge %d)", edge_of[i]);
+    if (n > n_max) n_max = n;
+  }
+  if (P > b->lml_cap) {
+    if (b->d_edge_of) (void)hipFree(b->d_edge_of);
+    if (b->d_theta) (void)hipFree(b->d_theta);
+    if (b->d_f) (void)hipFree(b->d_f);
+    if (b->d_g) (void)hipFree(b->d_g);
+    const int cap = P * 2;
+    HIPCHK(c, hipMalloc(&b->d_edge_of, sizeof(int) * cap));
+    HIPCHK(c, hipMalloc(&b->d_theta, sizeof(double) * 3 * cap));
+    HIPCHK(c, hipMalloc(&b->d_f, sizeof(double) * cap));
+    HIPCHK(c, hipMalloc(&b->d_g, sizeof(double) * 3 * cap));
+    b->lml_cap = cap;
+  }
+  HIPCHK(c, hipMemcpyAsync(b->d_edge_of, edge_of, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b->d_theta, theta, sizeof(double) * 3 * P, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_lml(c->stream, b->d_edges, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g));
+  HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
 }
 
 int gpet_select_pixels_only(gpet_batch* b) {
@@ -679,10 +749,15 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
   for (int it = 0; it < max_iters; ++it) {
-    // every kernel skips edges whose `done` flag is set, so finished edges cost nothing
+    // every kernel skips edges whose `done` flag is set, so finished edges cost nothing.
+    // Normals: the seeds of upcoming iterations are known (gpet.py:839), so one launch fills
+    // the ring for the next z_ring iterations, one workgroup per (iteration, edge).
+    if (it % b->bd.z_ring == 0) {
+      const int ahead = (max_iters - it) < b->bd.z_ring ? (max_iters - it) : b->bd.z_ring;
+      HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, ahead));
+    }
     HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
     HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
-    HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1));
     HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));

@@ -13,7 +13,7 @@ struct EdgeDev {
   int M, N, x_st, x_en, Lg, S, n_keep, z_cols, r_cap, n_cap, obs_cap, n_init;
   int kernel_type, nu_code;  // nu_code: 0 -> 0.5, 1 -> 1.5, 2 -> 2.5
   int fix_endpoints, delta_x, pixel_thresh, algo_thresh, n_bins, a_rows_cap;
-  int factor_injected, pad0;
+  int factor_injected, z_ring;  // z_ring: slots of pre-generated normals (one per upcoming iteration)
   double sigma_f, length_scale, noise_y, jitter;
   // inputs
   const float* grad;      // [M*N] normalised gradient image (values are f32-exact, gpet.py:97)
@@ -34,7 +34,7 @@ struct EdgeDev {
   double *C, *W, *theta; // [r_cap*r_cap], [r_cap*r_cap], [r_cap]
   int* order;            // [r_cap] eigenvalue order (descending)
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
-  double* Z;             // [S*z_cols]
+  double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
   double* Y;             // [S*Lg]
   double* costs;         // [S]
   double* best_costs;    // [n_keep]
@@ -49,7 +49,8 @@ struct EdgeDev {
   unsigned int* mm;      // [4] ordered-uint min/max of the raw KDE
   unsigned long long* binbest;  // [n_bins] bits of the best score per bin (scores are >= 0)
   long long* binarg;     // [n_bins] order key of the best candidate per bin
-  int bin_lo, pad1;      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
+  int bin_lo, fin_n;     // fin_n: training points of the converged fit
+  double *fin_x, *fin_y, *fin_w;  // [n_cap] standardised training set of the converged fit (gpet.py:235-238)      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
 };
 
 }  // namespace gpet

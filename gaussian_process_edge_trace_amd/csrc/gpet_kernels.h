@@ -5,7 +5,7 @@
 namespace gpet {
 
 struct BatchDims {
-  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap;
+  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap, z_ring;
 };
 
 hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,
@@ -15,11 +15,15 @@ hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, con
                             float* d_out);
 hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov);
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
-hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter);
+hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
+                          int n_ahead);
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+
+hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                      double* d_f, double* d_g);
 
 }  // namespace gpet

@@ -584,6 +584,123 @@ __global__ void __launch_bounds__(1024) k_jacobi(EdgeDev* edges) {
   }
 }
 
+// step 3 (fast path, r_cap <= 96): the same cyclic Jacobi with the Gram matrix and the
+// accumulated rotations resident in LDS (2 * r * (r|1) doubles <= 146 KB of the CU's 160 KB).
+// Row stride ld is odd so that both the column walk (stride ld) and the row walk (stride 1)
+// are bank-conflict free for 8-byte accesses.
+__global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  extern __shared__ double s_mem[];
+  __shared__ double s_red[16];
+  __shared__ double s_c[64], s_s[64];
+  __shared__ int s_p[64], s_q[64];
+  const int r = sc->rank, ldg = E.r_cap;
+  const int ld = r | 1;
+  double* A = s_mem;
+  double* W = s_mem + (size_t)r * ld;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  for (int e = tid; e < r * r; e += bs) {
+    const int i = e / r, j = e - i * r;
+    A[i * ld + j] = E.C[(size_t)i * ldg + j];
+    W[i * ld + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int m = (r + 1) & ~1;
+  const int half = m >> 1;
+  if (r >= 2) {
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < r * r; e += bs) {
+        const int i = e / r, j = e - i * r;
+        const double v = A[i * ld + j];
+        if (i == j) dg += v * v; else off += v * v;
+      }
+      off = block_sum(off, s_red);
+      dg = block_sum(dg, s_red);
+      if (off <= 1e-30 * dg || off == 0.0) break;
+      for (int round = 0; round < m - 1; ++round) {
+        for (int k = tid; k < half; k += bs) {
+          int p, q;
+          if (k == 0) {
+            p = m - 1;
+            q = round;
+          } else {
+            p = (round + k) % (m - 1);
+            q = (round - k + (m - 1)) % (m - 1);
+          }
+          if (p > q) {
+            const int t = p;
+            p = q;
+            q = t;
+          }
+          double c = 1.0, s = 0.0;
+          if (q < r) {
+            const double apq = A[p * ld + q];
+            const double app = A[p * ld + p], aqq = A[q * ld + q];
+            if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
+              const double tau = (aqq - app) / (2.0 * apq);
+              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+              c = 1.0 / sqrt(1.0 + t * t);
+              s = t * c;
+            }
+          } else {
+            q = -1;
+          }
+          s_c[k] = c;
+          s_s[k] = s;
+          s_p[k] = p;
+          s_q[k] = q;
+        }
+        __syncthreads();
+        for (int e = tid; e < half * r; e += bs) {
+          const int k = e / r, i = e - k * r;
+          const int q = s_q[k];
+          const double s = s_s[k];
+          if (q < 0 || s == 0.0) continue;
+          const int p = s_p[k];
+          const double c = s_c[k];
+          const double ap = A[i * ld + p], aq = A[i * ld + q];
+          A[i * ld + p] = c * ap - s * aq;
+          A[i * ld + q] = s * ap + c * aq;
+          const double wp = W[i * ld + p], wq = W[i * ld + q];
+          W[i * ld + p] = c * wp - s * wq;
+          W[i * ld + q] = s * wp + c * wq;
+        }
+        __syncthreads();
+        for (int e = tid; e < half * r; e += bs) {
+          const int k = e / r, j = e - k * r;
+          const int q = s_q[k];
+          const double s = s_s[k];
+          if (q < 0 || s == 0.0) continue;
+          const int p = s_p[k];
+          const double c = s_c[k];
+          const double ap = A[p * ld + j], aq = A[q * ld + j];
+          A[p * ld + j] = c * ap - s * aq;
+          A[q * ld + j] = s * ap + c * aq;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (int k = tid; k < r; k += bs) E.theta[k] = A[k * ld + k];
+  for (int e = tid; e < r * r; e += bs) {
+    const int i = e / r, j = e - i * r;
+    E.W[(size_t)i * ldg + j] = W[i * ld + j];
+  }
+  __syncthreads();
+  for (int k = tid; k < r; k += bs) {
+    const double v = A[k * ld + k];
+    int pos = 0;
+    for (int j = 0; j < r; ++j) {
+      const double u = A[j * ld + j];
+      pos += (u > v) || (u == v && j < k);
+    }
+    E.order[pos] = k;
+  }
+}
+
 // step 4: factor rows  A[k, :] = sum_t W[t, order[k]] * G[t, :]  (= sqrt(s_k) v_k up to sign).
 // Sign convention (LAPACK's is implementation-defined): sum_j A[k, j] / (j + 1) >= 0.
 __global__ void __launch_bounds__(256) k_factor_rows(EdgeDev* edges) {
@@ -625,17 +742,22 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
 }
 
+// blockIdx.x = how many iterations ahead of the edge's current one this stream belongs to: the
+// seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
+// generated by one launch, one workgroup per (iteration, edge).
 __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter) {
 #pragma clang fp contract(off)
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if (sc->done || sc->status != GPET_OK) return;
+  const int iter_idx = sc->iter + (int)blockIdx.x;
+  double* __restrict__ Zs = E.Z + (size_t)(iter_idx % E.z_ring) * ((size_t)E.S * E.z_cols);
   __shared__ unsigned int s_mt[2][624];
   __shared__ int s_cnt[2][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
     // seed of iteration k (0-based) = base + k + 1 (gpet.py:839)
-    unsigned int p = seeds[blockIdx.y] + (add_iter ? (unsigned int)(sc->iter + 1) : 0u);
+    unsigned int p = seeds[blockIdx.y] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);
     s_mt[0][0] = p;
     for (int i = 1; i < 624; ++i) {
       p = 1812433253u * (p ^ (p >> 30)) + (unsigned int)i;
@@ -690,12 +812,12 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
       if (q0 < total) {
         const long long srow = q0 / E.Lg;
         const int colq = (int)(q0 - srow * E.Lg);
-        if (colq < E.z_cols) E.Z[(size_t)srow * E.z_cols + colq] = g0;
+        if (colq < E.z_cols) Zs[(size_t)srow * E.z_cols + colq] = g0;
       }
       if (q0 + 1 < total) {
         const long long srow = (q0 + 1) / E.Lg;
         const int colq = (int)(q0 + 1 - srow * E.Lg);
-        if (colq < E.z_cols) E.Z[(size_t)srow * E.z_cols + colq] = g1;
+        if (colq < E.z_cols) Zs[(size_t)srow * E.z_cols + colq] = g1;
       }
     }
     done_pairs += tot;
@@ -716,6 +838,7 @@ __global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
   const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (s0 >= S || j0 >= Lg) return;
   const int rows = sc->rank;
+  const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
   __shared__ double sz[16][65];  // [k][s]
   __shared__ double sa[16][65];  // [k][j]
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -728,7 +851,7 @@ __global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
     for (int e = threadIdx.x; e < 16 * 64; e += 256) {
       const int kk = e & 15, ss = e >> 4;  // Z is [s][k]: k fastest
       const int k = k0 + kk, s = s0 + ss;
-      sz[kk][ss] = (k < rows && s < S) ? E.Z[(size_t)s * zc + k] : 0.0;
+      sz[kk][ss] = (k < rows && s < S) ? Zs[(size_t)s * zc + k] : 0.0;
     }
     for (int e = threadIdx.x; e < 16 * 64; e += 256) {
       const int jj = e & 63, kk = e >> 6;
@@ -1141,6 +1264,183 @@ __global__ void __launch_bounds__(64) k_pix_select(EdgeDev* edges) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// f2  converged fit: -log marginal likelihood and its gradient wrt theta = log(c, l, noise)
+//     sklearn_gpr.py:512-585 on the standardised training set (gpet.py:235-248).
+//     One workgroup per (edge, restart) problem; L and L^-1 packed-lower in LDS (n <= 128).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, double a, double b, double& R, double& dR) {
+  const double d = a - b;
+  const double D = d * d;
+  if (kernel_type == GPET_KERNEL_RBF) {
+    R = exp(-0.5 * D);
+    dR = R * D;
+    return;
+  }
+  const double r = sqrt(D);
+  if (nu_code == 0) {
+    R = exp(-r);
+    dR = (r > 0.0) ? R * D / r : 0.0;
+  } else if (nu_code == 1) {
+    const double k = r * 1.7320508075688772;
+    R = (1.0 + k) * exp(-k);
+    dR = 3.0 * D * exp(-sqrt(3.0 * D));
+  } else {
+    const double k = r * 2.23606797749979;
+    const double t = sqrt(5.0 * D);
+    R = (1.0 + k + k * k / 3.0) * exp(-k);
+    dR = 5.0 / 3.0 * D * (t + 1.0) * exp(-t);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+                                             double* g_out) {
+  const int pb = blockIdx.x;
+  const EdgeDev E = edges[edge_of[pb]];
+  const int n = E.fin_n;
+  extern __shared__ double s_mem[];
+  __shared__ double s_red[16];
+  __shared__ double s_diag;
+  __shared__ int s_bad;
+  const int np = n * (n + 1) / 2;
+  double* Lp = s_mem;            // packed lower L
+  double* Xp = s_mem + np;       // packed lower L^-1
+  double* sa = s_mem + 2 * np;   // a = x / l
+  double* sy = sa + n;           // y, then z
+  double* sal = sy + n;          // alpha
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
+  for (int i = tid; i < n; i += bs) {
+    sa[i] = E.fin_x[i] / ell;
+    sy[i] = E.fin_y[i];
+  }
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  for (int q = tid; q < np; q += bs) {
+    int i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= q) ++i;
+    while (i * (i + 1) / 2 > q) --i;
+    const int j = q - i * (i + 1) / 2;
+    double v;
+    if (i == j) {
+      v = c + nl * E.fin_w[i];
+      v = v + 1e-6;
+    } else {
+      v = c * corr_fn(E.kernel_type, E.nu_code, sa[i], sa[j]);
+    }
+    Lp[q] = v;
+  }
+  __syncthreads();
+  // Cholesky, left-looking, packed
+  for (int j = 0; j < n; ++j) {
+    const double* rj = Lp + j * (j + 1) / 2;
+    for (int i = j + tid; i < n; i += bs) {
+      double* ri = Lp + i * (i + 1) / 2;
+      double sacc = ri[j];
+      for (int t = 0; t < j; ++t) sacc -= ri[t] * rj[t];
+      if (i == j) s_diag = sacc; else ri[j] = sacc;
+    }
+    __syncthreads();
+    const double d = s_diag;
+    if (!(d > 0.0)) {
+      if (tid == 0) s_bad = 1;
+      break;
+    }
+    const double dj = sqrt(d);
+    for (int i = j + tid; i < n; i += bs) {
+      double* ri = Lp + i * (i + 1) / 2;
+      if (i == j) ri[j] = dj; else ri[j] = ri[j] / dj;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (s_bad) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
+    if (tid == 0) {
+      f_out[pb] = INFINITY;
+      g_out[3 * pb] = g_out[3 * pb + 1] = g_out[3 * pb + 2] = 0.0;
+    }
+    return;
+  }
+  // X = L^-1, one column per thread
+  for (int j = tid; j < n; j += bs) {
+    Xp[j * (j + 1) / 2 + j] = 1.0 / Lp[j * (j + 1) / 2 + j];
+    for (int i = j + 1; i < n; ++i) {
+      const double* ri = Lp + i * (i + 1) / 2;
+      double acc = 0.0;
+      for (int k = j; k < i; ++k) acc += ri[k] * Xp[k * (k + 1) / 2 + j];
+      Xp[i * (i + 1) / 2 + j] = -acc / ri[i];
+    }
+  }
+  double ld = 0.0;
+  for (int i = tid; i < n; i += bs) ld += log(Lp[i * (i + 1) / 2 + i]);
+  const double logdet = block_sum(ld, s_red);  // (contains the barrier after the X columns)
+  // z = X y (in place over a copy), alpha = X^T z
+  for (int i = tid; i < n; i += bs) {
+    const double* xi = Xp + i * (i + 1) / 2;
+    double acc = 0.0;
+    for (int k = 0; k <= i; ++k) acc += xi[k] * sy[k];
+    sal[i] = acc;  // z_i (temporarily in sal)
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += bs) {
+    double acc = 0.0;
+    for (int i = j; i < n; ++i) acc += Xp[i * (i + 1) / 2 + j] * sal[i];
+    sa[j] = acc;  // alpha_j (sa no longer needed as scaled inputs? -> keep a copy below)
+  }
+  __syncthreads();
+  // sa now holds alpha; scaled inputs are recomputed on the fly from E.fin_x
+  double yta = 0.0;
+  for (int i = tid; i < n; i += bs) yta += sy[i] * sa[i];
+  yta = block_sum(yta, s_red);
+  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij
+  double gc = 0.0, gl = 0.0, gn = 0.0;
+  for (int q = tid; q < np; q += bs) {
+    int i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= q) ++i;
+    while (i * (i + 1) / 2 > q) --i;
+    const int j = q - i * (i + 1) / 2;
+    double kinv = 0.0;
+    for (int k = i; k < n; ++k) {
+      const double* xk = Xp + k * (k + 1) / 2;
+      kinv += xk[i] * xk[j];
+    }
+    const double inner = sa[i] * sa[j] - kinv;
+    if (i == j) {
+      gc += inner * c;
+      gn += inner * (nl * E.fin_w[i]);
+    } else {
+      double R, dR;
+      corr_and_dlog(E.kernel_type, E.nu_code, E.fin_x[i] / ell, E.fin_x[j] / ell, R, dR);
+      gc += 2.0 * inner * (c * R);
+      gl += 2.0 * inner * (c * dR);
+    }
+  }
+  gc = block_sum(gc, s_red);
+  gl = block_sum(gl, s_red);
+  gn = block_sum(gn, s_red);
+  if (tid == 0) {
+    const double lml = -0.5 * yta - logdet - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    f_out[pb] = -lml;
+    g_out[3 * pb] = -0.5 * gc;
+    g_out[3 * pb + 1] = -0.5 * gl;
+    g_out[3 * pb + 2] = -0.5 * gn;
+  }
+}
+
+hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                      double* d_f, double* d_g) {
+  (void)hipGetLastError();
+  const size_t lds = ((size_t)n_max * (n_max + 1) + 3 * (size_t)n_max) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_lml, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_lml, dim3(P), dim3(256), lds, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -1187,16 +1487,27 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)bd.Lg * sizeof(double), st, d_edges);
   const int t = cdiv(bd.r_cap, 16);
   hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
-  const int half = (bd.r_cap + 2) / 2;
-  hipLaunchKernelGGL(k_jacobi, dim3(1, B), dim3(1024), (size_t)(2 * half) * sizeof(double) + 2 * half * sizeof(int),
-                     st, d_edges);
+  if (bd.r_cap <= 96) {
+    const size_t lds = (size_t)2 * bd.r_cap * (bd.r_cap | 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges);
+  } else {
+    const int half = (bd.r_cap + 2) / 2;
+    hipLaunchKernelGGL(k_jacobi, dim3(1, B), dim3(1024), (size_t)(2 * half) * sizeof(double) + 2 * half * sizeof(int),
+                       st, d_edges);
+  }
   hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
 }
 
-hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter) {
+hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
+                          int n_ahead) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_mt_normals, dim3(1, B), dim3(256), 0, st, d_edges, d_seeds, add_iter);
+  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter);
   return hipGetLastError();
 }
 

@@ -59,8 +59,22 @@ def resolve_params(init, grad_shape, kernel_options=(1, 3, 3), noise_y=1, obs=np
     return p
 
 
+def auto_factor_cap(p):
+    """Rows kept by the eigen-factor sampler.  The RBF correlation matrix on a unit grid has
+    eigenvalues ~ exp(-(pi k l / N)^2 / 2): they fall below 1e-14 of the largest at
+    k ~ 2.6 N / l, and the posterior covariance cannot have higher rank.  <= 96 rows take the
+    LDS-resident Jacobi path; Matern spectra decay polynomially, so keep every row."""
+    Lg = p["edge_length"]
+    if p["kernel_type"] != "RBF":
+        return Lg
+    est = int(2.6 * Lg / float(p["sigma_l"])) + 12
+    return 0 if est <= 96 else min(Lg, int(est * 1.2))
+
+
 def to_abi_params(p, obs_cap=None, factor_cap=0, z_cols=0):
     """gpet_params (include/gpet_hip.h) from the resolved constructor state."""
+    if not factor_cap:
+        factor_cap = auto_factor_cap(p)
     q = _lib.GpetParams()
     q.kernel_type = _lib.KERNEL_MATERN if p["kernel_type"] == "Matern" else _lib.KERNEL_RBF
     q.nu = float(p["kernel_nu"])
@@ -194,9 +208,13 @@ class GP_Edge_Tracing(object):
         pre_fobs = b.read(_lib.BUF_OBS)
         self.score_thresh = b.scalars().score_thresh
         # final hyper-parameter-optimised fit (gpet.py:874-876), seed = seed + N_iter
-        y_mean_optim, y_std, self._theta = converged_fit_predict(
-            self.init, pre_fobs, self.x_grid, self.kernel_type, self.kernel_nu, self.noise_y, self.fix_endpoints,
-            self.seed + n_iter)
+        if pre_fobs.shape[0] + self.N_inits <= 128:
+            fits, _ = device_final_fits(b, [dict(self._p, seed=self.seed)], [pre_fobs], [n_iter])
+            y_mean_optim, y_std, self._theta = fits[0]
+        else:  # more training points than the LDS-resident LML kernel takes: host objective
+            y_mean_optim, y_std, self._theta = converged_fit_predict(
+                self.init, pre_fobs, self.x_grid, self.kernel_type, self.kernel_nu, self.noise_y,
+                self.fix_endpoints, self.seed + n_iter)
         cred_interval = (y_mean_optim - 1.96 * y_std, y_mean_optim + 1.96 * y_std)
         all_samples.append(y_mean_optim)
         all_obs.append(pre_fobs)
@@ -210,6 +228,36 @@ class GP_Edge_Tracing(object):
         if not return_lines:
             return edge_trace
         return edge_trace, (all_samples, all_obs, iter_optimal_curves)
+
+
+def device_final_fits(batch, ps, obs_list, iters):
+    """Converged fits (gpet.py:874) of many edges at once: scipy's own L-BFGS-B routine is driven in
+    lock step for all (edge, restart) problems and every round of objective evaluations is one
+    batched launch of the LML kernel (gpet_lml_batch).  Returns [(mean, std, theta)] per edge."""
+    from . import _final_fit as ff
+    from ._lbfgsb_lockstep import minimize_many
+
+    preps, x0s, edge_of = [], [], []
+    for e, (p, obs) in enumerate(zip(ps, obs_list)):
+        pr = ff.prepare(p["init"], obs, p["x_grid"], p["fix_endpoints"])
+        preps.append(pr)
+        batch.final_set_training(e, pr["xs"], pr["yt"], pr["w"])
+        th = ff.start_points(p["noise_y"], p["seed"] + iters[e])
+        x0s += th
+        edge_of += [e] * len(th)
+    edge_of = np.asarray(edge_of, dtype=np.int32)
+
+    def eval_batch(idx, X):
+        return batch.lml_batch(edge_of[idx], X)
+
+    X, F, rounds = minimize_many(eval_batch, x0s, ff.BOUNDS)
+    out = []
+    for e, p in enumerate(ps):
+        sel = np.nonzero(edge_of == e)[0]
+        theta = X[sel[int(np.argmin(F[sel]))]]
+        mean, std = ff.finish(preps[e], theta, p["kernel_type"], p["kernel_nu"])
+        out.append((mean, std, theta))
+    return out, rounds
 
 
 def _final_fit_job(args):
@@ -254,7 +302,7 @@ class GP_Edge_Tracing_Batch(object):
     def reset(self):
         self._batch.reset()
 
-    def run_loop(self, max_iter=1000, chunk=4):
+    def run_loop(self, max_iter=1000, chunk=16):
         """The device-resident while-loops of all edges (gpet.py:829-870); returns iterations per edge."""
         b = self._batch
         n_active = self.B
@@ -275,7 +323,10 @@ class GP_Edge_Tracing_Batch(object):
                          p["fix_endpoints"], p["seed"] + iters[e]))
         if self._pool is not None and len(jobs) > 1:
             return self._pool.map(_final_fit_job, jobs)
-        return [_final_fit_job(j) for j in jobs]
+        if all(len(j[1]) + len(j[0]) <= 128 for j in jobs):
+            fits, self._fit_rounds = device_final_fits(b, self._ps, [j[1] for j in jobs], iters)
+            return fits
+        return [_final_fit_job(j) for j in jobs]  # > 128 training points: host objective
 
     def __call__(self, max_iter=1000):
         t0 = t.time()

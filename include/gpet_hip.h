@@ -186,6 +186,16 @@ int gpet_select_pixels_only(gpet_batch* b);
  * (gpet.py:839).  Returns the number of edges still not done in *n_active. */
 int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active);
 
+/* ---- f2: converged fit (gpet.py:232-248; sklearn_gpr.py:254-295, 475-585) ----------------- */
+/* Upload edge e's standardised training set (x, y standardised as gpet.py:235-238 and
+ * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= 128. */
+int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n);
+/* Objective of the reference's L-BFGS-B runs for P problems at once: problem i evaluates
+ * -log_marginal_likelihood and its gradient wrt theta_i = log(constant, length_scale, noise_level)
+ * on edge edge_of[i]'s training set.  theta [P*3], f_out [P], g_out [P*3] (host).  A non-PD
+ * kernel matrix gives f = +inf, g = 0 (sklearn_gpr.py:521-522). */
+int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Enqueue one stage `reps` times between two hipEvents on the context's stream and return the
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample

@@ -112,3 +112,50 @@ def test_trace_quality_band(amd, ctx):
     assert amd.gpet_utils.trace_MSE(et, truth) < 150.0
     assert amd.gpet_utils.trace_dicecoef(et, truth) > 0.97
     assert 8 <= tr._n_iter <= 40
+
+
+def test_lml_kernel_vs_oracle(amd, ctx, golden):
+    """f2: batched -log marginal likelihood + gradient (sklearn_gpr.py:512-585) vs the oracle."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128")]:
+        g = golden(name)
+        grad = golden(stage)["ref_grad"]
+        kw = CTOR[stage]
+        tr = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, _ctx=ctx)
+        last = max(int(k[8:]) for k in g if k.startswith("ref_obs_"))
+        obs = g["ref_obs_%02d" % last]
+        pr = ff.prepare(tr.init, obs, tr.x_grid, tr.fix_endpoints)
+        b = tr._batch
+        b.final_set_training(0, pr["xs"], pr["yt"], pr["w"])
+        rng = np.random.default_rng(0)
+        th = ff.BOUNDS[:, 0] + (ff.BOUNDS[:, 1] - ff.BOUNDS[:, 0]) * rng.uniform(size=(40, 3))
+        th[:, 2] = np.log(rng.uniform(1e-4, 1.0, size=40))  # keep most of them positive definite
+        th[0] = np.log([5.0, 5.0, 1.0])
+        f, gr = b.lml_batch(np.zeros(40, dtype=np.int32), th)
+        for i in range(40):
+            lml, g_o = orc.lml_and_grad(th[i], pr["xs"], pr["yt"], pr["w"], tr.kernel_type, tr.kernel_nu)
+            if not np.isfinite(lml):
+                assert np.isinf(f[i]) and f[i] > 0
+                continue
+            np.testing.assert_allclose(f[i], -lml, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(gr[i], -g_o, rtol=1e-6, atol=1e-6 * (1 + np.abs(g_o).max()))
+
+
+def test_final_fit_matches_reference_theta(amd, ctx, golden):
+    """The converged fit driven in lock step with the device objective lands on the reference's
+    optimum (theta and CI from the reference run, trace_* fixtures, given its observations)."""
+    from gaussian_process_edge_trace_amd.gpet import device_final_fits
+    for name, stage in [("trace_rbf64", "stage_rbf64"), ("trace_mat128", "stage_mat128"),
+                        ("trace_rbf500", "stage_rbf500")]:
+        g = golden(name)
+        grad = golden(stage)["ref_grad"]
+        kw = dict(CTOR[stage])
+        tr = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, _ctx=ctx)
+        n_iter = int(g["ref_n_iter"])
+        obs = g["ref_obs_%02d" % n_iter]
+        fits, rounds = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [n_iter])
+        mean, std, theta = fits[0]
+        np.testing.assert_allclose(theta, g["ref_final_theta"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(mean - 1.96 * std, g["ref_ci_lower"], rtol=1e-5, atol=1e-4)
+        assert np.array_equal(np.rint(mean).astype(int), g["ref_edge_trace"][:, 0])
