@@ -19,31 +19,13 @@ except Exception:  # pragma: no cover
     _HAVE_SETULB = False
 
 
-class _Problem:
-    __slots__ = ("x", "f", "g", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "n_iter", "nfev",
-                 "state", "low", "up", "nbd")
-
-    def __init__(self, x0, bounds, m):
-        n = x0.shape[0]
-        lo, hi = bounds[:, 0], bounds[:, 1]
-        self.x = np.clip(np.array(x0, dtype=np.float64), lo, hi)
-        self.f = 0.0
-        self.g = np.zeros(n, dtype=np.float64)
-        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
-        self.iwa = np.zeros(3 * n, dtype=np.int32)
-        self.task = np.zeros(2, dtype=np.int32)
-        self.ln_task = np.zeros(2, dtype=np.int32)
-        self.lsave = np.zeros(4, dtype=np.int32)
-        self.isave = np.zeros(44, dtype=np.int32)
-        self.dsave = np.zeros(29, dtype=np.float64)
-        self.low = np.where(np.isinf(lo), 0.0, lo).astype(np.float64)
-        self.up = np.where(np.isinf(hi), 0.0, hi).astype(np.float64)
-        code = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}
-        self.nbd = np.array([code[(bool(np.isfinite(a)), bool(np.isfinite(b)))] for a, b in zip(lo, hi)],
-                            dtype=np.int32)
-        self.n_iter = 0
-        self.nfev = 0
-        self.state = "run"  # run | want_fg | done
+def _bound_arrays(bounds):
+    lo, hi = bounds[:, 0], bounds[:, 1]
+    low = np.where(np.isinf(lo), 0.0, lo).astype(np.float64)
+    up = np.where(np.isinf(hi), 0.0, hi).astype(np.float64)
+    code = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}
+    nbd = np.array([code[(bool(np.isfinite(a)), bool(np.isfinite(b)))] for a, b in zip(lo, hi)], dtype=np.int32)
+    return low, up, nbd
 
 
 def minimize_many(eval_batch, x0s, bounds, m=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxiter=15000,
@@ -51,9 +33,13 @@ def minimize_many(eval_batch, x0s, bounds, m=10, ftol=2.2204460492503131e-09, gt
     """Minimise len(x0s) problems that share ``bounds`` (n, 2).
 
     ``eval_batch(idx, X)``: idx = list of problem indices, X = (len(idx), n) points;
-    returns (f (len(idx),), g (len(idx), n)).  Returns (xs (P, n), funs (P,), n_rounds)."""
+    returns (f (len(idx),), g (len(idx), n)).  Returns (xs (P, n), funs (P,), n_rounds).
+    Every problem sees exactly the call sequence ``scipy.optimize.minimize(method='L-BFGS-B',
+    jac=True, bounds=...)`` would issue (same workspace sizes, factr, pgtol, maxls, stopping
+    rules); state lives in row views of a few 2-D arrays so that a step costs one ``setulb`` call."""
     bounds = np.asarray(bounds, dtype=np.float64)
     P = len(x0s)
+    n = bounds.shape[0]
     if not _HAVE_SETULB:  # pragma: no cover - same results, one problem at a time
         import scipy.optimize
         xs, fs = [], []
@@ -66,35 +52,229 @@ def minimize_many(eval_batch, x0s, bounds, m=10, ftol=2.2204460492503131e-09, gt
             fs.append(r.fun)
         return np.array(xs), np.array(fs), -1
     factr = ftol / np.finfo(float).eps
-    probs = [_Problem(np.asarray(x0, dtype=np.float64), bounds, m) for x0 in x0s]
+    low, up, nbd = _bound_arrays(bounds)
+    X = np.clip(np.asarray(x0s, dtype=np.float64).reshape(P, n), bounds[:, 0], bounds[:, 1])
+    G = np.zeros((P, n))
+    WA = np.zeros((P, 2 * m * n + 5 * n + 11 * m * m + 8 * m))
+    IWA = np.zeros((P, 3 * n), dtype=np.int32)
+    TASK = np.zeros((P, 2), dtype=np.int32)
+    LNT = np.zeros((P, 2), dtype=np.int32)
+    LSAVE = np.zeros((P, 4), dtype=np.int32)
+    ISAVE = np.zeros((P, 44), dtype=np.int32)
+    DSAVE = np.zeros((P, 29))
+    rows = [(X[i], G[i], WA[i], IWA[i], TASK[i], LSAVE[i], ISAVE[i], DSAVE[i], LNT[i]) for i in range(P)]
+    F = [0.0] * P
+    n_iter = [0] * P
+    nfev = [0] * P
+    setulb = _lbfgsb.setulb
+    active = list(range(P))
     rounds = 0
-    while True:
+    while active:
         pending = []
-        for i, p in enumerate(probs):
-            while p.state == "run":
-                _lbfgsb.setulb(m, p.x, p.low, p.up, p.nbd, p.f, p.g, factr, gtol, p.wa, p.iwa, p.task, p.lsave,
-                               p.isave, p.dsave, maxls, p.ln_task)
-                if p.task[0] == 3:
-                    p.state = "want_fg"
-                elif p.task[0] == 1:
-                    p.n_iter += 1
-                    if p.n_iter >= maxiter:
-                        p.task[0], p.task[1] = 5, 504
-                    elif p.nfev > maxfun:
-                        p.task[0], p.task[1] = 5, 502
-                else:
-                    p.state = "done"
-            if p.state == "want_fg":
-                pending.append(i)
+        for i in active:
+            x, g, wa, iwa, task, lsave, isave, dsave, lnt = rows[i]
+            f = F[i]
+            while True:
+                setulb(m, x, low, up, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, lnt)
+                t0 = task[0]
+                if t0 == 3:
+                    pending.append(i)
+                    break
+                if t0 == 1:
+                    n_iter[i] += 1
+                    if n_iter[i] >= maxiter:
+                        task[0], task[1] = 5, 504
+                    elif nfev[i] > maxfun:
+                        task[0], task[1] = 5, 502
+                    continue
+                break
         if not pending:
             break
-        X = np.stack([probs[i].x for i in pending])
-        f, g = eval_batch(pending, X)
+        idx = np.asarray(pending, dtype=np.intp)
+        f, g = eval_batch(pending, X[idx])
+        G[idx] = g
+        fl = np.asarray(f, dtype=np.float64).tolist()
         for k, i in enumerate(pending):
-            p = probs[i]
-            p.f = float(f[k])
-            p.g = np.array(g[k], dtype=np.float64)
-            p.nfev += 1
-            p.state = "run"
+            F[i] = fl[k]
+            nfev[i] += 1
+        active = pending
         rounds += 1
-    return np.stack([p.x for p in probs]), np.array([p.f for p in probs]), rounds
+    return X, np.asarray(F), rounds
+
+
+# ---------------------------------------------------------------------------------------------
+# The same lock-step scheme spread over worker processes.  A setulb step costs ~5-7 us of real
+# L-BFGS-B arithmetic and holds the GIL, so thousands of problems are advanced by W processes
+# that share X / F / G / state arrays with the parent; the parent only runs the batched GPU
+# objective between two barrier waits per round.
+# ---------------------------------------------------------------------------------------------
+def _attach(name, shape, dtype):
+    from multiprocessing import shared_memory
+    shm = shared_memory.SharedMemory(name=name)
+    return shm, np.ndarray(shape, dtype=dtype, buffer=shm.buf)
+
+
+def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
+    try:
+        from threadpoolctl import threadpool_limits
+        _lim = threadpool_limits(limits=1)  # noqa: F841  (kept alive)
+    except Exception:
+        pass
+    shms = []
+    arrs = {}
+    for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
+                                 S=((pmax,), np.int8), C=((4,), np.int64)).items():
+        shm, a = _attach(names[key], shape, dt)
+        shms.append(shm)
+        arrs[key] = a
+    X, Fs, G, S, C = arrs["X"], arrs["F"], arrs["G"], arrs["S"], arrs["C"]
+    setulb = _lbfgsb.setulb
+    while True:
+        msg = conn.recv()
+        if msg[0] == "quit":
+            break
+        _, P, bounds, ftol, gtol, maxiter, maxfun, maxls = msg
+        factr = ftol / np.finfo(float).eps
+        low, up, nbd = _bound_arrays(bounds)
+        base, rem = divmod(P, W)
+        lo = wid * base + min(wid, rem)
+        hi = lo + base + (1 if wid < rem else 0)
+        cnt = hi - lo
+        WA = np.zeros((cnt, 2 * m * n + 5 * n + 11 * m * m + 8 * m))
+        IWA = np.zeros((cnt, 3 * n), dtype=np.int32)
+        TASK = np.zeros((cnt, 2), dtype=np.int32)
+        LNT = np.zeros((cnt, 2), dtype=np.int32)
+        LSAVE = np.zeros((cnt, 4), dtype=np.int32)
+        ISAVE = np.zeros((cnt, 44), dtype=np.int32)
+        DSAVE = np.zeros((cnt, 29))
+        rows = {i: (X[i], G[i], WA[i - lo], IWA[i - lo], TASK[i - lo], LSAVE[i - lo], ISAVE[i - lo], DSAVE[i - lo],
+                    LNT[i - lo]) for i in range(lo, hi)}
+        n_iter = dict.fromkeys(range(lo, hi), 0)
+        nfev = dict.fromkeys(range(lo, hi), 0)
+        first = True
+        active = list(range(lo, hi))
+        while True:
+            pending = []
+            for i in active:
+                x, g, wa, iwa, task, lsave, isave, dsave, lnt = rows[i]
+                f = 0.0 if first else float(Fs[i])
+                while True:
+                    setulb(m, x, low, up, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, lnt)
+                    t0 = task[0]
+                    if t0 == 3:
+                        pending.append(i)
+                        break
+                    if t0 == 1:
+                        n_iter[i] += 1
+                        if n_iter[i] >= maxiter:
+                            task[0], task[1] = 5, 504
+                        elif nfev[i] > maxfun:
+                            task[0], task[1] = 5, 502
+                        continue
+                    S[i] = 2
+                    break
+            for i in pending:
+                S[i] = 1
+                nfev[i] += 1
+            first = False
+            barrier.wait()  # parent may now collect the pending points
+            barrier.wait()  # parent has written F / G (or decided to stop)
+            if C[0] == 0:
+                break
+            active = pending
+    for shm in shms:
+        shm.close()
+
+
+class LockstepFarm:
+    """W worker processes advancing L-BFGS-B problems in lock step (see minimize_many).
+    Create it BEFORE the process initialises HIP: the fork server is exec'ed here."""
+
+    def __init__(self, workers, pmax=16384, n=3, m=10):
+        import multiprocessing as mp
+        import os
+        from multiprocessing import shared_memory
+        self.W, self.pmax, self.n, self.m = int(workers), int(pmax), n, m
+        self._shms = {}
+        self._arr = {}
+        for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
+                                     S=((pmax,), np.int8), C=((4,), np.int64)).items():
+            shm = shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * np.dtype(dt).itemsize)
+            self._shms[key] = shm
+            self._arr[key] = np.ndarray(shape, dtype=dt, buffer=shm.buf)
+            self._arr[key][...] = 0
+        saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+        for k in saved:
+            os.environ[k] = "1"
+        try:
+            ctx = mp.get_context("forkserver")
+            ctx.set_forkserver_preload(["numpy", "scipy.optimize"])
+            self._barrier = ctx.Barrier(self.W + 1)
+            names = {k: s.name for k, s in self._shms.items()}
+            self._conns, self._procs = [], []
+            for w in range(self.W):
+                a, b = ctx.Pipe()
+                p = ctx.Process(target=_farm_worker, args=(w, self.W, self.pmax, n, m, names, self._barrier, b),
+                                daemon=True)
+                p.start()
+                self._conns.append(a)
+                self._procs.append(p)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    def minimize(self, eval_batch, x0s, bounds, ftol=2.2204460492503131e-09, gtol=1e-5, maxiter=15000,
+                 maxfun=15000, maxls=20):
+        bounds = np.asarray(bounds, dtype=np.float64)
+        P = len(x0s)
+        if P > self.pmax:
+            raise ValueError("too many problems for this farm")
+        X, F, G, S, C = (self._arr[k] for k in "XFGSC")
+        X[:P] = np.clip(np.asarray(x0s, dtype=np.float64).reshape(P, self.n), bounds[:, 0], bounds[:, 1])
+        S[:P] = 0
+        C[0] = 1
+        for c in self._conns:
+            c.send(("go", P, bounds, ftol, gtol, maxiter, maxfun, maxls))
+        rounds = 0
+        while True:
+            self._barrier.wait()
+            idx = np.nonzero(S[:P] == 1)[0]
+            if idx.size == 0:
+                C[0] = 0
+                self._barrier.wait()
+                break
+            f, g = eval_batch(idx, X[idx])
+            F[idx] = f
+            G[idx] = g
+            S[idx] = 0
+            self._barrier.wait()
+            rounds += 1
+        return X[:P].copy(), F[:P].copy(), rounds
+
+    def close(self):
+        for c in self._conns:
+            try:
+                c.send(("quit",))
+            except Exception:
+                pass
+        for p in self._procs:
+            p.join(timeout=2)
+            if p.is_alive():
+                p.terminate()
+        for s in self._shms.values():
+            try:
+                s.close()
+                s.unlink()
+            except Exception:
+                pass
+        self._procs = []
+
+    def __del__(self):
+        try:
+            if self._procs:
+                self.close()
+        except Exception:
+            pass

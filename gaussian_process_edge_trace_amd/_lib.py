@@ -79,6 +79,10 @@ SYMBOLS = {
     "gpet_select_pixels_only": (C.c_int, [_P]),
     "gpet_final_set_training": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "gpet_lml_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "gpet_final_set_training_all": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    "gpet_batch_read_obs_all": (C.c_int, [_P, _P, _P, C.c_int]),
+    "gpet_batch_read_scalars_all": (C.c_int, [_P, _P]),
+    "gpet_final_predict_all": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -199,6 +203,11 @@ class Batch:
         self.ctx.check(self.lib.gpet_batch_read(self.h, e, BUF_SCALARS, C.byref(s), C.sizeof(s)))
         return s
 
+    def all_scalars(self):
+        arr = (GpetScalars * self.B)()
+        self.ctx.check(self.lib.gpet_batch_read_scalars_all(self.h, arr))
+        return list(arr)
+
     def set_obs(self, e, obs_xy):
         o = np.ascontiguousarray(np.asarray(obs_xy).reshape(-1, 2), dtype=np.int64)
         self.ctx.check(self.lib.gpet_batch_set_obs(self.h, e, o.ctypes.data if o.size else None, o.shape[0]))
@@ -253,6 +262,30 @@ class Batch:
         xs, ys, w = (np.ascontiguousarray(a, dtype=np.float64) for a in (xs, ys, w))
         self.ctx.check(self.lib.gpet_final_set_training(self.h, e, xs.ctypes.data, ys.ctypes.data, w.ctypes.data,
                                                         xs.shape[0]))
+
+    def read_obs_all(self):
+        cap = max(self.info(e)["obs_cap"] for e in range(self.B))
+        dst = np.zeros((self.B, cap, 2), dtype=np.int64)
+        cnt = np.zeros(self.B, dtype=np.int32)
+        self.ctx.check(self.lib.gpet_batch_read_obs_all(self.h, dst.ctypes.data, cnt.ctypes.data, cap))
+        return [dst[e, :cnt[e]].copy() for e in range(self.B)]
+
+    def final_set_training_all(self, xs_list, ys_list, w_list):
+        stride = max(len(x) for x in xs_list)
+        pack = lambda lst: np.ascontiguousarray(np.stack([np.pad(np.asarray(a, dtype=np.float64), (0, stride - len(a)))
+                                                          for a in lst]))
+        xs, ys, w = pack(xs_list), pack(ys_list), pack(w_list)
+        n = np.asarray([len(x) for x in xs_list], dtype=np.int32)
+        self.ctx.check(self.lib.gpet_final_set_training_all(self.h, xs.ctypes.data, ys.ctypes.data, w.ctypes.data,
+                                                            n.ctypes.data, stride))
+
+    def final_predict_all(self, par):
+        par = np.ascontiguousarray(par, dtype=np.float64).reshape(self.B, 12)
+        Lg = max(self.info(e)["Lg"] for e in range(self.B))
+        mean = np.zeros((self.B, Lg))
+        std = np.zeros((self.B, Lg))
+        self.ctx.check(self.lib.gpet_final_predict_all(self.h, par.ctypes.data, mean.ctypes.data, std.ctypes.data, Lg))
+        return mean, std
 
     def lml_batch(self, edge_of, theta):
         edge_of = np.ascontiguousarray(edge_of, dtype=np.int32)

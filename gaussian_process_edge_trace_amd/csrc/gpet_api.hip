@@ -32,6 +32,13 @@ struct gpet_batch {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   unsigned int* d_seeds = nullptr;
+  gpet_scalars* d_scalars = nullptr;   // [B] contiguous: one copy reads every edge's state
+  double* d_fin_out = nullptr;         // [B][2][Lg_max] contiguous results of the converged fits
+  std::vector<gpet_scalars> h_scalars;
+  int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
+  hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
+  hipEvent_t ev_norm[16] = {};
+  hipEvent_t ev_main = nullptr;
   unsigned int* d_minmax = nullptr;
   int share_image = 0;
   // converged-fit scratch (grown on demand)
@@ -82,7 +89,6 @@ int nu_to_code(double nu) {
 void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   const size_t Lg = E.Lg, nc = E.n_cap, rc = E.r_cap, S = E.S;
   const size_t px = (size_t)E.M * E.N, gpx = (size_t)(E.M + 2) * (E.N + 2);
-  E.sc = cv.take<gpet_scalars>(1);
   E.init_xy = cv.take<long long>(2 * (size_t)E.n_init);
   E.obs_xy = cv.take<long long>(2 * (size_t)E.obs_cap);
   E.obs_new = cv.take<long long>(2 * (size_t)E.obs_cap);
@@ -119,6 +125,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.fin_x = cv.take<double>(nc);
   E.fin_y = cv.take<double>(nc);
   E.fin_w = cv.take<double>(nc);
+  E.fin_par = cv.take<double>(12);
   if (own_image) {
     E.grad = cv.take<float>(px);
     E.grad_kde = cv.take<float>(px);
@@ -330,6 +337,8 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     shared_grad = meas.take<float>(px);
     shared_kde = meas.take<float>(px);
   }
+  (void)meas.take<gpet_scalars>((size_t)B);
+  (void)meas.take<double>((size_t)B * 2 * bd.Lg);
   for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image);
   (void)shared_grad;
   (void)shared_kde;
@@ -346,8 +355,13 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     shared_grad = cv.take<float>(px);
     shared_kde = cv.take<float>(px);
   }
+  b->d_scalars = cv.take<gpet_scalars>((size_t)B);
+  b->d_fin_out = cv.take<double>((size_t)B * 2 * bd.Lg);
+  b->h_scalars.resize(B);
   for (int e = 0; e < B; ++e) {
     EdgeDev& E = b->h_edges[e];
+    E.sc = b->d_scalars + e;
+    E.fin_out = b->d_fin_out + (size_t)e * 2 * bd.Lg;
     carve_edge(cv, E, !b->share_image);
     if (b->share_image) {
       E.grad = shared_grad;
@@ -357,6 +371,9 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   HIPCHK(c, hipMalloc(&b->d_edges, sizeof(EdgeDev) * B));
   HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
   HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
+  HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_norm[i], hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
   float* d_raw = nullptr;
   HIPCHK(c, hipMalloc(&d_raw, px * sizeof(float)));
@@ -396,6 +413,13 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_edges) (void)hipFree(b->d_edges);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->side) {
+    (void)hipStreamSynchronize(b->side);
+    (void)hipStreamDestroy(b->side);
+  }
+  for (int i = 0; i < 16; ++i)
+    if (b->ev_norm[i]) (void)hipEventDestroy(b->ev_norm[i]);
+  if (b->ev_main) (void)hipEventDestroy(b->ev_main);
   if (b->d_edge_of) (void)hipFree(b->d_edge_of);
   if (b->d_theta) (void)hipFree(b->d_theta);
   if (b->d_f) (void)hipFree(b->d_f);
@@ -420,16 +444,26 @@ static int read_scalars(gpet_batch* b, int e, gpet_scalars* s) {
   return GPET_OK;
 }
 
+static int fetch_all_scalars(gpet_batch* b) {
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipMemcpyAsync(b->h_scalars.data(), b->d_scalars, sizeof(gpet_scalars) * b->B, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
 static int check_device_status(gpet_batch* b) {
   gpet_ctx* c = b->ctx;
+  int rc = fetch_all_scalars(b);
+  if (rc) return rc;
   for (int e = 0; e < b->B; ++e) {
-    gpet_scalars s;
-    int rc = read_scalars(b, e, &s);
-    if (rc) return rc;
+    const gpet_scalars& s = b->h_scalars[e];
     if (s.status == GPET_ERR_NOT_PD)
       return fail(c, GPET_ERR_NOT_PD, "edge %d: the kernel matrix is not positive definite (n=%d)", e, s.n);
     if (s.status == GPET_ERR_RANK_CAP)
       return fail(c, GPET_ERR_RANK_CAP, "edge %d: posterior covariance rank exceeds factor_cap=%d", e, b->h_edges[e].r_cap);
+    if (s.status == GPET_ERR_ITER_CAP)
+      return fail(c, GPET_ERR_ITER_CAP, "edge %d: no score threshold yields enough new pixels (the reference would loop forever, gpet.py:591-609)", e);
     if (s.status != GPET_OK) return fail(c, s.status, "edge %d: device status %d", e, s.status);
   }
   return GPET_OK;
@@ -447,6 +481,8 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.n_obs = n_obs;
   s.done = (n_obs >= E.algo_thresh) ? 1 : 0;
   s.status = GPET_OK;
+  s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
+  b->iters_issued = 0;   // (all edges of a batch are restarted together)
   if (n_obs > 0)
     HIPCHK(c, hipMemcpyAsync(E.obs_xy, obs_xy, sizeof(long long) * 2 * n_obs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(E.sc, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
@@ -604,7 +640,7 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, 1));
+  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, -1, 1));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->have_normals = true;
   return GPET_OK;
@@ -641,12 +677,14 @@ int gpet_select_pixels(gpet_batch* b) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
   HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  b->iters_issued += 1;  // k_pix_select advanced every active edge's iteration counter
   return check_device_status(b);
 }
 
 int gpet_batch_reset(gpet_batch* b) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
+  b->iters_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));
   for (int e = 0; e < b->B; ++e) {
     gpet_scalars s0;
@@ -668,7 +706,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
     switch (stage) {
       case 0: HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1)); break;
       case 1: HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd)); break;
-      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, b->bd.z_ring)); break;
+      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring)); break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0)); break;
@@ -697,6 +735,73 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
   HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GPET_OK;
+}
+
+int gpet_batch_read_scalars_all(gpet_batch* b, gpet_scalars* dst) {
+  if (!b || !dst) return GPET_ERR_BAD_ARG;
+  HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+  int rc = fetch_all_scalars(b);
+  if (rc) return rc;
+  memcpy(dst, b->h_scalars.data(), sizeof(gpet_scalars) * b->B);
+  return GPET_OK;
+}
+
+int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int stride_obs) {
+  if (!b || !dst || !counts || stride_obs < 1) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fetch_all_scalars(b);
+  if (rc) return rc;
+  for (int e = 0; e < b->B; ++e) {
+    const int n = b->h_scalars[e].n_obs;
+    counts[e] = n;
+    if (n > stride_obs) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_read_obs_all: edge %d has %d observations > stride %d", e, n, stride_obs);
+    if (n > 0)
+      HIPCHK(c, hipMemcpyAsync(dst + (size_t)e * stride_obs * 2, b->h_edges[e].obs_xy, sizeof(int64_t) * 2 * n,
+                               hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* ys, const double* w, const int32_t* n,
+                                int stride) {
+  if (!b || !xs || !ys || !w || !n || stride < 1) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int e = 0; e < b->B; ++e) {
+    EdgeDev& E = b->h_edges[e];
+    if (n[e] < 1 || n[e] > E.n_cap || n[e] > stride) return fail(c, GPET_ERR_BAD_ARG, "final fit: edge %d n=%d out of range", e, n[e]);
+    HIPCHK(c, hipMemcpyAsync(E.fin_x, xs + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(E.fin_y, ys + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(E.fin_w, w + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
+    E.fin_n = n[e];
+  }
+  HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * b->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GPET_OK;
+}
+
+int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, double* std_out, int stride) {
+  if (!b || !par || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int e = 0; e < b->B; ++e) {
+    if (b->h_edges[e].fin_n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_predict_all before the training sets are set");
+    HIPCHK(c, hipMemcpyAsync(b->h_edges[e].fin_par, par + (size_t)e * 12, sizeof(double) * 12, hipMemcpyHostToDevice,
+                             c->stream));
+  }
+  HIPCHK(c, launch_final_predict(c->stream, b->d_edges, b->B, b->bd));
+  std::vector<double> host((size_t)b->B * 2 * b->bd.Lg);
+  HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int e = 0; e < b->B; ++e) {
+    const int Lg = b->h_edges[e].Lg;
+    memcpy(mean_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg, sizeof(double) * Lg);
+    memcpy(std_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg + b->bd.Lg, sizeof(double) * Lg);
+  }
+  b->have_fit = false;  // the loop's L/alpha were overwritten by the converged fit
+  return check_device_status(b);
 }
 
 int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out) {
@@ -737,6 +842,7 @@ int gpet_select_pixels_only(gpet_batch* b) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd));
   HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  b->iters_issued += 1;
   return check_device_status(b);
 }
 
@@ -750,29 +856,34 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
   for (int it = 0; it < max_iters; ++it) {
     // every kernel skips edges whose `done` flag is set, so finished edges cost nothing.
-    // Normals: the seeds of upcoming iterations are known (gpet.py:839), so one launch fills
-    // the ring for the next z_ring iterations, one workgroup per (iteration, edge).
-    if (it % b->bd.z_ring == 0) {
-      const int ahead = (max_iters - it) < b->bd.z_ring ? (max_iters - it) : b->bd.z_ring;
-      HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, ahead));
+    // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs
+    // ahead of the loop on its own HIP stream, one launch per iteration, up to one ring ahead;
+    // the sample GEMM of iteration k waits on that iteration's event only.
+    const int ring = b->bd.z_ring;
+    if (it % ring == 0) {
+      // the previous ring's slots must be consumed before they are overwritten
+      HIPCHK(c, hipEventRecord(b->ev_main, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_main, 0));
+      const int ahead = (max_iters - it) < ring ? (max_iters - it) : ring;
+      for (int k = 0; k < ahead; ++k) {
+        HIPCHK(c, launch_normals(b->side, b->d_edges, b->B, b->d_seeds, 1, b->iters_issued + k, 1));
+        HIPCHK(c, hipEventRecord(b->ev_norm[(it + k) % 16], b->side));
+      }
     }
     HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
     HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[it % 16], 0));
     HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
     HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+    b->iters_issued += 1;
   }
   b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = (max_iters > 0) || b->have_fit;
   int rc = check_device_status(b);
   if (rc) return rc;
   int active = 0;
-  for (int e = 0; e < b->B; ++e) {
-    gpet_scalars s;
-    rc = read_scalars(b, e, &s);
-    if (rc) return rc;
-    active += s.done ? 0 : 1;
-  }
+  for (int e = 0; e < b->B; ++e) active += b->h_scalars[e].done ? 0 : 1;
   *n_active = active;
   return GPET_OK;
 }

@@ -50,7 +50,10 @@ struct EdgeDev {
   unsigned long long* binbest;  // [n_bins] bits of the best score per bin (scores are >= 0)
   long long* binarg;     // [n_bins] order key of the best candidate per bin
   int bin_lo, fin_n;     // fin_n: training points of the converged fit
-  double *fin_x, *fin_y, *fin_w;  // [n_cap] standardised training set of the converged fit (gpet.py:235-238)      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
+  double *fin_x, *fin_y, *fin_w;  // [n_cap] standardised training set of the converged fit (gpet.py:235-238)
+  // optimum + transforms of the converged fit: c, l, noise, X_m, X_s, y_m, y_s, m2, s2 (values, not logs)
+  double* fin_par;       // [12]
+  double* fin_out;       // [2 * Lg_max] mean (pixels) then std, in the batch's contiguous output block      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
 };
 
 }  // namespace gpet

@@ -133,18 +133,42 @@ __global__ void k_normalise_f32(const float* __restrict__ in, size_t count, cons
 // a2-a4  training-set assembly + K_obs + Cholesky + alpha   (one workgroup per edge)
 //        gpet.py:209-231, sklearn_gpr.py:221-227, 304-320
 // ---------------------------------------------------------------------------------------
+// K_IN_LDS: the n x n matrix lives in LDS (n_cap <= 128, odd row stride) and only the finished
+// factor is written to HBM; otherwise it is factored in place in HBM (large n, config 3).
+// FINAL: the converged fit at the optimum found by L-BFGS-B (gpet.py:232-266): training set,
+// amplitude, length scale and noise come from fin_x/fin_y/fin_w/fin_par instead of the loop state.
+template <bool K_IN_LDS, bool FINAL>
 __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
-  extern __shared__ double s_dyn[];  // [n_cap] solve vector
+  if (!FINAL && (sc->done || sc->status != GPET_OK)) return;
+  extern __shared__ double s_dyn[];  // [n_cap] solve vector (+ [n_cap * ld] matrix when K_IN_LDS)
   __shared__ double s_red[16];
   __shared__ double s_diag;
   const int tid = threadIdx.x, bs = blockDim.x;
   const int n_obs = sc->n_obs;
-  const int n = E.n_init + n_obs;
-  const int ld = E.n_cap;
-  double* K = E.K;
+  const int n = FINAL ? E.fin_n : (E.n_init + n_obs);
+  const int ld = K_IN_LDS ? (E.n_cap | 1) : E.n_cap;
+  double* K = K_IN_LDS ? (s_dyn + E.n_cap) : E.K;
+  double amp, length, noise_lvl, jit;
+  if (FINAL) {
+    for (int i = tid; i < n; i += bs) {
+      E.xt[i] = E.fin_x[i];
+      E.yt[i] = E.fin_y[i];
+      E.wt[i] = E.fin_w[i];
+    }
+    amp = E.fin_par[0];
+    length = E.fin_par[1];
+    noise_lvl = E.fin_par[2];
+    jit = 1e-6;
+    if (tid == 0) {
+      sc->amp = amp;
+      sc->y_mean = E.fin_par[7];
+      sc->y_std = E.fin_par[8];
+      sc->n = n;
+    }
+    __syncthreads();
+  } else {
 
   // 1. gather + stable rank sort by x (np.argsort, gpet.py:212)
   const double w_init = E.fix_endpoints ? 1e-7 : 0.5;  // gpet.py:161
@@ -187,7 +211,10 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
   double sd2 = sqrt(block_sum(part, s_red) / n);
   if (sd2 == 0.0) sd2 = 1.0;  // _handle_zeros_in_scale scalar path
   for (int i = tid; i < n; i += bs) E.yt[i] -= m2;
-  const double amp = E.sigma_f * E.sigma_f / (y_s * y_s);
+  amp = E.sigma_f * E.sigma_f / (y_s * y_s);
+  length = E.length_scale;
+  noise_lvl = E.noise_y;
+  jit = E.jitter;
   if (tid == 0) {
     sc->y_s = y_s;
     sc->amp = amp;
@@ -196,6 +223,7 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
     sc->n = n;
   }
   __syncthreads();
+  }  // !FINAL
 
   // 3. K = amp * rho + diag(noise_y * w) + jitter     (lower triangle only)
   //    inputs are divided by l exactly as sklearn does (X / length_scale)
@@ -206,10 +234,10 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
     double v;
     if (i == j) {
       v = amp;
-      v = v + (zero_noise ? 0.0 : E.noise_y * E.wt[i]);
-      v = v + E.jitter;
+      v = v + ((zero_noise && !FINAL) ? 0.0 : noise_lvl * E.wt[i]);  // (FINAL: the host already zeroed w)
+      v = v + jit;
     } else {
-      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / E.length_scale, E.xt[j] / E.length_scale);
+      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length);
     }
     K[(size_t)i * ld + j] = v;
   }
@@ -261,36 +289,87 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
     }
     for (int i = lane; i < n; i += WAVE) E.alpha[i] = z[i];
   }
+  if (K_IN_LDS) {  // publish the factor for k_predict / readers (row stride n_cap in HBM)
+    for (int idx = tid; idx < n * n; idx += bs) {
+      const int i = idx / n, j = idx - i * n;
+      if (j <= i) E.K[(size_t)i * E.n_cap + j] = K[(size_t)i * ld + j];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
 // a5  predict: K_* on the fly, mean, V = L^-1 K_*^T, std          (thread per grid point)
 //     sklearn_gpr.py:381-394, 414-436
+//     One wave per 64 grid points.  V_LDS: the wave keeps its 64 columns of V in LDS
+//     ([n][64], conflict-free) and streams the rows of L through LDS, so the forward
+//     substitution has no global-load latency chain; the HBM copy of V is write-only here.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_predict(EdgeDev* edges) {
+// FINAL: prediction of the converged fit on the standardised grid (gpet.py:264-266); results go
+// to the batch's contiguous output block as mean in pixels and std in standardised units.
+template <bool V_LDS, bool FINAL>
+__global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= E.Lg) return;
+  if (!FINAL && (sc->done || sc->status != GPET_OK)) return;
+  extern __shared__ double s_dyn[];
+  const int lane = threadIdx.x;
+  const int j = blockIdx.x * 64 + lane;
   const int n = sc->n, ld = E.n_cap, Lg = E.Lg;
+  const bool live = j < Lg;
   const double amp = sc->amp;
-  const double xq = (double)(E.x_st + j) / E.length_scale;
+  const double length = FINAL ? E.fin_par[1] : E.length_scale;
+  double xq = (double)(E.x_st + (live ? j : 0));
+  if (FINAL) xq = (xq - E.fin_par[3]) / E.fin_par[4];  // (x_grid - X_m) / X_s
+  xq = xq / length;
   double msum = 0.0, vsum = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / E.length_scale);
-    const double* ri = E.K + (size_t)i * ld;
-    double acc = ki;
-    for (int t = 0; t < i; ++t) acc -= ri[t] * E.V[(size_t)t * Lg + j];
-    const double v = acc / ri[i];
-    E.V[(size_t)i * Lg + j] = v;
-    msum += ki * E.alpha[i];
-    vsum += v * v;
+  if (V_LDS) {
+    double* s_v = s_dyn;                      // [n_cap][64]
+    double* s_l = s_dyn + (size_t)E.n_cap * 64;  // [n_cap] current row of L
+    double* s_x = s_l + E.n_cap;              // [n_cap] x_i / l
+    double* s_a = s_x + E.n_cap;              // [n_cap] alpha
+    for (int i = lane; i < n; i += 64) {
+      s_x[i] = E.xt[i] / length;
+      s_a[i] = E.alpha[i];
+    }
+    for (int i = 0; i < n; ++i) {
+      __syncthreads();
+      const double* ri = E.K + (size_t)i * ld;
+      for (int t = lane; t <= i; t += 64) s_l[t] = ri[t];
+      __syncthreads();
+      const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, s_x[i]);
+      double acc = ki;
+      for (int t = 0; t < i; ++t) acc -= s_l[t] * s_v[t * 64 + lane];
+      const double v = acc / s_l[i];
+      s_v[i * 64 + lane] = v;
+      if (live) E.V[(size_t)i * Lg + j] = v;
+      msum += ki * s_a[i];
+      vsum += v * v;
+    }
+  } else {
+    if (!live) return;
+    for (int i = 0; i < n; ++i) {
+      const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / length);
+      const double* ri = E.K + (size_t)i * ld;
+      double acc = ki;
+      for (int t = 0; t < i; ++t) acc -= ri[t] * E.V[(size_t)t * Lg + j];
+      const double v = acc / ri[i];
+      E.V[(size_t)i * Lg + j] = v;
+      msum += ki * E.alpha[i];
+      vsum += v * v;
+    }
   }
-  E.mean[j] = sc->y_std * msum + sc->y_mean;
+  if (!live) return;
+  const double mean = sc->y_std * msum + sc->y_mean;
   double var = amp - vsum;
   if (var < 0.0) var = 0.0;
-  E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
+  const double sd = sqrt(var * (sc->y_std * sc->y_std));
+  if (FINAL) {
+    E.fin_out[j] = E.fin_par[6] * mean + E.fin_par[5];  // y_s * y_mean + y_m   (gpet.py:266)
+    E.fin_out[out_stride + j] = sd;                      // not rescaled (gpet.py:266, quirk Q10)
+  } else {
+    E.mean[j] = mean;
+    E.std[j] = sd;
+  }
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2        sklearn_gpr.py:398-403
@@ -407,11 +486,15 @@ __global__ void __launch_bounds__(1024) k_pchol(EdgeDev* edges) {
     if (!(dp > tol) || !(dp > 0.0)) break;
     const double sq = sqrt(dp);
     if (tid == 0) E.perm[k] = p;
+    double* s_gp = s_d + Lg;  // [r_cap] the pivot's entries of the previous columns
+    for (int t = tid; t < k; t += bs) s_gp[t] = E.G[(size_t)t * Lg + p];
+    __syncthreads();
+    const double* __restrict__ crow = E.cov + (size_t)p * Lg;  // cov is exactly symmetric: row p == column p
     for (int i = tid; i < Lg; i += bs) {
       double g = 0.0;
       if (s_d[i] >= 0.0) {  // not yet pivoted
-        g = E.cov[(size_t)i * Lg + p];
-        for (int t = 0; t < k; ++t) g -= E.G[(size_t)t * Lg + i] * E.G[(size_t)t * Lg + p];
+        g = crow[i];
+        for (int t = 0; t < k; ++t) g -= E.G[(size_t)t * Lg + i] * s_gp[t];
         g = g / sq;
       }
       E.G[(size_t)k * Lg + i] = g;
@@ -745,12 +828,15 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
 // blockIdx.x = how many iterations ahead of the edge's current one this stream belongs to: the
 // seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
 // generated by one launch, one workgroup per (iteration, edge).
-__global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter) {
+__global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
+                                                    int iter_abs) {
 #pragma clang fp contract(off)
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if (sc->done || sc->status != GPET_OK) return;
-  const int iter_idx = sc->iter + (int)blockIdx.x;
+  // iter_abs >= 0: the host names the iteration (the RNG stream runs ahead of the loop, so the
+  // device counter is not meaningful here); otherwise relative to the edge's current iteration
+  const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + (int)blockIdx.x;
   double* __restrict__ Zs = E.Z + (size_t)(iter_idx % E.z_ring) * ((size_t)E.S * E.z_cols);
   __shared__ unsigned int s_mt[2][624];
   __shared__ int s_cnt[2][4];
@@ -779,22 +865,20 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
     if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
     __syncthreads();
-    // 156 polar attempts
+    // 156 polar attempts.  Every attempt's accept/reject decision is needed (it positions the
+    // rest of the stream), but the log/sqrt only for the normals that are actually stored
+    // (columns < z_cols of each sample row).
     bool ok = false;
-    double g0 = 0.0, g1 = 0.0;
+    double x1 = 0.0, x2 = 0.0, r2 = 1.0;
     if (tid < 156) {
       const unsigned int a = mt_temper(nw[4 * tid]) >> 5, b = mt_temper(nw[4 * tid + 1]) >> 6;
       const unsigned int c = mt_temper(nw[4 * tid + 2]) >> 5, d = mt_temper(nw[4 * tid + 3]) >> 6;
       const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
       const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
-      const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
-      const double r2 = x1 * x1 + x2 * x2;
+      x1 = 2.0 * u1 - 1.0;
+      x2 = 2.0 * u2 - 1.0;
+      r2 = x1 * x1 + x2 * x2;
       ok = !(r2 >= 1.0 || r2 == 0.0);
-      if (ok) {
-        const double f = sqrt(-2.0 * log(r2) / r2);
-        g0 = f * x2;
-        g1 = f * x1;
-      }
     }
     const unsigned long long bal = __ballot(ok);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -807,17 +891,22 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
       tot += cq;
     }
     if (ok) {
-      const long long pidx = done_pairs + base + before;
-      const long long q0 = 2 * pidx;
+      const long long q0 = 2 * (done_pairs + base + before);
       if (q0 < total) {
-        const long long srow = q0 / E.Lg;
-        const int colq = (int)(q0 - srow * E.Lg);
-        if (colq < E.z_cols) Zs[(size_t)srow * E.z_cols + colq] = g0;
-      }
-      if (q0 + 1 < total) {
-        const long long srow = (q0 + 1) / E.Lg;
-        const int colq = (int)(q0 + 1 - srow * E.Lg);
-        if (colq < E.z_cols) Zs[(size_t)srow * E.z_cols + colq] = g1;
+        const int srow = (int)(q0 / E.Lg);
+        const int col0 = (int)(q0 - (long long)srow * E.Lg);
+        int srow1 = srow, col1 = col0 + 1;
+        if (col1 == E.Lg) {
+          col1 = 0;
+          srow1 = srow + 1;
+        }
+        const bool w0 = col0 < E.z_cols;
+        const bool w1 = (q0 + 1 < total) && (col1 < E.z_cols);
+        if (w0 || w1) {
+          const double f = sqrt(-2.0 * log(r2) / r2);
+          if (w0) Zs[(size_t)srow * E.z_cols + col0] = f * x2;
+          if (w1) Zs[(size_t)srow1 * E.z_cols + col1] = f * x1;
+        }
       }
     }
     done_pairs += tot;
@@ -1109,6 +1198,154 @@ __global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode)
     a[i] = (a[i] - mn) / span;
 }
 
+// ---- fused curve KDE (per-iteration path) ----------------------------------------------
+// k_kde_prep: total kept weight W (KDEpy normalises the weights by their sum), points removed
+// for lying outside the image (gpet.py:498-500), and the per-iteration resets.
+__global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  __shared__ double s_red[16];
+  __shared__ double s_inv;
+  if (threadIdx.x == 0) {
+    double inv_sum = 0.0;
+    for (int b = 0; b < E.n_keep; ++b) inv_sum += 1.0 / E.best_costs[b];
+    s_inv = inv_sum;
+    E.mm[0] = 0xFFFFFFFFu;
+    E.mm[1] = 0u;
+  }
+  for (int i = threadIdx.x; i < E.n_bins; i += blockDim.x) {
+    E.binbest[i] = 0ull;
+    E.binarg[i] = 0x7FFFFFFFFFFFFFFFll;
+  }
+  __syncthreads();
+  const double inv_sum = s_inv, ymax = (double)(E.M - 1);
+  double wsum = 0.0;
+  int removed = 0;
+  // all (curve, column) points in parallel: independent coalesced loads, no serial chain
+  for (int b = 0; b < E.n_keep; ++b) {
+    const double* __restrict__ row = E.Y + (size_t)E.best_idx[b] * E.Lg;
+    const double wb = (1.0 / E.best_costs[b]) / inv_sum;
+    for (int k = threadIdx.x; k < E.Lg; k += blockDim.x) {
+      const double y = row[k];
+      if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
+    }
+  }
+  wsum = block_sum(wsum, s_red);
+  const double rem = block_sum((double)removed, s_red);
+  if (threadIdx.x == 0) {
+    E.colsum[0] = wsum;     // W
+    E.colsum[1] = inv_sum;  // sum of 1/cost over the kept curves
+    sc->n_removed = (int)rem;
+  }
+}
+
+#define KDE_TX 16
+
+// One workgroup per (16-column tile, row chunk, edge): linear binning of the tile's curve points
+// straight into LDS (columns x0-4 .. x0+19, rows r0-4 .. r0+RY+4), separable 9-tap Gaussian
+// (vertical then horizontal) between two LDS tiles, f32 cast, min/max.  Rows/columns outside
+// the padded grid simply never receive weight, so no boundary tests are needed.
+// The 2 MB/edge global binning grid and its two global convolution passes are gone.
+__global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges, int rows_per_chunk) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  extern __shared__ double s_a[];
+  const int M = E.M, N = E.N;
+  const int x0 = blockIdx.x * KDE_TX;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  if (x0 >= N || r0 >= M) return;
+  const int nrow = (M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk;  // image rows of this chunk
+  const int ld = (rows_per_chunk + 8) | 1;
+  const int NC = KDE_TX + 8;
+  double* s_t = s_a + NC * ld;        // [NC][ld] vertically filtered
+  double* s_y = s_t + NC * ld;        // [64][NC] staged curve points
+  double* s_wt = s_y + 64 * NC;       // [64] staged weights
+  // LDS row l of s_a <-> padded-grid row gy = r0 - 3 + l  (gy = y + 1; halo 4)
+  const int tid = threadIdx.x;
+  const bool band = (x0 + KDE_TX + 4 > E.x_st) && (x0 - 4 <= E.x_en);
+  float* __restrict__ out = E.kde;
+  unsigned int kmin = 0xFFFFFFFFu, kmax = 0u;
+  if (!band) {
+    for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
+      const int xl = idx % KDE_TX, y = r0 + idx / KDE_TX;
+      if (x0 + xl < N) out[(size_t)y * N + x0 + xl] = 0.f;
+    }
+    kmin = kmax = f32_order_key(0.f);
+  } else {
+    for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
+    const double W = E.colsum[0], inv_sum = E.colsum[1], ymax = (double)(M - 1);
+    const int lmax = nrow + 8;
+    for (int b0 = 0; b0 < E.n_keep; b0 += 64) {
+      const int nb = (E.n_keep - b0) < 64 ? (E.n_keep - b0) : 64;
+      __syncthreads();
+      for (int e = tid; e < nb * NC; e += 256) {
+        const int bb = e / NC, c = e - bb * NC;
+        const int xc = x0 + c - 4;
+        double y = -1.0;  // marks "no point"
+        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)E.best_idx[b0 + bb] * E.Lg + (xc - E.x_st)];
+        s_y[e] = y;
+      }
+      for (int e = tid; e < nb; e += 256) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
+      __syncthreads();
+      if (tid < NC) {
+        double* col = s_a + tid * ld;
+        for (int bb = 0; bb < nb; ++bb) {
+          const double y = s_y[bb * NC + tid];
+          if (y < 0.0 || y > ymax) continue;  // gpet.py:498-500 (and columns outside the edge)
+          const double gy = y + 1.0;
+          const int iy = (int)floor(gy);
+          const int l = iy - (r0 - 3);
+          if (l + 1 < 0 || l >= lmax) continue;
+          const double w = s_wt[bb];
+          const double fy = gy - (double)iy;
+          if (l >= 0) col[l] += (1.0 - fy) * w;
+          if (l + 1 < lmax) col[l + 1] += fy * w;
+        }
+      }
+    }
+    __syncthreads();
+    double g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
+    // vertical pass: t[c][yl] = sum_dy a[c][yl + 4 + dy] g[dy]
+    for (int idx = tid; idx < NC * nrow; idx += 256) {
+      const int c = idx / nrow, yl = idx - c * nrow;
+      const double* col = s_a + c * ld + yl;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += col[t] * g[t];
+      s_t[c * ld + yl] = acc;
+    }
+    __syncthreads();
+    // horizontal pass + crop + f32
+    for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
+      const int xl = idx % KDE_TX, yl = idx / KDE_TX;
+      const int x = x0 + xl, y = r0 + yl;
+      if (x >= N) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += s_t[(xl + t) * ld + yl] * g[t];
+      acc *= 0.15915494309189535;  // 1 / (2 pi): 2-D Gaussian pdf normalisation
+      const float v = (float)acc;
+      out[(size_t)y * N + x] = v;
+      const unsigned int key = f32_order_key(v);
+      kmin = min(kmin, key);
+      kmax = max(kmax, key);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
+    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(&E.mm[0], kmin);
+    atomicMax(&E.mm[1], kmax);
+  }
+}
+
 // pixel_scores = 1/3 * (i*g + i + g) with numpy's rounding order (gpet.py:582)
 __device__ __forceinline__ double pixel_score(double iv, double gv) {
 #pragma clang fp contract(off)
@@ -1122,31 +1359,48 @@ __device__ __forceinline__ int bin_of(const EdgeDev& E, int x) {
   return (int)rint((double)(x - E.x_st) / (double)E.delta_x) - E.bin_lo;  // np.round = half-to-even
 }
 
-// best new candidate of every admissible column (first in row-major order among equals)
-__global__ void __launch_bounds__(64) k_pix_columns(EdgeDev* edges) {
+// best new candidate of every admissible column (first in row-major order among equals).
+// 16 columns x 16 row-lanes per workgroup: each thread scans every 16th row of its column
+// (independent, column-coalesced loads), then the 16 lanes of a column reduce in LDS.
+__global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if (sc->done || sc->status != GPET_OK) return;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= E.N) return;
+  __shared__ double s_best[16][17];
+  __shared__ int s_by[16][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int x = blockIdx.x * 16 + cx;
   double best = -1.0;
   int by = -1;
-  const bool admissible = E.fix_endpoints ? (x > E.x_st && x < E.x_en) : true;  // gpet.py:655-657
+  const bool admissible = (x < E.N) && (E.fix_endpoints ? (x > E.x_st && x < E.x_en) : true);  // gpet.py:655-657
   if (admissible) {
-    for (int y = 0; y < E.M; ++y) {
+    for (int y = ry; y < E.M; y += 16) {
       const double iv = (double)E.kde[(size_t)y * E.N + x];
       if (iv > 1e-3) {  // gpet.py:651
         const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
-        if (sv > best) {
+        if (sv > best) {  // rows visited in increasing order: first maximum kept
           best = sv;
           by = y;
         }
       }
     }
   }
-  E.colbest[x] = best;
-  E.colbest_y[x] = by;
-  if (by >= 0) atomicMax(&E.binbest[bin_of(E, x)], (unsigned long long)__double_as_longlong(best));
+  s_best[ry][cx] = best;
+  s_by[ry][cx] = by;
+  __syncthreads();
+  if (ry == 0 && x < E.N) {
+    for (int q = 1; q < 16; ++q) {
+      const double v = s_best[q][cx];
+      const int yy = s_by[q][cx];
+      if (yy >= 0 && (v > best || (v == best && yy < by))) {
+        best = v;
+        by = yy;
+      }
+    }
+    E.colbest[x] = best;
+    E.colbest_y[x] = by;
+    if (by >= 0) atomicMax(&E.binbest[bin_of(E, x)], (unsigned long long)__double_as_longlong(best));
+  }
 }
 
 // previously accepted observations are re-scored and compete first (gpet.py:568-579)
@@ -1470,10 +1724,29 @@ hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, con
   return hipGetLastError();
 }
 
+static void fit_predict_attrs() {
+  static bool attr_set = false;
+  if (attr_set) return;
+  (void)hipFuncSetAttribute((const void*)k_fit<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_fit<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_predict<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_predict<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  attr_set = true;
+}
+
 hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_fit, dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
-  hipLaunchKernelGGL(k_predict, dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges);
+  fit_predict_attrs();
+  if (bd.n_cap <= 128)
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
+                       ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
+  else
+    hipLaunchKernelGGL((k_fit<false, false>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  const size_t plds = ((size_t)bd.n_cap * 64 + 3 * (size_t)bd.n_cap) * sizeof(double);
+  if (plds <= 150 * 1024)
+    hipLaunchKernelGGL((k_predict<true, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, 0);
+  else
+    hipLaunchKernelGGL((k_predict<false, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, 0);
   if (want_cov) {
     const int t = cdiv(bd.Lg, 32);
     hipLaunchKernelGGL(k_cov, dim3(t, t, B), dim3(256), 0, st, d_edges);
@@ -1481,10 +1754,27 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
   return hipGetLastError();
 }
 
+// converged fit at the optimum: factor + alpha, then mean/std on the standardised grid
+hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();
+  fit_predict_attrs();
+  if (bd.n_cap <= 128)
+    hipLaunchKernelGGL((k_fit<true, true>), dim3(1, B), dim3(256),
+                       ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
+  else
+    hipLaunchKernelGGL((k_fit<false, true>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  const size_t plds = ((size_t)bd.n_cap * 64 + 3 * (size_t)bd.n_cap) * sizeof(double);
+  if (plds <= 150 * 1024)
+    hipLaunchKernelGGL((k_predict<true, true>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, bd.Lg);
+  else
+    hipLaunchKernelGGL((k_predict<false, true>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, bd.Lg);
+  return hipGetLastError();
+}
+
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   int pth = bd.Lg >= 1024 ? 1024 : (bd.Lg > 512 ? 1024 : (bd.Lg > 256 ? 512 : 256));
-  hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)bd.Lg * sizeof(double), st, d_edges);
+  hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)(bd.Lg + bd.r_cap) * sizeof(double), st, d_edges);
   const int t = cdiv(bd.r_cap, 16);
   hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
   if (bd.r_cap <= 96) {
@@ -1505,20 +1795,33 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 }
 
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
-                          int n_ahead) {
+                          int iter_abs, int n_ahead) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter);
+  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs);
   return hipGetLastError();
 }
 
 // mode 0: KDE of the best curves -> E.kde ; mode 1: KDE of the gradient image -> E.grad_kde
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
+  if (mode == 0) {
+    // per-iteration path: one prep kernel + one fused bin/convolve kernel + normalise
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_kde_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    // row chunks of <= 128 rows, balanced: two (KDE_TX+8) x (rows+8) f64 LDS tiles per workgroup
+    const int nchunk = cdiv(bd.M, 128);
+    const int rows = cdiv(bd.M, nchunk);
+    const size_t lds = ((size_t)2 * (KDE_TX + 8) * ((rows + 8) | 1) + 64 * (KDE_TX + 8) + 64) * sizeof(double);
+    hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), cdiv(bd.M, rows), B), dim3(256), lds, st, d_edges, rows);
+    hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_kde_clear, dim3(64, B), dim3(256), 0, st, d_edges, mode);
-  if (mode == 0)
-    hipLaunchKernelGGL(k_kde_bin_curves, dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges);
-  else
-    hipLaunchKernelGGL(k_kde_bin_gradient, dim3(bd.N, B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_kde_bin_gradient, dim3(bd.N, B), dim3(256), 0, st, d_edges);
   hipLaunchKernelGGL(k_kde_conv_y, dim3(cdiv(bd.M + 2, 256), bd.N + 2, B), dim3(256), 0, st, d_edges, mode);
   hipLaunchKernelGGL(k_kde_conv_x, dim3(cdiv(bd.M, 256), bd.N, B), dim3(256), 0, st, d_edges, mode);
   hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
@@ -1542,7 +1845,7 @@ hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const Ba
 
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 64), B), dim3(64), 0, st, d_edges);
+  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 16), B), dim3(256), 0, st, d_edges);
   const int nt = bd.N > bd.obs_cap ? bd.N : bd.obs_cap;
   hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges);
   hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges);

@@ -230,10 +230,15 @@ class GP_Edge_Tracing(object):
         return edge_trace, (all_samples, all_obs, iter_optimal_curves)
 
 
-def device_final_fits(batch, ps, obs_list, iters):
-    """Converged fits (gpet.py:874) of many edges at once: scipy's own L-BFGS-B routine is driven in
-    lock step for all (edge, restart) problems and every round of objective evaluations is one
-    batched launch of the LML kernel (gpet_lml_batch).  Returns [(mean, std, theta)] per edge."""
+def device_final_fits(batch, ps, obs_list, iters, farm=None):
+    """Converged fits (gpet.py:874) of every edge of a batch at once.
+
+    Host: standardisation of the <=128-point training sets (numpy, as the reference does it) and
+    scipy's own L-BFGS-B routine, driven in lock step for all (edge, restart) problems
+    (``_lbfgsb_lockstep``, optionally spread over worker processes).  Device: every round of
+    objective evaluations is one batched launch of the LML kernel (gpet_lml_batch), and the
+    posterior at the optimum is one more launch (gpet_final_predict_all).
+    Returns ([(mean, std, theta)] per edge, number of optimiser rounds)."""
     from . import _final_fit as ff
     from ._lbfgsb_lockstep import minimize_many
 
@@ -241,22 +246,29 @@ def device_final_fits(batch, ps, obs_list, iters):
     for e, (p, obs) in enumerate(zip(ps, obs_list)):
         pr = ff.prepare(p["init"], obs, p["x_grid"], p["fix_endpoints"])
         preps.append(pr)
-        batch.final_set_training(e, pr["xs"], pr["yt"], pr["w"])
         th = ff.start_points(p["noise_y"], p["seed"] + iters[e])
         x0s += th
         edge_of += [e] * len(th)
+    batch.final_set_training_all([pr["xs"] for pr in preps], [pr["yt"] for pr in preps], [pr["w"] for pr in preps])
     edge_of = np.asarray(edge_of, dtype=np.int32)
 
     def eval_batch(idx, X):
         return batch.lml_batch(edge_of[idx], X)
 
-    X, F, rounds = minimize_many(eval_batch, x0s, ff.BOUNDS)
-    out = []
-    for e, p in enumerate(ps):
+    if farm is not None:
+        X, F, rounds = farm.minimize(eval_batch, x0s, ff.BOUNDS)
+    else:
+        X, F, rounds = minimize_many(eval_batch, x0s, ff.BOUNDS)
+    thetas = []
+    par = np.zeros((len(ps), 12))
+    for e, pr in enumerate(preps):
         sel = np.nonzero(edge_of == e)[0]
-        theta = X[sel[int(np.argmin(F[sel]))]]
-        mean, std = ff.finish(preps[e], theta, p["kernel_type"], p["kernel_nu"])
-        out.append((mean, std, theta))
+        theta = X[sel[int(np.argmin(F[sel]))]]  # first minimum, like np.argmin in sklearn_gpr.py:292
+        thetas.append(theta)
+        par[e, :3] = np.exp(theta)
+        par[e, 3:9] = [pr["X_m"], pr["X_s"], pr["y_m"], pr["y_s"], pr["m2"], pr["s2"]]
+    mean, std = batch.final_predict_all(par)
+    out = [(mean[e, :len(p["x_grid"])].copy(), std[e, :len(p["x_grid"])].copy(), thetas[e]) for e, p in enumerate(ps)]
     return out, rounds
 
 
@@ -279,7 +291,7 @@ class GP_Edge_Tracing_Batch(object):
 
     def __init__(self, inits, grad_imgs, seeds, kernel_options=(1, 3, 3), noise_y=1, N_samples=500, score_thresh=1,
                  delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, device=0,
-                 stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None):
+                 stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None, fit_farm=None):
         share = not isinstance(grad_imgs, (list, tuple))
         imgs = [grad_imgs] if share else list(grad_imgs)
         B = len(inits)
@@ -298,6 +310,8 @@ class GP_Edge_Tracing_Batch(object):
         # optional multiprocessing pool for the host-side final fits; create it BEFORE the process
         # touches the GPU (make_fit_pool) -- never fork/spawn after HIP is initialised
         self._pool = fit_pool
+        # optional LockstepFarm: worker processes that advance the L-BFGS-B problems of the final fits
+        self._farm = fit_farm
 
     def reset(self):
         self._batch.reset()
@@ -312,19 +326,23 @@ class GP_Edge_Tracing_Batch(object):
             done_iters += chunk
             if done_iters >= max_iter and n_active > 0:
                 raise _lib.GpetError(_lib.ERR_ITER_CAP, f"{n_active} edges did not converge in {max_iter} iterations")
-        return [b.scalars(e).iter for e in range(self.B)]
+        return self._iters()
+
+    def _iters(self):
+        return [s.iter for s in self._batch.all_scalars()]
 
     def final_fits(self, iters):
         jobs = []
         b = self._batch
+        all_obs = b.read_obs_all()
         for e, p in enumerate(self._ps):
-            obs = b.read(_lib.BUF_OBS, e)
+            obs = all_obs[e]
             jobs.append((p["init"], obs, p["x_grid"], p["kernel_type"], p["kernel_nu"], p["noise_y"],
                          p["fix_endpoints"], p["seed"] + iters[e]))
         if self._pool is not None and len(jobs) > 1:
             return self._pool.map(_final_fit_job, jobs)
         if all(len(j[1]) + len(j[0]) <= 128 for j in jobs):
-            fits, self._fit_rounds = device_final_fits(b, self._ps, [j[1] for j in jobs], iters)
+            fits, self._fit_rounds = device_final_fits(b, self._ps, [j[1] for j in jobs], iters, self._farm)
             return fits
         return [_final_fit_job(j) for j in jobs]  # > 128 training points: host objective
 

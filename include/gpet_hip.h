@@ -190,6 +190,17 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
 /* Upload edge e's standardised training set (x, y standardised as gpet.py:235-238 and
  * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= 128. */
 int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n);
+/* The same for every edge of the batch in one call: xs/ys/w are [B*stride], n [B]. */
+int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* ys, const double* w, const int32_t* n,
+                                int stride);
+/* Scalar state of every edge in one copy: dst [B]. */
+int gpet_batch_read_scalars_all(gpet_batch* b, gpet_scalars* dst);
+/* Observation sets of every edge in one call: dst i64 [B*stride_obs*2] xy, counts [B]. */
+int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int stride_obs);
+/* Posterior of the converged fit at the optimum (gpet.py:262-266) for every edge: par [B*12] =
+ * constant, length_scale, noise_level (values, not logs), X_m, X_s, y_m, y_s, m2, s2, 0, 0, 0;
+ * mean_out (pixels) and std_out (standardised units, as the reference returns it) are [B*stride]. */
+int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, double* std_out, int stride);
 /* Objective of the reference's L-BFGS-B runs for P problems at once: problem i evaluates
  * -log_marginal_likelihood and its gradient wrt theta_i = log(constant, length_scale, noise_level)
  * on edge edge_of[i]'s training set.  theta [P*3], f_out [P], g_out [P*3] (host).  A non-PD
