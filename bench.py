@@ -184,13 +184,17 @@ def main():
     tracer._batch.iterate(seeds, 7)
     n_mid = tracer._batch.scalars(0).n
     rank_mid = tracer._batch.scalars(0).rank
-    stage_ms = {name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}
+    ring = 16  # the normals stage fills a ring of 16 upcoming iterations per launch: report per iteration
+    def per_iter(d):
+        d["normals"] = d["normals"] / ring
+        return d
+    stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
     # single edge (BASELINE config 2): latency view
     one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **README_KW, _ctx=ctx)
     one(); one.reset()
     ts = time.time(); one(); single_s = time.time() - ts
     one.reset(); one._batch.iterate([1], 7)
-    one_ms = {name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}
+    one_ms = per_iter({name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
 
     # ---- roofline of the dominant kernel group: algorithmic bytes / flops per launch
     S, Lg, nk = README_KW["N_samples"], N, int(README_KW["keep_ratio"] * README_KW["N_samples"])

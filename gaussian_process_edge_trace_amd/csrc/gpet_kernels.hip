@@ -522,6 +522,106 @@ __global__ void __launch_bounds__(1024) k_pchol(EdgeDev* edges) {
   }
 }
 
+// step 1, register-resident variant (Lg <= 512, r_cap <= 96): thread i owns row i of the factor and
+// keeps its <= 96 entries in registers (zero until computed), so a step is 96 FMAs against the
+// pivot row broadcast from LDS -- no global-load chain.  Same arithmetic order as k_pchol.
+#define PCH_R 96
+__global__ void __launch_bounds__(512) k_pchol_reg(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  __shared__ double s_d[512];
+  __shared__ double s_gp[PCH_R];
+  __shared__ double s_val[8];
+  __shared__ int s_idx[8];
+  __shared__ double s_piv;
+  __shared__ int s_pidx;
+  const int tid = threadIdx.x, Lg = E.Lg;
+  const int lane = tid & 63, w = tid >> 6;
+  const bool live = tid < Lg;
+  double gown[PCH_R];
+#pragma unroll
+  for (int t = 0; t < PCH_R; ++t) gown[t] = 0.0;
+  double dloc = live ? E.cov[(size_t)tid * Lg + tid] : -1.0;  // remaining diagonal (-1: pivoted / absent)
+  s_d[tid] = dloc;
+  __syncthreads();
+  double tol = 0.0;
+  int k = 0;
+  const int rcap = E.r_cap < PCH_R ? E.r_cap : PCH_R;
+  for (; k < rcap; ++k) {
+    double bv = dloc;
+    int bi = live ? tid : 0x7FFFFFFF;
+    if (!(bv >= 0.0)) {
+      bv = -1.0;
+      bi = 0x7FFFFFFF;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, WAVE);
+      const int oi = __shfl_xor(bi, o, WAVE);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[w] = bv;
+      s_idx[w] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_val[0];
+      int ix = s_idx[0];
+      for (int q = 1; q < 8; ++q)
+        if (s_val[q] > v || (s_val[q] == v && s_idx[q] < ix)) {
+          v = s_val[q];
+          ix = s_idx[q];
+        }
+      s_piv = v;
+      s_pidx = ix;
+    }
+    __syncthreads();
+    const double dp = s_piv;
+    const int p = s_pidx;
+    if (k == 0) tol = dp * 1e-14;
+    if (!(dp > tol) || !(dp > 0.0)) break;
+    const double sq = sqrt(dp);
+    if (tid == p) {
+      E.perm[k] = p;
+#pragma unroll
+      for (int t = 0; t < PCH_R; ++t) s_gp[t] = gown[t];
+    }
+    __syncthreads();
+    double g = 0.0;
+    if (live && dloc >= 0.0) {  // not yet pivoted
+      g = E.cov[(size_t)p * Lg + tid];  // cov is exactly symmetric: row p == column p
+#pragma unroll
+      for (int t = 0; t < PCH_R; ++t) g -= gown[t] * s_gp[t];
+      g = g / sq;
+    }
+    if (live) E.G[(size_t)k * Lg + tid] = g;
+#pragma unroll
+    for (int t = 0; t < PCH_R; ++t) gown[t] = (t == k) ? g : gown[t];
+    if (tid == p) {
+      dloc = -1.0;
+    } else if (dloc >= 0.0) {
+      const double nd = dloc - g * g;
+      dloc = nd > 0.0 ? nd : 0.0;
+    }
+    // (s_gp / s_val are rewritten only after the next step's barriers)
+  }
+  s_d[tid] = dloc;
+  __syncthreads();
+  if (tid == 0) {
+    sc->rank = k;
+    if (k == rcap) {
+      double rem = 0.0;
+      for (int i = 0; i < Lg; ++i) rem = s_d[i] > rem ? s_d[i] : rem;
+      if (rem > tol * 1e4) sc->status = GPET_ERR_RANK_CAP;
+    }
+  }
+}
+
 // step 2: Gram matrix C = G G^T (rank x rank)
 __global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
@@ -668,9 +768,12 @@ __global__ void __launch_bounds__(1024) k_jacobi(EdgeDev* edges) {
 }
 
 // step 3 (fast path, r_cap <= 96): the same cyclic Jacobi with the Gram matrix and the
-// accumulated rotations resident in LDS (2 * r * (r|1) doubles <= 146 KB of the CU's 160 KB).
-// Row stride ld is odd so that both the column walk (stride ld) and the row walk (stride 1)
-// are bank-conflict free for 8-byte accesses.
+// accumulated rotations resident in LDS (2 * m * (m|1) doubles <= 146 KB of the CU's 160 KB).
+// A round applies its m/2 disjoint rotations as independent 2x2 blocks: block (a, b) holds the
+// four entries touched by the row rotation of pair a and the column rotation of pair b, so one
+// thread updates it in place (column rotation, then row rotation -- the arithmetic of the
+// sequential algorithm) and the whole round needs two barriers.  Odd ranks are padded with a
+// decoupled zero row/column.  Row stride ld is odd: conflict-free row and column walks.
 __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
@@ -680,18 +783,19 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   __shared__ double s_c[64], s_s[64];
   __shared__ int s_p[64], s_q[64];
   const int r = sc->rank, ldg = E.r_cap;
-  const int ld = r | 1;
+  const int m = (r + 1) & ~1;
+  const int ld = m | 1;
   double* A = s_mem;
-  double* W = s_mem + (size_t)r * ld;
+  double* W = s_mem + (size_t)m * ld;
   const int tid = threadIdx.x, bs = blockDim.x;
-  for (int e = tid; e < r * r; e += bs) {
-    const int i = e / r, j = e - i * r;
-    A[i * ld + j] = E.C[(size_t)i * ldg + j];
+  for (int e = tid; e < m * m; e += bs) {
+    const int i = e / m, j = e - i * m;
+    A[i * ld + j] = (i < r && j < r) ? E.C[(size_t)i * ldg + j] : 0.0;
     W[i * ld + j] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int m = (r + 1) & ~1;
   const int half = m >> 1;
+  int sweeps = 0;
   if (r >= 2) {
     for (int sweep = 0; sweep < 40; ++sweep) {
       double off = 0.0, dg = 0.0;
@@ -702,7 +806,9 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
       }
       off = block_sum(off, s_red);
       dg = block_sum(dg, s_red);
-      if (off <= 1e-30 * dg || off == 0.0) break;
+      // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
+      if (off <= 1e-24 * dg || off == 0.0) break;
+      ++sweeps;
       for (int round = 0; round < m - 1; ++round) {
         for (int k = tid; k < half; k += bs) {
           int p, q;
@@ -719,17 +825,13 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
             q = t;
           }
           double c = 1.0, s = 0.0;
-          if (q < r) {
-            const double apq = A[p * ld + q];
-            const double app = A[p * ld + p], aqq = A[q * ld + q];
-            if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
-              const double tau = (aqq - app) / (2.0 * apq);
-              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-              c = 1.0 / sqrt(1.0 + t * t);
-              s = t * c;
-            }
-          } else {
-            q = -1;
+          const double apq = A[p * ld + q];
+          const double app = A[p * ld + p], aqq = A[q * ld + q];
+          if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
           }
           s_c[k] = c;
           s_s[k] = s;
@@ -737,31 +839,32 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
           s_q[k] = q;
         }
         __syncthreads();
-        for (int e = tid; e < half * r; e += bs) {
-          const int k = e / r, i = e - k * r;
-          const int q = s_q[k];
-          const double s = s_s[k];
-          if (q < 0 || s == 0.0) continue;
-          const int p = s_p[k];
-          const double c = s_c[k];
-          const double ap = A[i * ld + p], aq = A[i * ld + q];
-          A[i * ld + p] = c * ap - s * aq;
-          A[i * ld + q] = s * ap + c * aq;
-          const double wp = W[i * ld + p], wq = W[i * ld + q];
-          W[i * ld + p] = c * wp - s * wq;
-          W[i * ld + q] = s * wp + c * wq;
+        // A: 2x2 blocks (pair a rows) x (pair b columns)
+        for (int e = tid; e < half * half; e += bs) {
+          const int a = e / half, b = e - a * half;
+          const double sa = s_s[a], sb = s_s[b];
+          if (sa == 0.0 && sb == 0.0) continue;
+          const double ca = s_c[a], cb = s_c[b];
+          const int pa = s_p[a], qa = s_q[a], pb = s_p[b], qb = s_q[b];
+          const double b00 = A[pa * ld + pb], b01 = A[pa * ld + qb];
+          const double b10 = A[qa * ld + pb], b11 = A[qa * ld + qb];
+          const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+          const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+          A[pa * ld + pb] = ca * t00 - sa * t10;
+          A[qa * ld + pb] = sa * t00 + ca * t10;
+          A[pa * ld + qb] = ca * t01 - sa * t11;
+          A[qa * ld + qb] = sa * t01 + ca * t11;
         }
-        __syncthreads();
+        // W: column rotations only
         for (int e = tid; e < half * r; e += bs) {
-          const int k = e / r, j = e - k * r;
-          const int q = s_q[k];
-          const double s = s_s[k];
-          if (q < 0 || s == 0.0) continue;
-          const int p = s_p[k];
-          const double c = s_c[k];
-          const double ap = A[p * ld + j], aq = A[q * ld + j];
-          A[p * ld + j] = c * ap - s * aq;
-          A[q * ld + j] = s * ap + c * aq;
+          const int b = e / r, i = e - b * r;
+          const double sb = s_s[b];
+          if (sb == 0.0) continue;
+          const double cb = s_c[b];
+          const int pb = s_p[b], qb = s_q[b];
+          const double wp = W[i * ld + pb], wq = W[i * ld + qb];
+          W[i * ld + pb] = cb * wp - sb * wq;
+          W[i * ld + qb] = sb * wp + cb * wq;
         }
         __syncthreads();
       }
@@ -782,6 +885,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
     }
     E.order[pos] = k;
   }
+  if (tid == 0) sc->reserved = sweeps;
 }
 
 // step 4: factor rows  A[k, :] = sum_t W[t, order[k]] * G[t, :]  (= sqrt(s_k) v_k up to sign).
@@ -1548,6 +1652,11 @@ __device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, doub
   }
 }
 
+// Right-looking formulation: at step k the column k of L is finalised, row k of X = L^-1 is
+// finalised, and both trailing updates (Schur complement of L; rows > k of X) run as flat
+// parallel loops -- depth ~ n^3/(3*256) instead of the n^2/2 serial dot products of a
+// left-looking factorisation, with two barriers per step shared by both recurrences.
+#define PK(i, j) ((i) * ((i) + 1) / 2 + (j))
 __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                              double* g_out) {
   const int pb = blockIdx.x;
@@ -1555,15 +1664,15 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
   const int n = E.fin_n;
   extern __shared__ double s_mem[];
   __shared__ double s_red[16];
-  __shared__ double s_diag;
   __shared__ int s_bad;
   const int np = n * (n + 1) / 2;
-  double* Lp = s_mem;            // packed lower L
-  double* Xp = s_mem + np;       // packed lower L^-1
-  double* sa = s_mem + 2 * np;   // a = x / l
-  double* sy = sa + n;           // y, then z
-  double* sal = sy + n;          // alpha
+  double* Lp = s_mem;            // packed lower: K, then L
+  double* Xp = s_mem + np;       // packed lower: L^-1
+  double* sa = s_mem + 2 * np;   // x / l, later alpha
+  double* sy = sa + n;           // y
+  double* sal = sy + n;          // scaled pivot column, later z
   const int tid = threadIdx.x, bs = blockDim.x;
+  const int tx = tid & 15, ty = tid >> 4;
   const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
   for (int i = tid; i < n; i += bs) {
     sa[i] = E.fin_x[i] / ell;
@@ -1571,41 +1680,62 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
   }
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  for (int q = tid; q < np; q += bs) {
-    int i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= q) ++i;
-    while (i * (i + 1) / 2 > q) --i;
-    const int j = q - i * (i + 1) / 2;
-    double v;
-    if (i == j) {
-      v = c + nl * E.fin_w[i];
-      v = v + 1e-6;
-    } else {
-      v = c * corr_fn(E.kernel_type, E.nu_code, sa[i], sa[j]);
+  // K (lower, packed) and X = I, 16x16 thread tiles over (i, j), j <= i
+  for (int i0 = 0; i0 < n; i0 += 16)
+    for (int j0 = 0; j0 <= i0; j0 += 16) {
+      const int i = i0 + ty, j = j0 + tx;
+      if (i < n && j <= i) {
+        double v;
+        if (i == j) {
+          v = c + nl * E.fin_w[i];
+          v = v + 1e-6;
+        } else {
+          v = c * corr_fn(E.kernel_type, E.nu_code, sa[i], sa[j]);
+        }
+        Lp[PK(i, j)] = v;
+        Xp[PK(i, j)] = (i == j) ? 1.0 : 0.0;
+      }
     }
-    Lp[q] = v;
-  }
   __syncthreads();
-  // Cholesky, left-looking, packed
-  for (int j = 0; j < n; ++j) {
-    const double* rj = Lp + j * (j + 1) / 2;
-    for (int i = j + tid; i < n; i += bs) {
-      double* ri = Lp + i * (i + 1) / 2;
-      double sacc = ri[j];
-      for (int t = 0; t < j; ++t) sacc -= ri[t] * rj[t];
-      if (i == j) s_diag = sacc; else ri[j] = sacc;
-    }
-    __syncthreads();
-    const double d = s_diag;
+  double logdet = 0.0;
+  for (int k = 0; k < n; ++k) {
+    // phase A: finalise column k of L and row k of X
+    const double d = Lp[PK(k, k)];
     if (!(d > 0.0)) {
       if (tid == 0) s_bad = 1;
       break;
     }
-    const double dj = sqrt(d);
-    for (int i = j + tid; i < n; i += bs) {
-      double* ri = Lp + i * (i + 1) / 2;
-      if (i == j) ri[j] = dj; else ri[j] = ri[j] / dj;
+    const double dk = sqrt(d);
+    logdet += log(dk);  // every thread keeps the same running sum
+    __syncthreads();    // all reads of the unscaled pivot are done
+    for (int i = k + tid; i < n; i += bs) {
+      const double v = (i == k) ? dk : Lp[PK(i, k)] / dk;
+      Lp[PK(i, k)] = v;
+      sal[i] = v;
     }
+    for (int j = tid; j <= k; j += bs) Xp[PK(k, j)] = Xp[PK(k, j)] / dk;
+    __syncthreads();
+    // phase B: trailing updates
+    const int m = n - k - 1;
+    if (m > 0) {
+      //   L: a_ij -= l_ik l_jk for k < j <= i          (lower tiles of the m x m trailing block)
+      for (int a0 = 0; a0 < m; a0 += 16)
+        for (int b0 = 0; b0 <= a0; b0 += 16) {
+          const int ii = a0 + ty, jj = b0 + tx;
+          if (ii < m && jj <= ii) {
+            const int i = k + 1 + ii, j = k + 1 + jj;
+            Lp[PK(i, j)] -= sal[i] * sal[j];
+          }
+        }
+      //   X: x_ij -= l_ik x_kj for i > k, j <= k       (m x (k+1) block)
+      const int wcols = k + 1;
+      for (int e = tid; e < m * wcols; e += bs) {
+        const int ii = e / wcols, j = e - ii * wcols;
+        const int i = k + 1 + ii;
+        Xp[PK(i, j)] -= sal[i] * Xp[PK(k, j)];
+      }
+    }
+    // (the barrier at the top of the next step orders phase B before the next pivot scaling)
     __syncthreads();
   }
   __syncthreads();
@@ -1616,60 +1746,46 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
     }
     return;
   }
-  // X = L^-1, one column per thread
-  for (int j = tid; j < n; j += bs) {
-    Xp[j * (j + 1) / 2 + j] = 1.0 / Lp[j * (j + 1) / 2 + j];
-    for (int i = j + 1; i < n; ++i) {
-      const double* ri = Lp + i * (i + 1) / 2;
-      double acc = 0.0;
-      for (int k = j; k < i; ++k) acc += ri[k] * Xp[k * (k + 1) / 2 + j];
-      Xp[i * (i + 1) / 2 + j] = -acc / ri[i];
-    }
-  }
-  double ld = 0.0;
-  for (int i = tid; i < n; i += bs) ld += log(Lp[i * (i + 1) / 2 + i]);
-  const double logdet = block_sum(ld, s_red);  // (contains the barrier after the X columns)
-  // z = X y (in place over a copy), alpha = X^T z
+  // z = X y, alpha = X^T z
   for (int i = tid; i < n; i += bs) {
-    const double* xi = Xp + i * (i + 1) / 2;
+    const double* xi = Xp + PK(i, 0);
     double acc = 0.0;
     for (int k = 0; k <= i; ++k) acc += xi[k] * sy[k];
-    sal[i] = acc;  // z_i (temporarily in sal)
+    sal[i] = acc;
   }
   __syncthreads();
   for (int j = tid; j < n; j += bs) {
     double acc = 0.0;
-    for (int i = j; i < n; ++i) acc += Xp[i * (i + 1) / 2 + j] * sal[i];
-    sa[j] = acc;  // alpha_j (sa no longer needed as scaled inputs? -> keep a copy below)
+    for (int i = j; i < n; ++i) acc += Xp[PK(i, j)] * sal[i];
+    sa[j] = acc;  // alpha (the scaled inputs are recomputed from fin_x below)
   }
   __syncthreads();
-  // sa now holds alpha; scaled inputs are recomputed on the fly from E.fin_x
   double yta = 0.0;
   for (int i = tid; i < n; i += bs) yta += sy[i] * sa[i];
   yta = block_sum(yta, s_red);
-  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij
+  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij over 16x16 tiles of the lower triangle
   double gc = 0.0, gl = 0.0, gn = 0.0;
-  for (int q = tid; q < np; q += bs) {
-    int i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= q) ++i;
-    while (i * (i + 1) / 2 > q) --i;
-    const int j = q - i * (i + 1) / 2;
-    double kinv = 0.0;
-    for (int k = i; k < n; ++k) {
-      const double* xk = Xp + k * (k + 1) / 2;
-      kinv += xk[i] * xk[j];
+  for (int i0 = 0; i0 < n; i0 += 16)
+    for (int j0 = 0; j0 <= i0; j0 += 16) {
+      const int i = i0 + ty, j = j0 + tx;
+      if (i < n && j <= i) {
+        double kinv = 0.0;
+        for (int k = i; k < n; ++k) {
+          const double* xk = Xp + PK(k, 0);
+          kinv += xk[i] * xk[j];
+        }
+        const double inner = sa[i] * sa[j] - kinv;
+        if (i == j) {
+          gc += inner * c;
+          gn += inner * (nl * E.fin_w[i]);
+        } else {
+          double R, dR;
+          corr_and_dlog(E.kernel_type, E.nu_code, E.fin_x[i] / ell, E.fin_x[j] / ell, R, dR);
+          gc += 2.0 * inner * (c * R);
+          gl += 2.0 * inner * (c * dR);
+        }
+      }
     }
-    const double inner = sa[i] * sa[j] - kinv;
-    if (i == j) {
-      gc += inner * c;
-      gn += inner * (nl * E.fin_w[i]);
-    } else {
-      double R, dR;
-      corr_and_dlog(E.kernel_type, E.nu_code, E.fin_x[i] / ell, E.fin_x[j] / ell, R, dR);
-      gc += 2.0 * inner * (c * R);
-      gl += 2.0 * inner * (c * dR);
-    }
-  }
   gc = block_sum(gc, s_red);
   gl = block_sum(gl, s_red);
   gn = block_sum(gn, s_red);
@@ -1773,12 +1889,17 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
 
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  int pth = bd.Lg >= 1024 ? 1024 : (bd.Lg > 512 ? 1024 : (bd.Lg > 256 ? 512 : 256));
-  hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)(bd.Lg + bd.r_cap) * sizeof(double), st, d_edges);
+  if (bd.Lg <= 512 && bd.r_cap <= PCH_R) {
+    hipLaunchKernelGGL(k_pchol_reg, dim3(1, B), dim3(512), 0, st, d_edges);
+  } else {
+    int pth = bd.Lg >= 1024 ? 1024 : (bd.Lg > 512 ? 1024 : (bd.Lg > 256 ? 512 : 256));
+    hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)(bd.Lg + bd.r_cap) * sizeof(double), st, d_edges);
+  }
   const int t = cdiv(bd.r_cap, 16);
   hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
   if (bd.r_cap <= 96) {
-    const size_t lds = (size_t)2 * bd.r_cap * (bd.r_cap | 1) * sizeof(double);
+    const int mm = (bd.r_cap + 1) & ~1;
+    const size_t lds = (size_t)2 * mm * (mm | 1) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
