@@ -324,6 +324,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     if (E.n_cap > bd.n_cap) bd.n_cap = E.n_cap;
     if (E.n_bins > bd.n_bins) bd.n_bins = E.n_bins;
     if (E.obs_cap > bd.obs_cap) bd.obs_cap = E.obs_cap;
+    if (E.a_rows_cap > bd.a_rows_cap) bd.a_rows_cap = E.a_rows_cap;
     if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
   }
   b->bd = bd;

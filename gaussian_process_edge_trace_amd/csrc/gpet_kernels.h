@@ -5,7 +5,7 @@
 namespace gpet {
 
 struct BatchDims {
-  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap, z_ring;
+  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap, z_ring, a_rows_cap;
 };
 
 hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,

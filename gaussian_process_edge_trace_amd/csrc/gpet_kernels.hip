@@ -3,6 +3,7 @@
 #include "gpet_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace gpet {
 
@@ -1076,6 +1077,201 @@ __global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
     }
 }
 
+// K6 on the matrix cores: v_mfma_f64_16x16x4_f64.  64x64 output tile per workgroup, 4 waves, wave w
+// owns rows 16w..16w+15 and all 64 columns (4 accumulators of 4 f64 per lane); K streamed through
+// LDS in chunks of 32.  Operand maps (cdna_hip_programming.md section 3): A lane l <- A[l&15][l>>4],
+// B lane l <- B[l>>4][l&15]; D register g of lane l -> row (l>>4) + 4g, column l&15.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int Lg = E.Lg, S = E.S, zc = E.z_cols;
+  const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (s0 >= S || j0 >= Lg) return;
+  const int rows = sc->rank;
+  const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  __shared__ double sz[64][33];  // [s][k]
+  __shared__ double sa[32][65];  // [k][j]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < rows; k0 += 32) {
+    for (int e = tid; e < 64 * 32; e += 256) {
+      const int kk = e & 31, ss = e >> 5;
+      const int k = k0 + kk, sidx = s0 + ss;
+      sz[ss][kk] = (k < rows && sidx < S) ? Zs[(size_t)sidx * zc + k] : 0.0;
+    }
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int jj = e & 63, kk = e >> 6;
+      const int k = k0 + kk, j = j0 + jj;
+      sa[kk][jj] = (k < rows && j < Lg) ? E.A[(size_t)k * Lg + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+      const double a = sz[16 * w + li][kk + lq];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = sa[kk + lq][16 * t + li];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const double y_s = sc->y_s;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + 16 * t + li;
+    if (j >= Lg) continue;
+    const double mu = E.mean[j];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int sidx = s0 + 16 * w + lq + 4 * g;
+      if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[t][g] + mu) * y_s;
+    }
+  }
+}
+
+// K6, rank <= 96 (the production case): each wave keeps its 16 rows of Z -- the whole K extent,
+// 24 f64 per lane -- in registers for the entire sweep over the columns, so Z is read exactly
+// once.  A workgroup is 8 waves = 128 sample rows; the K x 64 chunk of the factor for the
+// current column tile sits in LDS (shared by the 8 waves) while the next chunk is already in
+// flight from HBM/L2 into registers, so the matrix pipe does not wait for the staging.
+// The MFMA loop only runs over the actual rank (rounded up to 4).
+#define GEMM_KMAX 96
+#define GEMM_PF ((GEMM_KMAX * 64) / 512)  // prefetch registers per thread
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int Lg = E.Lg, S = E.S, zc = E.z_cols;
+  const int s0 = blockIdx.x * 128;
+  if (s0 >= S) return;
+  const int rows = sc->rank;
+  const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  extern __shared__ double s_fa[];  // [GEMM_KMAX][65]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int srow = s0 + 16 * w + li;
+  double areg[GEMM_KMAX / 4];
+#pragma unroll
+  for (int q = 0; q < GEMM_KMAX / 4; ++q) {
+    const int k = 4 * q + lq;
+    areg[q] = (k < rows && srow < S) ? Zs[(size_t)srow * zc + k] : 0.0;
+  }
+  const int ksteps = (rows + 3) >> 2;
+  const int kfill = ksteps * 4;
+  const double y_s = sc->y_s;
+  double pf[GEMM_PF];
+  // element e = tid + 512 * u of the [kfill][64] chunk: row kk = e >> 6, column jj = e & 63
+#pragma unroll
+  for (int u = 0; u < GEMM_PF; ++u) {
+    const int e = tid + 512 * u;
+    const int kk = e >> 6, j = e & 63;
+    pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
+  }
+  for (int j0 = 0; j0 < Lg; j0 += 64) {
+    __syncthreads();  // previous tile's LDS reads are done
+#pragma unroll
+    for (int u = 0; u < GEMM_PF; ++u) {
+      const int e = tid + 512 * u;
+      if (e < kfill * 64) s_fa[(e >> 6) * 65 + (e & 63)] = pf[u];
+    }
+    __syncthreads();
+    if (j0 + 64 < Lg) {  // next tile's chunk: loads stay in flight during the MFMAs below
+#pragma unroll
+      for (int u = 0; u < GEMM_PF; ++u) {
+        const int e = tid + 512 * u;
+        const int kk = e >> 6, j = j0 + 64 + (e & 63);
+        pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
+      }
+    }
+    v4f64 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < GEMM_KMAX / 4; ++q) {
+      if (q < ksteps) {
+        const double a = areg[q];
+        const double* brow = s_fa + (4 * q + lq) * 65 + li;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * t], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + 16 * t + li;
+      if (j >= Lg) continue;
+      const double mu = E.mean[j];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sidx = s0 + 16 * w + lq + 4 * g;
+        if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[t][g] + mu) * y_s;
+      }
+    }
+  }
+}
+
+// cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
+// both operands are 32-row chunks of V; only tiles on or above the diagonal are computed and mirrored.
+__global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int Lg = E.Lg;
+  const int r0 = by * 64, c0 = bx * 64;
+  if (r0 >= Lg || c0 >= Lg) return;
+  const int n = sc->n;
+  __shared__ double sr[32][65];  // [i][row j]
+  __shared__ double sc_[32][65]; // [i][col j']
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int jj = e & 63, ii = e >> 6;
+      const int i = i0 + ii;
+      sr[ii][jj] = (i < n && r0 + jj < Lg) ? E.V[(size_t)i * Lg + r0 + jj] : 0.0;
+      sc_[ii][jj] = (i < n && c0 + jj < Lg) ? E.V[(size_t)i * Lg + c0 + jj] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+      const double a = sr[kk + lq][16 * w + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = sc_[kk + lq][16 * t + li];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const double amp = sc->amp, s2 = sc->y_std * sc->y_std;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = c0 + 16 * t + li;
+    if (c >= Lg) continue;
+    const double xc = (double)(E.x_st + c) / E.length_scale;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = r0 + 16 * w + lq + 4 * g;
+      if (r >= Lg) continue;
+      if (bx == by && c < r) continue;  // diagonal tile: the mirror write below covers it
+      const double k = (r == c) ? amp : amp * corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + r) / E.length_scale, xc);
+      const double val = (k - acc[t][g]) * s2;
+      E.cov[(size_t)r * Lg + c] = val;
+      E.cov[(size_t)c * Lg + r] = val;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // a7  cost of every sampled curve (gpet.py:391-408): one wave per curve, Simpson pairs
 //     spread over the lanes.
@@ -1432,6 +1628,129 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges, int rows_per_
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc += s_t[(xl + t) * ld + yl] * g[t];
       acc *= 0.15915494309189535;  // 1 / (2 pi): 2-D Gaussian pdf normalisation
+      const float v = (float)acc;
+      out[(size_t)y * N + x] = v;
+      const unsigned int key = f32_order_key(v);
+      kmin = min(kmin, key);
+      kmax = max(kmax, key);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
+    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(&E.mm[0], kmin);
+    atomicMax(&E.mm[1], kmax);
+  }
+}
+
+// Full-height variant (M <= 700): one workgroup per (16-column tile, edge), a single
+// (KDE_TX+8) x (M+8) f64 LDS tile.  Binning runs on 24 columns x 8 row-slots (thread owns the rows
+// l with l % 8 == slot, scans the curves in order -> per-bin summation order is the sequential
+// one, with 8x the parallelism); the vertical 9-tap pass is done in place with a register sliding
+// window (each thread first saves the 8 halo values that neighbouring segments overwrite).
+__global__ void __launch_bounds__(256) k_kde_fused_full(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if (sc->done || sc->status != GPET_OK) return;
+  extern __shared__ double s_a[];
+  const int M = E.M, N = E.N;
+  const int x0 = blockIdx.x * KDE_TX;
+  if (x0 >= N) return;
+  const int NC = KDE_TX + 8;
+  const int ld = (M + 8) | 1;
+  double* s_y = s_a + NC * ld;   // [64][NC]
+  double* s_wt = s_y + 64 * NC;  // [64]
+  const int tid = threadIdx.x;
+  const bool band = (x0 + KDE_TX + 4 > E.x_st) && (x0 - 4 <= E.x_en);
+  float* __restrict__ out = E.kde;
+  unsigned int kmin = 0xFFFFFFFFu, kmax = 0u;
+  if (!band) {
+    for (int idx = tid; idx < KDE_TX * M; idx += 256) {
+      const int xl = idx % KDE_TX, y = idx / KDE_TX;
+      if (x0 + xl < N) out[(size_t)y * N + x0 + xl] = 0.f;
+    }
+    kmin = kmax = f32_order_key(0.f);
+  } else {
+    for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
+    const double W = E.colsum[0], inv_sum = E.colsum[1], ymax = (double)(M - 1);
+    const int bc = tid % NC, slot = tid / NC;  // binning role (tid < 8 * NC)
+    for (int b0 = 0; b0 < E.n_keep; b0 += 64) {
+      const int nb = (E.n_keep - b0) < 64 ? (E.n_keep - b0) : 64;
+      __syncthreads();
+      for (int e = tid; e < nb * NC; e += 256) {
+        const int bb = e / NC, c = e - bb * NC;
+        const int xc = x0 + c - 4;
+        double y = -1.0;
+        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)E.best_idx[b0 + bb] * E.Lg + (xc - E.x_st)];
+        s_y[e] = y;
+      }
+      for (int e = tid; e < nb; e += 256) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
+      __syncthreads();
+      if (slot < 8) {
+        double* col = s_a + bc * ld;
+        for (int bb = 0; bb < nb; ++bb) {
+          const double y = s_y[bb * NC + bc];
+          if (y < 0.0 || y > ymax) continue;  // gpet.py:498-500 (and columns outside the edge)
+          const double gy = y + 1.0;
+          const int iy = (int)floor(gy);
+          const int l = iy + 3;  // LDS row of padded-grid row gy (halo 4, gy = -1 -> l = 2 ... )
+          const bool lo = ((l & 7) == slot), hi = (((l + 1) & 7) == slot);
+          if (!(lo || hi)) continue;
+          const double w = s_wt[bb];
+          const double fy = gy - (double)iy;
+          if (lo) col[l] += (1.0 - fy) * w;
+          if (hi) col[l + 1] += fy * w;
+        }
+      }
+    }
+    __syncthreads();
+    double g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
+    // vertical pass, in place: filtered value of image row y is written to LDS row y + 4
+    {
+      int nseg = 256 / NC;                       // segments per column, each >= 16 rows
+      if (nseg > M / 16) nseg = (M / 16 > 0) ? M / 16 : 1;
+      const int seg = tid / NC, c = tid % NC;    // (tid < nseg * NC)
+      const int R = (M + nseg - 1) / nseg;
+      const int y0 = seg * R, y1 = (y0 + R < M) ? (y0 + R) : M;
+      double* col = s_a + c * ld;
+      double head[4], tail[4];
+      const bool active = (seg < nseg) && (y0 < M);
+      if (active) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          head[t] = col[y0 + t];       // rows the previous segment overwrites (its last outputs)
+          tail[t] = col[y1 + 4 + t];   // rows the next segment overwrites (its first outputs)
+        }
+      }
+      __syncthreads();
+      if (active) {
+        double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
+        double w4 = col[y0 + 4], w5 = col[y0 + 5], w6 = col[y0 + 6], w7 = col[y0 + 7];
+        for (int y = y0; y < y1; ++y) {
+          const int lnew = y + 8;
+          const double w8 = (lnew >= y1 + 4) ? tail[lnew - (y1 + 4)] : col[lnew];
+          const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
+                             w7 * g[7] + w8 * g[8];
+          col[y + 4] = acc;
+          w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+        }
+      }
+    }
+    __syncthreads();
+    // horizontal pass + crop + f32
+    for (int idx = tid; idx < KDE_TX * M; idx += 256) {
+      const int xl = idx % KDE_TX, y = idx / KDE_TX;
+      const int x = x0 + xl;
+      if (x >= N) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += s_a[(xl + t) * ld + y + 4] * g[t];
+      acc *= 0.15915494309189535;  // 1 / (2 pi)
       const float v = (float)acc;
       out[(size_t)y * N + x] = v;
       const unsigned int key = f32_order_key(v);
@@ -1864,8 +2183,8 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
   else
     hipLaunchKernelGGL((k_predict<false, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, 0);
   if (want_cov) {
-    const int t = cdiv(bd.Lg, 32);
-    hipLaunchKernelGGL(k_cov, dim3(t, t, B), dim3(256), 0, st, d_edges);
+    const int t = cdiv(bd.Lg, 64);
+    hipLaunchKernelGGL(k_cov_mfma, dim3(t, t, B), dim3(256), 0, st, d_edges);
   }
   return hipGetLastError();
 }
@@ -1905,7 +2224,8 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges);
+    const int jt = getenv("GPET_JACOBI_THREADS") ? atoi(getenv("GPET_JACOBI_THREADS")) : 1024;
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(jt), lds, st, d_edges);
   } else {
     const int half = (bd.r_cap + 2) / 2;
     hipLaunchKernelGGL(k_jacobi, dim3(1, B), dim3(1024), (size_t)(2 * half) * sizeof(double) + 2 * half * sizeof(int),
@@ -1937,7 +2257,17 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
     const int rows = cdiv(bd.M, nchunk);
     const size_t lds = ((size_t)2 * (KDE_TX + 8) * ((rows + 8) | 1) + 64 * (KDE_TX + 8) + 64) * sizeof(double);
     hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
-    hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), cdiv(bd.M, rows), B), dim3(256), lds, st, d_edges, rows);
+    if (bd.M <= 700) {
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)k_kde_fused_full, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr2 = true;
+      }
+      const size_t lds_full = ((size_t)(KDE_TX + 8) * ((bd.M + 8) | 1) + 64 * (KDE_TX + 8) + 64) * sizeof(double);
+      hipLaunchKernelGGL(k_kde_fused_full, dim3(cdiv(bd.N, KDE_TX), B), dim3(256), lds_full, st, d_edges);
+    } else {
+      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), cdiv(bd.M, rows), B), dim3(256), lds, st, d_edges, rows);
+    }
     hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
@@ -1976,7 +2306,14 @@ hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_sample_gemm, dim3(cdiv(bd.Lg, 64), cdiv(bd.S, 64), B), dim3(256), 0, st, d_edges);
+  // rank <= 96 everywhere in the batch (factor capacity): Z rows stay in registers; otherwise
+  // (full factors injected by tests, Matern ranks) the K-chunked kernel
+  if (bd.r_cap <= GEMM_KMAX && bd.a_rows_cap <= GEMM_KMAX) {
+    hipLaunchKernelGGL(k_sample_gemm_mfma_r, dim3(cdiv(bd.S, 128), B), dim3(512),
+                       (size_t)GEMM_KMAX * 65 * sizeof(double), st, d_edges);
+  } else {
+    hipLaunchKernelGGL(k_sample_gemm_mfma, dim3(cdiv(bd.Lg, 64), cdiv(bd.S, 64), B), dim3(256), 0, st, d_edges);
+  }
   return hipGetLastError();
 }
 
