@@ -37,7 +37,7 @@ class GpetScalars(C.Structure):
     _fields_ = [("y_s", C.c_double), ("amp", C.c_double), ("y_mean", C.c_double), ("y_std", C.c_double),
                 ("score_thresh", C.c_double), ("lml", C.c_double), ("n", C.c_int32), ("n_obs", C.c_int32),
                 ("rank", C.c_int32), ("status", C.c_int32), ("iter", C.c_int32), ("done", C.c_int32),
-                ("n_removed", C.c_int32), ("reserved", C.c_int32)]
+                ("n_removed", C.c_int32), ("force", C.c_int32)]
 
 
 class GpetError(RuntimeError):

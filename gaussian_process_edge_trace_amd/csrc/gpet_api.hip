@@ -107,6 +107,8 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.W = cv.take<double>(rc * rc);
   E.theta = cv.take<double>(rc);
   E.order = cv.take<int>(rc);
+  E.jb_cs = cv.take<double>(2 * (rc / 2 + 1));
+  E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
   E.Y = cv.take<double>(S * Lg);
@@ -271,6 +273,12 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   BatchDims bd{};
   bd.M = M;
   bd.N = N;
+  bool any_big = false;
+  for (int e = 0; e < B; ++e) {
+    const int Lg_e = params[e].x_en - params[e].x_st + 1;
+    const int cap = params[e].factor_cap > 0 ? params[e].factor_cap : 96;
+    if ((cap < Lg_e ? cap : Lg_e) > 96) any_big = true;
+  }
   for (int e = 0; e < B; ++e) {
     const gpet_params& p = params[e];
     EdgeDev& E = b->h_edges[e];
@@ -300,8 +308,12 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     E.n_cap = E.n_init + E.obs_cap;
     E.r_cap = p.factor_cap > 0 ? p.factor_cap : 96;  // <= 96: the LDS-resident Jacobi path
     if (E.r_cap > Lg) E.r_cap = Lg;
+    // A capacity above 96 selects the whole-GPU Jacobi on the full covariance; that path is
+    // chosen per batch, so then every edge keeps all Lg directions.
+    if (any_big) E.r_cap = Lg;
     E.z_cols = p.z_cols > 0 ? p.z_cols : E.r_cap;
     if (E.z_cols > Lg) E.z_cols = Lg;
+    if (any_big) E.z_cols = Lg;
     if (E.z_cols < E.r_cap) E.r_cap = E.z_cols;
     E.a_rows_cap = (E.z_cols >= Lg) ? Lg : E.r_cap;
     // ring of pre-generated normals; full-stream mode (z_cols == Lg) is for tests: keep it small
@@ -621,7 +633,9 @@ int gpet_gp_fit_predict(gpet_batch* b, int want_cov) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, want_cov));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->have_fit = true;
   return check_device_status(b);
 }
@@ -631,7 +645,9 @@ int gpet_gp_factor(gpet_batch* b) {
   gpet_ctx* c = b->ctx;
   if (!b->have_fit) return fail(c, GPET_ERR_STATE, "gpet_gp_factor before gpet_gp_fit_predict");
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->have_factor = true;
   return check_device_status(b);
 }
@@ -641,7 +657,9 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, -1, 1));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   b->have_normals = true;
   return GPET_OK;
@@ -653,7 +671,9 @@ int gpet_gp_sample(gpet_batch* b) {
   if (!b->have_fit || !b->have_factor || !b->have_normals)
     return fail(c, GPET_ERR_STATE, "gpet_gp_sample needs fit, factor and normals first");
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->have_samples = true;
   return GPET_OK;
 }
@@ -666,7 +686,9 @@ int gpet_score_curves(gpet_batch* b) {
     if (b->h_edges[e].Lg % 2 != 0)
       return fail(c, GPET_ERR_UNSUPPORTED, "edge %d: odd edge_length=%d (Simpson on an even sample count is scipy-version dependent)", e, b->h_edges[e].Lg);
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->have_scores = true;
   return GPET_OK;
 }
@@ -676,8 +698,10 @@ int gpet_select_pixels(gpet_batch* b) {
   gpet_ctx* c = b->ctx;
   if (!b->have_scores) return fail(c, GPET_ERR_STATE, "gpet_select_pixels before gpet_score_curves");
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
   HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->iters_issued += 1;  // k_pix_select advanced every active edge's iteration counter
   return check_device_status(b);
 }
@@ -841,8 +865,10 @@ int gpet_select_pixels_only(gpet_batch* b) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd));
   HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->iters_issued += 1;
   return check_device_status(b);
 }

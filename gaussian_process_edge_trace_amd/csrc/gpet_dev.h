@@ -33,6 +33,8 @@ struct EdgeDev {
   int* perm;             // [r_cap]
   double *C, *W, *theta; // [r_cap*r_cap], [r_cap*r_cap], [r_cap]
   int* order;            // [r_cap] eigenvalue order (descending)
+  double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
+  double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
   double* Y;             // [S*Lg]

@@ -20,6 +20,7 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
                           int iter_abs, int n_ahead);
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);

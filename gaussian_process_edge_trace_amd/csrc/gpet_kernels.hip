@@ -142,7 +142,7 @@ template <bool K_IN_LDS, bool FINAL>
 __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (!FINAL && (sc->done || sc->status != GPET_OK)) return;
+  if (!FINAL && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   extern __shared__ double s_dyn[];  // [n_cap] solve vector (+ [n_cap * ld] matrix when K_IN_LDS)
   __shared__ double s_red[16];
   __shared__ double s_diag;
@@ -311,7 +311,7 @@ template <bool V_LDS, bool FINAL>
 __global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (!FINAL && (sc->done || sc->status != GPET_OK)) return;
+  if (!FINAL && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   extern __shared__ double s_dyn[];
   const int lane = threadIdx.x;
   const int j = blockIdx.x * 64 + lane;
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) 
 __global__ void __launch_bounds__(256) k_cov(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int bx = blockIdx.x, by = blockIdx.y;
   if (bx < by) return;
   const int Lg = E.Lg;
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256) k_cov(EdgeDev* edges) {
 __global__ void __launch_bounds__(1024) k_pchol(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   extern __shared__ double s_d[];  // [Lg] remaining diagonal
   __shared__ double s_val[16];
   __shared__ int s_idx[16];
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(1024) k_pchol(EdgeDev* edges) {
 __global__ void __launch_bounds__(512) k_pchol_reg(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   __shared__ double s_d[512];
   __shared__ double s_gp[PCH_R];
   __shared__ double s_val[8];
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(512) k_pchol_reg(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   const int r = sc->rank, Lg = E.Lg;
   const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
   if (a0 >= r || b0 >= r || b0 > a0) return;
@@ -654,120 +654,6 @@ __global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
   }
 }
 
-// step 3: cyclic two-sided Jacobi (round-robin ordering) of the rank x rank Gram matrix.
-// C and the accumulated rotations W live in global memory (L2-resident, <= r_cap^2 doubles).
-__global__ void __launch_bounds__(1024) k_jacobi(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
-  gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
-  extern __shared__ double s_mem[];  // [2*m] rotations (c, s), then scratch
-  __shared__ double s_red[16];
-  const int r = sc->rank, ld = E.r_cap;
-  const int tid = threadIdx.x, bs = blockDim.x;
-  double* A = E.C;
-  double* W = E.W;
-  for (int e = tid; e < r * r; e += bs) {
-    const int i = e / r, j = e - i * r;
-    W[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  const int m = (r + 1) & ~1;  // even number of players; index m-1 may be a bye (== r)
-  const int half = m >> 1;
-  double* s_c = s_mem;
-  double* s_s = s_mem + half;
-  int* s_p = (int*)(s_mem + 2 * half);
-  int* s_q = s_p + half;
-  if (r >= 2) {
-    for (int sweep = 0; sweep < 40; ++sweep) {
-      // convergence: off(A)^2 <= eps^2 * diag(A)^2
-      double off = 0.0, dg = 0.0;
-      for (int e = tid; e < r * r; e += bs) {
-        const int i = e / r, j = e - i * r;
-        const double v = A[(size_t)i * ld + j];
-        if (i == j) dg += v * v; else off += v * v;
-      }
-      off = block_sum(off, s_red);
-      dg = block_sum(dg, s_red);
-      if (off <= 1e-30 * dg || off == 0.0) break;
-      for (int round = 0; round < m - 1; ++round) {
-        // rotation parameters for this round's disjoint pairs
-        if (tid < half) {
-          int p, q;
-          if (tid == 0) {
-            p = m - 1;
-            q = round;
-          } else {
-            p = (round + tid) % (m - 1);
-            q = (round - tid + (m - 1)) % (m - 1);
-          }
-          if (p > q) {
-            const int t = p;
-            p = q;
-            q = t;
-          }
-          double c = 1.0, s = 0.0;
-          if (q < r) {
-            const double apq = A[(size_t)p * ld + q];
-            const double app = A[(size_t)p * ld + p], aqq = A[(size_t)q * ld + q];
-            if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
-              const double tau = (aqq - app) / (2.0 * apq);
-              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-              c = 1.0 / sqrt(1.0 + t * t);
-              s = t * c;
-            }
-          } else {
-            q = -1;  // bye
-          }
-          s_c[tid] = c;
-          s_s[tid] = s;
-          s_p[tid] = p;
-          s_q[tid] = q;
-        }
-        __syncthreads();
-        // column rotations on A and W: (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)
-        for (int e = tid; e < half * r; e += bs) {
-          const int k = e / r, i = e - k * r;
-          const int p = s_p[k], q = s_q[k];
-          if (q < 0) continue;
-          const double c = s_c[k], s = s_s[k];
-          if (s == 0.0) continue;
-          const double ap = A[(size_t)i * ld + p], aq = A[(size_t)i * ld + q];
-          A[(size_t)i * ld + p] = c * ap - s * aq;
-          A[(size_t)i * ld + q] = s * ap + c * aq;
-          const double wp = W[(size_t)i * ld + p], wq = W[(size_t)i * ld + q];
-          W[(size_t)i * ld + p] = c * wp - s * wq;
-          W[(size_t)i * ld + q] = s * wp + c * wq;
-        }
-        __syncthreads();
-        // row rotations on A
-        for (int e = tid; e < half * r; e += bs) {
-          const int k = e / r, j = e - k * r;
-          const int p = s_p[k], q = s_q[k];
-          if (q < 0) continue;
-          const double c = s_c[k], s = s_s[k];
-          if (s == 0.0) continue;
-          const double ap = A[(size_t)p * ld + j], aq = A[(size_t)q * ld + j];
-          A[(size_t)p * ld + j] = c * ap - s * aq;
-          A[(size_t)q * ld + j] = s * ap + c * aq;
-        }
-        __syncthreads();
-      }
-    }
-  }
-  // eigenvalues + descending order (rank by counting; ties -> lower index first)
-  for (int k = tid; k < r; k += bs) E.theta[k] = A[(size_t)k * ld + k];
-  __syncthreads();
-  for (int k = tid; k < r; k += bs) {
-    const double v = E.theta[k];
-    int pos = 0;
-    for (int j = 0; j < r; ++j) {
-      const double u = E.theta[j];
-      pos += (u > v) || (u == v && j < k);
-    }
-    E.order[pos] = k;
-  }
-}
-
 // step 3 (fast path, r_cap <= 96): the same cyclic Jacobi with the Gram matrix and the
 // accumulated rotations resident in LDS (2 * m * (m|1) doubles <= 146 KB of the CU's 160 KB).
 // A round applies its m/2 disjoint rotations as independent 2x2 blocks: block (a, b) holds the
@@ -778,7 +664,7 @@ __global__ void __launch_bounds__(1024) k_jacobi(EdgeDev* edges) {
 __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   extern __shared__ double s_mem[];
   __shared__ double s_red[16];
   __shared__ double s_c[64], s_s[64];
@@ -886,7 +772,174 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
     }
     E.order[pos] = k;
   }
-  if (tid == 0) sc->reserved = sweeps;
+  if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
+}
+
+// ---- large ranks (r_cap > 96: Matern spectra, short RBF length scales) ---------------------
+// Cyclic Jacobi applied directly to the Lg x Lg posterior covariance, spread over the whole GPU:
+// one parameter kernel + one apply kernel per round (the round's Lg/2 disjoint rotations touch
+// disjoint 2x2 blocks), matrices in HBM/L2.  No pivoted Cholesky / Gram step: the eigenvectors
+// are the singular vectors numpy's SVD returns (up to sign), singular values = |eigenvalues|.
+__device__ __forceinline__ void jb_pair(int m, int round, int k, int& p, int& q) {
+  if (k == 0) {
+    p = m - 1;
+    q = round;
+  } else {
+    p = (round + k) % (m - 1);
+    q = (round - k + (m - 1)) % (m - 1);
+  }
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_jb_init(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = E.Lg, ld = E.r_cap;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)r * r; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / r), j = (int)(e - (size_t)i * r);
+    E.C[(size_t)i * ld + j] = E.cov[(size_t)i * r + j];
+    E.W[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc->rank = r;
+    E.jb_norm[0] = 1.0;  // "not converged yet"
+    E.jb_norm[1] = 1.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_jb_params(EdgeDev* edges, int round) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  if (E.jb_norm[0] <= 1e-24 * E.jb_norm[1]) return;  // converged: remaining launches are no-ops
+  const int r = E.Lg, ld = E.r_cap;
+  const int m = (r + 1) & ~1, half = m >> 1;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= half) return;
+  int p, q;
+  jb_pair(m, round, k, p, q);
+  double c = 1.0, s = 0.0;
+  if (q < r) {
+    const double apq = E.C[(size_t)p * ld + q];
+    const double app = E.C[(size_t)p * ld + p], aqq = E.C[(size_t)q * ld + q];
+    if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
+      const double tau = (aqq - app) / (2.0 * apq);
+      const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+      c = 1.0 / sqrt(1.0 + t * t);
+      s = t * c;
+    }
+  }
+  E.jb_cs[2 * k] = c;
+  E.jb_cs[2 * k + 1] = s;
+}
+
+// blockIdx.x enumerates (a, b-tile) for the 2x2 blocks, then the W items
+__global__ void __launch_bounds__(256) k_jb_apply(EdgeDev* edges, int round) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  if (E.jb_norm[0] <= 1e-24 * E.jb_norm[1]) return;
+  const int r = E.Lg, ld = E.r_cap;
+  const int m = (r + 1) & ~1, half = m >> 1;
+  const long long nblk = (long long)half * half, nw = (long long)half * r;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < nblk + nw;
+       e += (long long)gridDim.x * blockDim.x) {
+    if (e < nblk) {
+      const int a = (int)(e / half), b = (int)(e - (long long)a * half);
+      const double sa = E.jb_cs[2 * a + 1], sb = E.jb_cs[2 * b + 1];
+      if (sa == 0.0 && sb == 0.0) continue;
+      const double ca = E.jb_cs[2 * a], cb = E.jb_cs[2 * b];
+      int pa, qa, pb, qb;
+      jb_pair(m, round, a, pa, qa);
+      jb_pair(m, round, b, pb, qb);
+      if (qa >= r || qb >= r) continue;  // the padding index of an odd size never rotates
+      double* A = E.C;
+      const double b00 = A[(size_t)pa * ld + pb], b01 = A[(size_t)pa * ld + qb];
+      const double b10 = A[(size_t)qa * ld + pb], b11 = A[(size_t)qa * ld + qb];
+      const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+      const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+      A[(size_t)pa * ld + pb] = ca * t00 - sa * t10;
+      A[(size_t)qa * ld + pb] = sa * t00 + ca * t10;
+      A[(size_t)pa * ld + qb] = ca * t01 - sa * t11;
+      A[(size_t)qa * ld + qb] = sa * t01 + ca * t11;
+    } else {
+      const long long f = e - nblk;
+      const int b = (int)(f / r), i = (int)(f - (long long)b * r);
+      const double sb = E.jb_cs[2 * b + 1];
+      if (sb == 0.0) continue;
+      const double cb = E.jb_cs[2 * b];
+      int pb, qb;
+      jb_pair(m, round, b, pb, qb);
+      if (qb >= r) continue;
+      const double wp = E.W[(size_t)i * ld + pb], wq = E.W[(size_t)i * ld + qb];
+      E.W[(size_t)i * ld + pb] = cb * wp - sb * wq;
+      E.W[(size_t)i * ld + qb] = sb * wp + cb * wq;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_jb_norms(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  __shared__ double s_red[16];
+  const int r = E.Lg, ld = E.r_cap;
+  double off = 0.0, dg = 0.0;
+  for (size_t e = threadIdx.x; e < (size_t)r * r; e += blockDim.x) {
+    const int i = (int)(e / r), j = (int)(e - (size_t)i * r);
+    const double v = E.C[(size_t)i * ld + j];
+    if (i == j) dg += v * v; else off += v * v;
+  }
+  off = block_sum(off, s_red);
+  dg = block_sum(dg, s_red);
+  if (threadIdx.x == 0) {
+    E.jb_norm[0] = off;
+    E.jb_norm[1] = dg;
+  }
+}
+
+// singular values |theta| in descending order, factor rows sqrt(|theta_k|) * v_k with the sign convention
+__global__ void __launch_bounds__(1024) k_jb_order(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = E.Lg, ld = E.r_cap;
+  for (int k = threadIdx.x; k < r; k += blockDim.x) E.theta[k] = fabs(E.C[(size_t)k * ld + k]);
+  __syncthreads();
+  for (int k = threadIdx.x; k < r; k += blockDim.x) {
+    const double v = E.theta[k];
+    int pos = 0;
+    for (int j = 0; j < r; ++j) {
+      const double u = E.theta[j];
+      pos += (u > v) || (u == v && j < k);
+    }
+    E.order[pos] = k;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_jb_rows(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = E.Lg, Lg = E.Lg, ld = E.r_cap, k = blockIdx.x;
+  if (k >= r) return;
+  __shared__ double s_red[16];
+  const int col = E.order[k];
+  const double sv = sqrt(E.theta[col]);
+  double part = 0.0;
+  for (int j = threadIdx.x; j < Lg; j += blockDim.x) {
+    const double v = sv * E.W[(size_t)j * ld + col];
+    E.A[(size_t)k * Lg + j] = v;
+    part += v / (double)(j + 1);
+  }
+  const double dot = block_sum(part, s_red);
+  if (dot < 0.0)
+    for (int j = threadIdx.x; j < Lg; j += blockDim.x) E.A[(size_t)k * Lg + j] = -E.A[(size_t)k * Lg + j];
 }
 
 // step 4: factor rows  A[k, :] = sum_t W[t, order[k]] * G[t, :]  (= sqrt(s_k) v_k up to sign).
@@ -894,7 +947,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_factor_rows(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK || E.factor_injected) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   const int r = sc->rank, Lg = E.Lg, k = blockIdx.x;
   if (k >= r) return;
   __shared__ double s_red[16];
@@ -938,7 +991,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
 #pragma clang fp contract(off)
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   // iter_abs >= 0: the host names the iteration (the RNG stream runs ahead of the loop, so the
   // device counter is not meaningful here); otherwise relative to the edge's current iteration
   const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + (int)blockIdx.x;
@@ -1027,7 +1080,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
 __global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (s0 >= S || j0 >= Lg) return;
@@ -1085,7 +1138,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (s0 >= S || j0 >= Lg) return;
@@ -1146,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 __global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = blockIdx.x * 128;
   if (s0 >= S) return;
@@ -1220,7 +1273,7 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int bx = blockIdx.x, by = blockIdx.y;
   if (bx < by) return;
   const int Lg = E.Lg;
@@ -1290,7 +1343,7 @@ __device__ __forceinline__ double grad_at(const float* __restrict__ grad, int M,
 __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (s >= E.S) return;
@@ -1320,7 +1373,7 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   __shared__ double s_c[1024];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double ci = (i < E.S) ? E.costs[i] : 0.0;
@@ -1351,7 +1404,7 @@ __global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_kde_clear(EdgeDev* edges, int mode) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  if (mode == 0 && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   const size_t cells = (size_t)(E.N + 2) * (E.M + 2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cells; i += (size_t)gridDim.x * blockDim.x)
     E.bins[i] = 0.0;
@@ -1373,7 +1426,7 @@ __global__ void __launch_bounds__(256) k_kde_clear(EdgeDev* edges, int mode) {
 __global__ void __launch_bounds__(64) k_kde_bin_curves(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E.Lg) return;
   double inv_sum = 0.0;
@@ -1428,7 +1481,7 @@ __constant__ double c_gauss9[9] = {3.3546262790251185e-04, 1.1108996538242306e-0
 __global__ void __launch_bounds__(256) k_kde_conv_y(EdgeDev* edges, int mode) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  if (mode == 0 && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   const int H = E.M + 2, Wd = E.N + 2;
   const int gy = blockIdx.x * blockDim.x + threadIdx.x;
   const int gx = blockIdx.y;
@@ -1454,7 +1507,7 @@ __global__ void __launch_bounds__(256) k_kde_conv_y(EdgeDev* edges, int mode) {
 __global__ void __launch_bounds__(256) k_kde_conv_x(EdgeDev* edges, int mode) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  if (mode == 0 && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   const int H = E.M + 2, Wd = E.N + 2;
   const int y = blockIdx.x * blockDim.x + threadIdx.x;  // image row
   const int x = blockIdx.y;                             // image column
@@ -1489,7 +1542,7 @@ __global__ void __launch_bounds__(256) k_kde_conv_x(EdgeDev* edges, int mode) {
 __global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (mode == 0 && (sc->done || sc->status != GPET_OK)) return;
+  if (mode == 0 && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   const float mn = f32_from_key(E.mm[0]);
   const float span = f32_from_key(E.mm[1]) - mn;
   float* a = (mode == 0) ? E.kde : (float*)E.grad_kde;
@@ -1504,7 +1557,7 @@ __global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode)
 __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   __shared__ double s_red[16];
   __shared__ double s_inv;
   if (threadIdx.x == 0) {
@@ -1550,7 +1603,7 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges, int rows_per_chunk) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ double s_a[];
   const int M = E.M, N = E.N;
   const int x0 = blockIdx.x * KDE_TX;
@@ -1654,7 +1707,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges, int rows_per_
 __global__ void __launch_bounds__(256) k_kde_fused_full(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ double s_a[];
   const int M = E.M, N = E.N;
   const int x0 = blockIdx.x * KDE_TX;
@@ -1788,7 +1841,7 @@ __device__ __forceinline__ int bin_of(const EdgeDev& E, int x) {
 __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   __shared__ double s_best[16][17];
   __shared__ int s_by[16][17];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
@@ -1830,7 +1883,7 @@ __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sc->n_obs) return;
   const long long x = E.obs_xy[2 * i], y = E.obs_xy[2 * i + 1];
@@ -1846,7 +1899,7 @@ __global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges) {
 __global__ void __launch_bounds__(256) k_pix_argbest(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_obs = sc->n_obs;
   if (t < n_obs) {
@@ -1875,7 +1928,7 @@ __global__ void __launch_bounds__(64) k_pix_select(EdgeDev* edges) {
 #pragma clang fp contract(off)
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
-  if (sc->done || sc->status != GPET_OK) return;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int lane = threadIdx.x;
   const int n_pre = sc->n_obs;
   double thresh = sc->score_thresh;
@@ -2208,6 +2261,26 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
 
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
+  if (bd.r_cap > 96) {
+    // large ranks: whole-GPU Jacobi on the covariance itself.  A fixed budget of sweeps is
+    // enqueued; once the device-side convergence test passes the remaining launches return at once.
+    const int r = bd.Lg, m = (r + 1) & ~1, half = m >> 1;
+    const long long items = (long long)half * half + (long long)half * r;
+    int ablocks = (int)((items + 255) / 256);
+    if (ablocks > 4096) ablocks = 4096;
+    hipLaunchKernelGGL(k_jb_init, dim3(512, B), dim3(256), 0, st, d_edges);
+    // (graded spectra need up to ~20 sweeps from a cold start: linear phase, then quadratic)
+    for (int sweep = 0; sweep < 30; ++sweep) {
+      hipLaunchKernelGGL(k_jb_norms, dim3(1, B), dim3(1024), 0, st, d_edges);
+      for (int round = 0; round < m - 1; ++round) {
+        hipLaunchKernelGGL(k_jb_params, dim3(cdiv(half, 256), B), dim3(256), 0, st, d_edges, round);
+        hipLaunchKernelGGL(k_jb_apply, dim3(ablocks, B), dim3(256), 0, st, d_edges, round);
+      }
+    }
+    hipLaunchKernelGGL(k_jb_order, dim3(1, B), dim3(1024), 0, st, d_edges);
+    hipLaunchKernelGGL(k_jb_rows, dim3(r, B), dim3(256), 0, st, d_edges);
+    return hipGetLastError();
+  }
   if (bd.Lg <= 512 && bd.r_cap <= PCH_R) {
     hipLaunchKernelGGL(k_pchol_reg, dim3(1, B), dim3(512), 0, st, d_edges);
   } else {
@@ -2216,7 +2289,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   }
   const int t = cdiv(bd.r_cap, 16);
   hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
-  if (bd.r_cap <= 96) {
+  {
     const int mm = (bd.r_cap + 1) & ~1;
     const size_t lds = (size_t)2 * mm * (mm | 1) * sizeof(double);
     static bool attr_set = false;
@@ -2224,12 +2297,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_set = true;
     }
-    const int jt = getenv("GPET_JACOBI_THREADS") ? atoi(getenv("GPET_JACOBI_THREADS")) : 1024;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(jt), lds, st, d_edges);
-  } else {
-    const int half = (bd.r_cap + 2) / 2;
-    hipLaunchKernelGGL(k_jacobi, dim3(1, B), dim3(1024), (size_t)(2 * half) * sizeof(double) + 2 * half * sizeof(int),
-                       st, d_edges);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges);
   }
   hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
@@ -2285,6 +2353,14 @@ __global__ void __launch_bounds__(256) k_pix_reset(EdgeDev* edges) {
     E.binbest[i] = 0ull;
     E.binarg[i] = 0x7FFFFFFFFFFFFFFFll;
   }
+}
+
+__global__ void k_set_force(EdgeDev* edges, int v) { edges[blockIdx.x].sc->force = v; }
+
+hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_set_force, dim3(B), dim3(1), 0, st, d_edges, v);
+  return hipGetLastError();
 }
 
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {

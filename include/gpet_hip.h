@@ -97,7 +97,7 @@ typedef struct gpet_scalars {
   double y_mean;       /* _y_train_mean                         sklearn_gpr.py:222 */
   double y_std;        /* _y_train_std                          sklearn_gpr.py:223 */
   double score_thresh; /* persists across iterations            gpet.py:595 */
-  double lml;          /* reserved */
+  double lml;          /* diagnostics (Jacobi sweeps of the last factorisation) */
   int32_t n;           /* training points of the last fit */
   int32_t n_obs;       /* current observation count */
   int32_t rank;        /* rows of the factor */
@@ -105,7 +105,7 @@ typedef struct gpet_scalars {
   int32_t iter;        /* iterations done                       gpet.py:865 */
   int32_t done;        /* n_obs >= algo_thresh                  gpet.py:829 */
   int32_t n_removed;   /* curve points outside the image        gpet.py:498-500 */
-  int32_t reserved;
+  int32_t force;       /* set by the per-stage entry points: run the stage even if `done` */
 } gpet_scalars;
 
 typedef struct gpet_ctx gpet_ctx;

@@ -1,0 +1,86 @@
+"""GPU parity at the other BASELINE.json configurations' shapes (they are parity cases, not
+bench lines): config 3 (2048x2048, ~1500 observations, N_samples=4000: large-n Cholesky / TRSM
+path) and config 5's frame shape (1024x1024, Matern-5/2, warm start)."""
+import numpy as np
+import pytest
+
+from oracle import gpet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gaussian_process_edge_trace_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def ctx(amd):
+    return amd._lib.Context(0)
+
+
+def test_config3_large_n_gp_iteration(amd, ctx):
+    """2048^2 image, 1498 user-supplied observations (+2 inits = 1500 training points), S=4000:
+    one GP iteration + scoring.  T1 parity of mean/std vs the oracle and of the costs of the
+    device's own samples vs the oracle's cost function."""
+    L = amd._lib
+    N = 2048
+    img, truth = orc.synth_sinusoid_image(N, 0)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    assert np.array_equal(grad, orc.comp_grad_img(img, orc.kernel_builder((11, 5))))
+    init = truth[[0, -1], :][:, [1, 0]]
+    rng = np.random.default_rng(0)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=1498, replace=False))
+    obs = np.stack([cols, truth[cols, 0] + rng.integers(-2, 3, size=cols.size)], axis=1).astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=4000,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, obs=obs, **kw, _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, obs)
+    b.fit_predict(want_cov=True)
+    p = orc.resolve_params(init, grad, obs=obs, **kw)
+    x, y, w = orc.assemble_training(p["init"], obs, True)
+    y_s = np.std(y) + 1.0
+    fit = orc.gp_fit(x, y / y_s, w, p["sigma_f"] ** 2 / y_s ** 2, p["length_scale"], "RBF", 2.5, 1, N)
+    pred = orc.gp_predict(fit, p["x_grid"].astype(float), want_cov=False)
+    assert b.scalars().n == 1500
+    np.testing.assert_allclose(b.read(L.BUF_ALPHA), fit["alpha"], rtol=1e-5, atol=1e-7 * np.abs(fit["alpha"]).max())
+    np.testing.assert_allclose(b.read(L.BUF_MEAN), pred["mean"], rtol=1e-7)
+    np.testing.assert_allclose(b.read(L.BUF_STD), pred["std"], rtol=1e-5, atol=1e-7)
+    b.factor()
+    A = b.read(L.BUF_FACTOR)
+    cov = b.read(L.BUF_COV)
+    np.testing.assert_allclose(A.T @ A, cov, rtol=0, atol=1e-9 * np.abs(cov).max())
+    b.normals([7])
+    b.sample()
+    b.score()
+    Y = b.read(L.BUF_SAMPLES)
+    assert Y.shape == (4000, N)
+    # sample statistics against the exact posterior
+    np.testing.assert_allclose(Y.mean(axis=0), pred["mean"] * y_s, atol=6 * (pred["std"] * y_s).max() / np.sqrt(4000) + 1e-6)
+    costs = b.read(L.BUF_COSTS)
+    oc = orc.costs_batch(orc.normalise(grad, (0, 1), np.float64), p["x_grid"], Y.T)
+    np.testing.assert_allclose(costs, oc, rtol=1e-9)
+    assert np.array_equal(b.read(L.BUF_BEST_IDX), np.argsort(oc, kind="stable")[:400])
+
+
+def test_config5_matern_frame_with_warm_start(amd, ctx):
+    """1024^2 frame, Matern-5/2 (sigma_f ~ 154, l ~ 41), warm start from every 16th pixel of a
+    previous trace (fewer than algo_thresh points): the whole device trace vs the oracle run with
+    the library's sign convention -- observation sets and edge trace bit-exact."""
+    N = 1024
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    warm = truth[16:-16:16][:, [1, 0]].astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41}, noise_y=1,
+              N_samples=300, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True)
+    rec = []
+    et_o, ci_o, info = orc.trace(init, grad, obs=warm, record=rec, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx)
+    et, (all_samples, all_obs, curves) = tr(return_lines=True)
+    assert tr._n_iter == info["n_iter"] >= 1
+    for i, r in enumerate(rec):
+        assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
+    assert np.array_equal(et, et_o)

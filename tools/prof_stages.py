@@ -15,7 +15,7 @@ def main():
     tr = pkg.GP_Edge_Tracing_Batch([init] * E, grad, list(range(1, E + 1)), **README_KW, _ctx=ctx)
     tr._batch.iterate(tr.seeds, 7)
     s = tr._batch.scalars(0)
-    print("mid-trace state: n=%d rank=%d jacobi sweeps=%d" % (s.n, s.rank, s.reserved), flush=True)
+    print("mid-trace state: n=%d rank=%d jacobi sweeps=%d" % (s.n, s.rank, int(s.lml)), flush=True)
     for i, name in enumerate(STAGES):
         ms = tr._batch.profile_stage(i, reps)
         print("%-16s %.3f ms" % (name, ms), flush=True)
