@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 README_KW = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, N_samples=1000,
                  score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
 STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "curve_kde"]
+# gpet_profile_stage ids of the single kernels of one iteration (include/gpet_hip.h)
+KERNEL_IDS = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram", 112: "k_jacobi_lds",
+              113: "k_factor_rows", 130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
+              151: "k_kde_fused", 152: "k_kde_normalise"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak (spec)
 
@@ -179,16 +183,18 @@ def main():
     # ---- quality of this rank's traces vs ground truth (sanity band, not the metric)
     mse = float(np.mean([pkg.gpet_utils.trace_MSE(tr, truth) for tr in traces]))
 
-    # ---- per-stage device time at a mid-trace state (batch of E edges, ~7 iterations in)
+    # ---- per-stage and per-kernel device time at a mid-trace state (batch of E edges, 7 iterations in),
+    #      measured live with hipEvents on the library's stream (gpet_profile_stage)
     tracer.reset()
     tracer._batch.iterate(seeds, 7)
-    n_mid = tracer._batch.scalars(0).n
-    rank_mid = tracer._batch.scalars(0).rank
+    sc_mid = tracer._batch.scalars(0)
+    n_mid, rank_mid, sweeps_mid = sc_mid.n, sc_mid.rank, max(1, int(sc_mid.lml))
     ring = 16  # the normals stage fills a ring of 16 upcoming iterations per launch: report per iteration
     def per_iter(d):
         d["normals"] = d["normals"] / ring
         return d
     stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
+    kernel_ms = {name: tracer._batch.profile_stage(kid, 20) for kid, name in KERNEL_IDS.items()}
     # single edge (BASELINE config 2): latency view
     one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **README_KW, _ctx=ctx)
     one(); one.reset()
@@ -196,31 +202,47 @@ def main():
     one.reset(); one._batch.iterate([1], 7)
     one_ms = per_iter({name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
 
-    # ---- roofline of the dominant kernel group: algorithmic bytes / flops per launch
-    S, Lg, nk = README_KW["N_samples"], N, int(README_KW["keep_ratio"] * README_KW["N_samples"])
+    # ---- roofline of the dominant kernel: algorithmic bytes / flops per edge per launch
+    S, Lg, M_ = README_KW["N_samples"], N, N
+    nk = int(README_KW["keep_ratio"] * README_KW["N_samples"])
+    r, n_ = rank_mid, n_mid
     alg = {
-        # fp64 flops per edge per launch
-        "sample_gemm": dict(flops=2.0 * S * Lg * rank_mid, bytes=8.0 * (S * rank_mid + rank_mid * Lg + S * Lg)),
-        "score_topk": dict(flops=40.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * N * N),
-        "fit_predict_cov": dict(flops=n_mid ** 3 / 3.0 + n_mid ** 2 * Lg + 2.0 * Lg * Lg * n_mid,
-                                bytes=8.0 * (Lg * Lg + n_mid * Lg + n_mid * n_mid)),
-        "factor": dict(flops=Lg * rank_mid ** 2 * 3.0, bytes=8.0 * (Lg * Lg + 2 * rank_mid * Lg)),
-        "normals": dict(flops=30.0 * S * Lg, bytes=8.0 * S * min(Lg, 128)),
-        "curve_kde": dict(flops=40.0 * (N + 2) * (N + 2), bytes=8.0 * 3 * (N + 2) * (N + 2) + 4.0 * N * N * 2),
+        "k_fit": dict(flops=n_ ** 3 / 3.0 + 2.0 * n_ * n_, bytes=8.0 * (n_ * n_ + 4 * n_)),
+        "k_predict": dict(flops=1.0 * n_ * n_ * Lg + 4.0 * n_ * Lg, bytes=8.0 * (n_ * Lg + n_ * n_ / 2 + 2 * Lg)),
+        "k_cov_mfma": dict(flops=1.0 * Lg * Lg * n_ + 30.0 * Lg * Lg / 2, bytes=8.0 * (Lg * Lg + n_ * Lg)),
+        "k_pchol_reg": dict(flops=2.0 * Lg * r * r / 2 * 2, bytes=8.0 * (2 * r * Lg)),
+        "k_gram": dict(flops=1.0 * r * r * Lg, bytes=8.0 * (r * Lg + r * r)),
+        "k_jacobi_lds": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
+        "k_factor_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
+        "k_sample_gemm_mfma_r": dict(flops=2.0 * S * Lg * r, bytes=8.0 * (S * r + r * Lg + S * Lg)),
+        "k_score": dict(flops=60.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * M_ * N),
+        "k_topk": dict(flops=2.0 * S * S, bytes=16.0 * S),
+        "k_kde_prep": dict(flops=2.0 * nk * Lg, bytes=8.0 * nk * Lg),
+        "k_kde_fused": dict(flops=36.0 * M_ * N + 10.0 * nk * Lg, bytes=8.0 * nk * Lg + 4.0 * M_ * N),
+        "k_kde_normalise": dict(flops=2.0 * M_ * N, bytes=8.0 * M_ * N),
     }
-    dom = max(stage_ms, key=stage_ms.get)
-    d_ms = stage_ms[dom]
+    dom = max(kernel_ms, key=kernel_ms.get)
+    d_ms = kernel_ms[dom]
     a_bytes = alg[dom]["bytes"] * E
     a_flops = alg[dom]["flops"] * E
     gbs = a_bytes / (d_ms * 1e-3) / 1e9
     tfl = a_flops / (d_ms * 1e-3) / 1e12
-    # bound: whichever roof the algorithmic intensity puts closer
-    use_flops = (tfl / FP64_PEAK_TFLOPS) > (gbs / HBM_PEAK_GBS)
+    ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)  # flop per byte
+    use_flops = (a_flops / a_bytes) > ridge
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp):
+        prof = json.load(open(tp))
+        if prof.get("edges") == E and prof.get("image") == [N, N] and dom in prof.get("kernels", {}):
+            traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
     roofline = dict(kernel=dom, bound="mfma" if use_flops else "hbm",
                     achieved=tfl if use_flops else gbs, peak=FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS,
                     unit="TFLOP/s" if use_flops else "GB/s",
-                    frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=None,
-                    launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops)
+                    frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
+                    launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
+                    state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid),
+                    all_kernels={k: dict(ms=v, GBps=alg[k]["bytes"] * E / (v * 1e-3) / 1e9,
+                                         TFLOPps=alg[k]["flops"] * E / (v * 1e-3) / 1e12) for k, v in kernel_ms.items()})
 
     log("stage profile done; dominant stage %s %.3f ms" % (dom, d_ms))
     cpu = None

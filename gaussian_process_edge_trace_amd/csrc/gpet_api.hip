@@ -735,6 +735,15 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0)); break;
+      case 6: HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd)); break;  // (reset only: selection mutates the loop state)
+      // single kernels: 100+ fit/predict/cov, 110+ pchol/gram/jacobi/rows, 130 gemm, 140+ score/topk, 150+ kde prep/fused/normalise
+      case 100: case 101: case 102:
+        HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1, 1u << (stage - 100))); break;
+      case 110: case 111: case 112: case 113:
+        HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 110))); break;
+      case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
+      case 150: case 151: case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150))); break;
       default: return fail(c, GPET_ERR_BAD_ARG, "gpet_profile_stage: unknown stage %d", stage);
     }
   }

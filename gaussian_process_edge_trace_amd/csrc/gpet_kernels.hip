@@ -1340,6 +1340,11 @@ __device__ __forceinline__ double grad_at(const float* __restrict__ grad, int M,
   return (double)grad[(size_t)iy * N + x] * w0 + (double)grad[(size_t)iy1 * N + x] * w1;
 }
 
+// Lane i of a 64-pair chunk owns curve points 2i and 2i+1 (one 16-byte load, fully coalesced);
+// the third point of its Simpson pair, that point's gradient value and the following segment
+// length are the next lane's own values and arrive by wave shuffle -- each sample, each gather and
+// each square root is done exactly once per curve.  (Lane 63 fetches its successor's data itself.)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
@@ -1349,20 +1354,52 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   if (s >= E.S) return;
   const int Lg = E.Lg;
   const double* __restrict__ row = E.Y + (size_t)s * Lg;
+  const bool aligned = ((((size_t)row) & 15) == 0);
   const int npair = (Lg - 2) / 2;  // Simpson over Lg-1 samples (odd count)
   double al = 0.0, li = 0.0;
-  for (int i = lane; i < npair; i += WAVE) {
+  for (int i0 = 0; i0 < npair; i0 += WAVE) {
+    const int i = i0 + lane;
     const int k = 2 * i;
-    const double y0 = row[k], y1 = row[k + 1], y2 = row[k + 2], y3 = row[k + 3];
-    const double d0 = y1 - y0, d1 = y2 - y1, d2 = y3 - y2;
-    const double l0 = sqrt(1.0 + d0 * d0), l1 = sqrt(1.0 + d1 * d1), l2 = sqrt(1.0 + d2 * d2);
-    al += (2.0 / 6.0) * (l0 + 4.0 * l1 + l2);
-    const double g0 = grad_at(E.grad, E.M, E.N, y0, E.x_st + k) + 1e-3;
-    const double g1 = grad_at(E.grad, E.M, E.N, y1, E.x_st + k + 1) + 1e-3;
-    const double g2 = grad_at(E.grad, E.M, E.N, y2, E.x_st + k + 2) + 1e-3;
-    const double h0 = l1, h1 = l2;
-    const double hsum = h0 + h1, hprod = h0 * h1, hdiv = h0 / h1;
-    li += hsum / 6.0 * (g0 * (2.0 - 1.0 / hdiv) + g1 * (hsum * (hsum / hprod)) + g2 * (2.0 - hdiv));
+    // own points: valid while k + 1 < Lg (the lane after the last pair still supplies its data)
+    double y0 = 0.0, y1 = 0.0;
+    if (k + 1 < Lg) {
+      if (aligned) {
+        const v2f64 v = *reinterpret_cast<const v2f64*>(row + k);
+        y0 = v[0];
+        y1 = v[1];
+      } else {
+        y0 = row[k];
+        y1 = row[k + 1];
+      }
+    }
+    // segment length l = sqrt(1 + d^2) and its reciprocal from ONE rsqrt each (the Simpson weights
+    // need h1/h0, h0/h1 and hsum^2/(h0 h1): products of the reciprocals instead of three divisions)
+    const double d0 = y1 - y0;
+    const double q0 = 1.0 + d0 * d0;
+    const double r0 = rsqrt(q0), l0 = q0 * r0;
+    const double g0 = (k + 1 < Lg) ? grad_at(E.grad, E.M, E.N, y0, E.x_st + k) + 1e-3 : 0.0;
+    const double g1 = (k + 1 < Lg) ? grad_at(E.grad, E.M, E.N, y1, E.x_st + k + 1) + 1e-3 : 0.0;
+    double y2 = __shfl_down(y0, 1, WAVE), l2 = __shfl_down(l0, 1, WAVE), r2 = __shfl_down(r0, 1, WAVE);
+    double g2 = __shfl_down(g0, 1, WAVE);
+    if (lane == 63 && i < npair) {  // successor lives in the next chunk
+      y2 = row[k + 2];
+      const double y3 = row[k + 3];
+      const double d2 = y3 - y2;
+      const double q2 = 1.0 + d2 * d2;
+      r2 = rsqrt(q2);
+      l2 = q2 * r2;
+      g2 = grad_at(E.grad, E.M, E.N, y2, E.x_st + k + 2) + 1e-3;
+    }
+    if (i < npair) {
+      const double d1 = y2 - y1;
+      const double q1 = 1.0 + d1 * d1;
+      const double r1 = rsqrt(q1), l1 = q1 * r1;
+      al += (2.0 / 6.0) * (l0 + 4.0 * l1 + l2);
+      const double h0 = l1, h1 = l2, ih0 = r1, ih1 = r2;
+      const double hsum = h0 + h1;
+      li += hsum * (1.0 / 6.0) *
+            (g0 * (2.0 - h1 * ih0) + g1 * (hsum * hsum * (ih0 * ih1)) + g2 * (2.0 - h0 * ih1));
+    }
   }
   al = wave_sum(al);
   li = wave_sum(li);
@@ -1594,222 +1631,185 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 }
 
 #define KDE_TX 16
+#define KDE_H 128    // image rows per LDS row-chunk
+#define KDE_NB 128   // curves staged per pass
 
-// One workgroup per (16-column tile, row chunk, edge): linear binning of the tile's curve points
-// straight into LDS (columns x0-4 .. x0+19, rows r0-4 .. r0+RY+4), separable 9-tap Gaussian
-// (vertical then horizontal) between two LDS tiles, f32 cast, min/max.  Rows/columns outside
-// the padded grid simply never receive weight, so no boundary tests are needed.
-// The 2 MB/edge global binning grid and its two global convolution passes are gone.
-__global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges, int rows_per_chunk) {
-  const EdgeDev E = edges[blockIdx.z];
-  const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  extern __shared__ double s_a[];
-  const int M = E.M, N = E.N;
-  const int x0 = blockIdx.x * KDE_TX;
-  const int r0 = blockIdx.y * rows_per_chunk;
-  if (x0 >= N || r0 >= M) return;
-  const int nrow = (M - r0) < rows_per_chunk ? (M - r0) : rows_per_chunk;  // image rows of this chunk
-  const int ld = (rows_per_chunk + 8) | 1;
-  const int NC = KDE_TX + 8;
-  double* s_t = s_a + NC * ld;        // [NC][ld] vertically filtered
-  double* s_y = s_t + NC * ld;        // [64][NC] staged curve points
-  double* s_wt = s_y + 64 * NC;       // [64] staged weights
-  // LDS row l of s_a <-> padded-grid row gy = r0 - 3 + l  (gy = y + 1; halo 4)
-  const int tid = threadIdx.x;
-  const bool band = (x0 + KDE_TX + 4 > E.x_st) && (x0 - 4 <= E.x_en);
-  float* __restrict__ out = E.kde;
-  unsigned int kmin = 0xFFFFFFFFu, kmax = 0u;
-  if (!band) {
-    for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
-      const int xl = idx % KDE_TX, y = r0 + idx / KDE_TX;
-      if (x0 + xl < N) out[(size_t)y * N + x0 + xl] = 0.f;
-    }
-    kmin = kmax = f32_order_key(0.f);
-  } else {
-    for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
-    const double W = E.colsum[0], inv_sum = E.colsum[1], ymax = (double)(M - 1);
-    const int lmax = nrow + 8;
-    for (int b0 = 0; b0 < E.n_keep; b0 += 64) {
-      const int nb = (E.n_keep - b0) < 64 ? (E.n_keep - b0) : 64;
-      __syncthreads();
-      for (int e = tid; e < nb * NC; e += 256) {
-        const int bb = e / NC, c = e - bb * NC;
-        const int xc = x0 + c - 4;
-        double y = -1.0;  // marks "no point"
-        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)E.best_idx[b0 + bb] * E.Lg + (xc - E.x_st)];
-        s_y[e] = y;
-      }
-      for (int e = tid; e < nb; e += 256) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
-      __syncthreads();
-      if (tid < NC) {
-        double* col = s_a + tid * ld;
-        for (int bb = 0; bb < nb; ++bb) {
-          const double y = s_y[bb * NC + tid];
-          if (y < 0.0 || y > ymax) continue;  // gpet.py:498-500 (and columns outside the edge)
-          const double gy = y + 1.0;
-          const int iy = (int)floor(gy);
-          const int l = iy - (r0 - 3);
-          if (l + 1 < 0 || l >= lmax) continue;
-          const double w = s_wt[bb];
-          const double fy = gy - (double)iy;
-          if (l >= 0) col[l] += (1.0 - fy) * w;
-          if (l + 1 < lmax) col[l + 1] += fy * w;
-        }
-      }
-    }
-    __syncthreads();
-    double g[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
-    // vertical pass: t[c][yl] = sum_dy a[c][yl + 4 + dy] g[dy]
-    for (int idx = tid; idx < NC * nrow; idx += 256) {
-      const int c = idx / nrow, yl = idx - c * nrow;
-      const double* col = s_a + c * ld + yl;
-      double acc = 0.0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc += col[t] * g[t];
-      s_t[c * ld + yl] = acc;
-    }
-    __syncthreads();
-    // horizontal pass + crop + f32
-    for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
-      const int xl = idx % KDE_TX, yl = idx / KDE_TX;
-      const int x = x0 + xl, y = r0 + yl;
-      if (x >= N) continue;
-      double acc = 0.0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc += s_t[(xl + t) * ld + yl] * g[t];
-      acc *= 0.15915494309189535;  // 1 / (2 pi): 2-D Gaussian pdf normalisation
-      const float v = (float)acc;
-      out[(size_t)y * N + x] = v;
-      const unsigned int key = f32_order_key(v);
-      kmin = min(kmin, key);
-      kmax = max(kmax, key);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    kmin = min(kmin, (unsigned int)__shfl_xor((int)kmin, o, WAVE));
-    kmax = max(kmax, (unsigned int)__shfl_xor((int)kmax, o, WAVE));
-  }
-  if ((tid & 63) == 0) {
-    atomicMin(&E.mm[0], kmin);
-    atomicMax(&E.mm[1], kmax);
-  }
-}
-
-// Full-height variant (M <= 700): one workgroup per (16-column tile, edge), a single
-// (KDE_TX+8) x (M+8) f64 LDS tile.  Binning runs on 24 columns x 8 row-slots (thread owns the rows
-// l with l % 8 == slot, scans the curves in order -> per-bin summation order is the sequential
-// one, with 8x the parallelism); the vertical 9-tap pass is done in place with a register sliding
-// window (each thread first saves the 8 halo values that neighbouring segments overwrite).
-__global__ void __launch_bounds__(256) k_kde_fused_full(EdgeDev* edges) {
+// One workgroup per (16-column tile, edge).  The tile's curve points are staged in LDS once; the
+// rows that can receive weight are the band [ymin-4, ymax+5] of those points, and only that band is
+// processed, in chunks of KDE_H rows through ONE (KDE_TX+8) x (KDE_H+8) f64 LDS tile (39 KB per
+// workgroup with the staging -> 4 workgroups per CU):
+//   linear binning   24 columns x 8 row-slots; a thread owns the rows l with l % 8 == slot and scans
+//                    the curves in order, so every bin is summed in the sequential (KDEpy) order;
+//   vertical 9 taps  in place, register sliding window (halo rows saved before the barrier);
+//   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
+// Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
+// columns outside the padded grid never receive weight.
+__global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ double s_a[];
+  __shared__ int s_band[2];
   const int M = E.M, N = E.N;
   const int x0 = blockIdx.x * KDE_TX;
   if (x0 >= N) return;
   const int NC = KDE_TX + 8;
-  const int ld = (M + 8) | 1;
-  double* s_y = s_a + NC * ld;   // [64][NC]
-  double* s_wt = s_y + 64 * NC;  // [64]
+  const int ld = (KDE_H + 8) | 1;
+  double* s_y = s_a + NC * ld;        // [KDE_NB][NC] staged points (-1: none)
+  double* s_wt = s_y + KDE_NB * NC;   // [KDE_NB] staged weights
   const int tid = threadIdx.x;
   const bool band = (x0 + KDE_TX + 4 > E.x_st) && (x0 - 4 <= E.x_en);
   float* __restrict__ out = E.kde;
   unsigned int kmin = 0xFFFFFFFFu, kmax = 0u;
-  if (!band) {
-    for (int idx = tid; idx < KDE_TX * M; idx += 256) {
-      const int xl = idx % KDE_TX, y = idx / KDE_TX;
-      if (x0 + xl < N) out[(size_t)y * N + x0 + xl] = 0.f;
-    }
-    kmin = kmax = f32_order_key(0.f);
-  } else {
-    for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
+  int y_lo = M, y_hi = -1;  // band of image rows with possibly non-zero density
+  if (band) {
     const double W = E.colsum[0], inv_sum = E.colsum[1], ymax = (double)(M - 1);
-    const int bc = tid % NC, slot = tid / NC;  // binning role (tid < 8 * NC)
-    for (int b0 = 0; b0 < E.n_keep; b0 += 64) {
-      const int nb = (E.n_keep - b0) < 64 ? (E.n_keep - b0) : 64;
-      __syncthreads();
+    double g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
+    const bool single = (E.n_keep <= KDE_NB);  // all kept curves fit one staging pass (the usual case)
+    // stage curves [b0, b0+nb) of this tile's columns; returns the rows they touch through (lo, hi)
+    auto stage = [&](int b0, int nb, int& lo, int& hi) {
       for (int e = tid; e < nb * NC; e += 256) {
         const int bb = e / NC, c = e - bb * NC;
         const int xc = x0 + c - 4;
         double y = -1.0;
         if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)E.best_idx[b0 + bb] * E.Lg + (xc - E.x_st)];
+        if (y < 0.0 || y > ymax) y = -1.0;  // gpet.py:498-500
         s_y[e] = y;
+        if (y >= 0.0) {
+          const int iy = (int)floor(y);
+          lo = min(lo, iy);
+          hi = max(hi, iy + 1);
+        }
       }
       for (int e = tid; e < nb; e += 256) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
-      __syncthreads();
-      if (slot < 8) {
-        double* col = s_a + bc * ld;
-        for (int bb = 0; bb < nb; ++bb) {
-          const double y = s_y[bb * NC + bc];
-          if (y < 0.0 || y > ymax) continue;  // gpet.py:498-500 (and columns outside the edge)
-          const double gy = y + 1.0;
-          const int iy = (int)floor(gy);
-          const int l = iy + 3;  // LDS row of padded-grid row gy (halo 4, gy = -1 -> l = 2 ... )
-          const bool lo = ((l & 7) == slot), hi = (((l + 1) & 7) == slot);
-          if (!(lo || hi)) continue;
-          const double w = s_wt[bb];
-          const double fy = gy - (double)iy;
-          if (lo) col[l] += (1.0 - fy) * w;
-          if (hi) col[l + 1] += fy * w;
-        }
-      }
+    };
+    // phase A: band of rows that receive weight
+    if (tid == 0) {
+      s_band[0] = 0x7FFFFFFF;
+      s_band[1] = -1;
     }
     __syncthreads();
-    double g[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
-    // vertical pass, in place: filtered value of image row y is written to LDS row y + 4
     {
-      int nseg = 256 / NC;                       // segments per column, each >= 16 rows
-      if (nseg > M / 16) nseg = (M / 16 > 0) ? M / 16 : 1;
-      const int seg = tid / NC, c = tid % NC;    // (tid < nseg * NC)
-      const int R = (M + nseg - 1) / nseg;
-      const int y0 = seg * R, y1 = (y0 + R < M) ? (y0 + R) : M;
-      double* col = s_a + c * ld;
-      double head[4], tail[4];
-      const bool active = (seg < nseg) && (y0 < M);
-      if (active) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          head[t] = col[y0 + t];       // rows the previous segment overwrites (its last outputs)
-          tail[t] = col[y1 + 4 + t];   // rows the next segment overwrites (its first outputs)
-        }
+      int mylo = 0x7FFFFFFF, myhi = -1;
+      for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
+        const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
+        if (b0 > 0) __syncthreads();
+        stage(b0, nb, mylo, myhi);
       }
-      __syncthreads();
-      if (active) {
-        double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
-        double w4 = col[y0 + 4], w5 = col[y0 + 5], w6 = col[y0 + 6], w7 = col[y0 + 7];
-        for (int y = y0; y < y1; ++y) {
-          const int lnew = y + 8;
-          const double w8 = (lnew >= y1 + 4) ? tail[lnew - (y1 + 4)] : col[lnew];
-          const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
-                             w7 * g[7] + w8 * g[8];
-          col[y + 4] = acc;
-          w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
-        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mylo = min(mylo, __shfl_xor(mylo, o, WAVE));
+        myhi = max(myhi, __shfl_xor(myhi, o, WAVE));
+      }
+      if ((tid & 63) == 0) {
+        atomicMin(&s_band[0], mylo);
+        atomicMax(&s_band[1], myhi);
       }
     }
     __syncthreads();
-    // horizontal pass + crop + f32
-    for (int idx = tid; idx < KDE_TX * M; idx += 256) {
-      const int xl = idx % KDE_TX, y = idx / KDE_TX;
-      const int x = x0 + xl;
-      if (x >= N) continue;
-      double acc = 0.0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc += s_a[(xl + t) * ld + y + 4] * g[t];
-      acc *= 0.15915494309189535;  // 1 / (2 pi)
-      const float v = (float)acc;
-      out[(size_t)y * N + x] = v;
-      const unsigned int key = f32_order_key(v);
-      kmin = min(kmin, key);
-      kmax = max(kmax, key);
+    if (s_band[1] >= 0) {
+      y_lo = max(0, s_band[0] - 4);
+      y_hi = min(M - 1, s_band[1] + 4);
     }
+    // phase B: the band, KDE_H image rows at a time
+    for (int r0 = y_lo; r0 <= y_hi; r0 += KDE_H) {
+      const int nrow = (y_hi + 1 - r0) < KDE_H ? (y_hi + 1 - r0) : KDE_H;
+      // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
+      for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
+      __syncthreads();
+      for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
+        const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
+        if (!single) {
+          int dl = 0, dh = 0;
+          __syncthreads();
+          stage(b0, nb, dl, dh);
+          __syncthreads();
+        }
+        const int bc = tid % NC, slot = tid / NC;
+        if (slot < 8) {
+          double* col = s_a + bc * ld;
+          const int lmax = nrow + 8;
+          for (int bb = 0; bb < nb; ++bb) {
+            const double y = s_y[bb * NC + bc];
+            if (y < 0.0) continue;
+            const double gy = y + 1.0;
+            const int iy = (int)floor(gy);
+            const int l = iy - (r0 - 3);
+            if (l + 1 < 0 || l >= lmax) continue;
+            const bool lo = (l >= 0) && ((l & 7) == slot), hi = (l + 1 < lmax) && (((l + 1) & 7) == slot);
+            if (!(lo || hi)) continue;
+            const double w = s_wt[bb];
+            const double fy = gy - (double)iy;
+            if (lo) col[l] += (1.0 - fy) * w;
+            if (hi) col[l + 1] += fy * w;
+          }
+        }
+      }
+      __syncthreads();
+      {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
+        int nseg = 256 / NC;
+        if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
+        const int seg = tid / NC, c = tid % NC;
+        const int R = (nrow + nseg - 1) / nseg;
+        const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
+        double* col = s_a + c * ld;
+        double head[4], tail[4];
+        const bool active = (seg < nseg) && (q0 < nrow);
+        if (active) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            head[t] = col[q0 + t];
+            tail[t] = col[q1 + 4 + t];
+          }
+        }
+        __syncthreads();
+        if (active) {
+          double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
+          double w4 = col[q0 + 4], w5 = col[q0 + 5], w6 = col[q0 + 6], w7 = col[q0 + 7];
+          for (int q = q0; q < q1; ++q) {
+            const int lnew = q + 8;
+            const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
+            const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
+                               w7 * g[7] + w8 * g[8];
+            col[q + 4] = acc;
+            w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
+        const int xl = idx % KDE_TX, yl = idx / KDE_TX;
+        const int x = x0 + xl;
+        if (x >= N) continue;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += s_a[(xl + t) * ld + yl + 4] * g[t];
+        acc *= 0.15915494309189535;  // 1 / (2 pi): 2-D Gaussian pdf normalisation
+        const float v = (float)acc;
+        out[(size_t)(r0 + yl) * N + x] = v;
+        const unsigned int key = f32_order_key(v);
+        kmin = min(kmin, key);
+        kmax = max(kmax, key);
+      }
+      __syncthreads();
+    }
+  }
+  // rows outside the band (all rows for tiles away from the edge): zeros
+  bool wrote_zero = false;
+  for (int idx = tid; idx < KDE_TX * M; idx += 256) {
+    const int xl = idx % KDE_TX, y = idx / KDE_TX;
+    if (y >= y_lo && y <= y_hi) continue;
+    if (x0 + xl < N) {
+      out[(size_t)y * N + x0 + xl] = 0.f;
+      wrote_zero = true;
+    }
+  }
+  if (wrote_zero) {
+    const unsigned int kz = f32_order_key(0.f);
+    kmin = min(kmin, kz);
+    kmax = max(kmax, kz);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -2222,20 +2222,22 @@ static void fit_predict_attrs() {
   attr_set = true;
 }
 
-hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov) {
+hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   fit_predict_attrs();
-  if (bd.n_cap <= 128)
+  if (!(parts & 1u)) {
+  } else if (bd.n_cap <= 128)
     hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else
     hipLaunchKernelGGL((k_fit<false, false>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
   const size_t plds = ((size_t)bd.n_cap * 64 + 3 * (size_t)bd.n_cap) * sizeof(double);
-  if (plds <= 150 * 1024)
+  if (!(parts & 2u)) {
+  } else if (plds <= 150 * 1024)
     hipLaunchKernelGGL((k_predict<true, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, 0);
   else
     hipLaunchKernelGGL((k_predict<false, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, 0);
-  if (want_cov) {
+  if (want_cov && (parts & 4u)) {
     const int t = cdiv(bd.Lg, 64);
     hipLaunchKernelGGL(k_cov_mfma, dim3(t, t, B), dim3(256), 0, st, d_edges);
   }
@@ -2259,7 +2261,7 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
   return hipGetLastError();
 }
 
-hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   if (bd.r_cap > 96) {
     // large ranks: whole-GPU Jacobi on the covariance itself.  A fixed budget of sweeps is
@@ -2281,15 +2283,16 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     hipLaunchKernelGGL(k_jb_rows, dim3(r, B), dim3(256), 0, st, d_edges);
     return hipGetLastError();
   }
-  if (bd.Lg <= 512 && bd.r_cap <= PCH_R) {
+  if (!(parts & 1u)) {
+  } else if (bd.Lg <= 512 && bd.r_cap <= PCH_R) {
     hipLaunchKernelGGL(k_pchol_reg, dim3(1, B), dim3(512), 0, st, d_edges);
   } else {
     int pth = bd.Lg >= 1024 ? 1024 : (bd.Lg > 512 ? 1024 : (bd.Lg > 256 ? 512 : 256));
     hipLaunchKernelGGL(k_pchol, dim3(1, B), dim3(pth), (size_t)(bd.Lg + bd.r_cap) * sizeof(double), st, d_edges);
   }
   const int t = cdiv(bd.r_cap, 16);
-  hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
-  {
+  if (parts & 2u) hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
+  if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;
     const size_t lds = (size_t)2 * mm * (mm | 1) * sizeof(double);
     static bool attr_set = false;
@@ -2299,7 +2302,8 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     }
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges);
   }
-  hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
+  if (parts & 8u)
+    hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
 }
 
@@ -2311,32 +2315,14 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
 }
 
 // mode 0: KDE of the best curves -> E.kde ; mode 1: KDE of the gradient image -> E.grad_kde
-hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode) {
+hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   if (mode == 0) {
     // per-iteration path: one prep kernel + one fused bin/convolve kernel + normalise
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_kde_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
-    }
-    // row chunks of <= 128 rows, balanced: two (KDE_TX+8) x (rows+8) f64 LDS tiles per workgroup
-    const int nchunk = cdiv(bd.M, 128);
-    const int rows = cdiv(bd.M, nchunk);
-    const size_t lds = ((size_t)2 * (KDE_TX + 8) * ((rows + 8) | 1) + 64 * (KDE_TX + 8) + 64) * sizeof(double);
-    hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
-    if (bd.M <= 700) {
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)k_kde_fused_full, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr2 = true;
-      }
-      const size_t lds_full = ((size_t)(KDE_TX + 8) * ((bd.M + 8) | 1) + 64 * (KDE_TX + 8) + 64) * sizeof(double);
-      hipLaunchKernelGGL(k_kde_fused_full, dim3(cdiv(bd.N, KDE_TX), B), dim3(256), lds_full, st, d_edges);
-    } else {
-      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), cdiv(bd.M, rows), B), dim3(256), lds, st, d_edges, rows);
-    }
-    hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
+    const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
+    if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
+    if (parts & 2u) hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(256), lds, st, d_edges);
+    if (parts & 4u) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_kde_clear, dim3(64, B), dim3(256), 0, st, d_edges, mode);
@@ -2393,10 +2379,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   return hipGetLastError();
 }
 
-hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
-  hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  if (parts & 1u) hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+  if (parts & 2u) hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
   return hipGetLastError();
 }
 

@@ -210,7 +210,9 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Enqueue one stage `reps` times between two hipEvents on the context's stream and return the
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
- * GEMM, 4 scoring+top-k, 5 curve KDE.  (bench.py's roofline leg; leaves the state as-is.) */
+ * GEMM, 4 scoring+top-k, 5 curve KDE; single kernels: 100 fit, 101 predict, 102 covariance, 110 pivoted
+ * Cholesky, 111 Gram, 112 Jacobi, 113 factor rows, 130 sample GEMM, 140 scoring, 141 top-k, 150 KDE prep,
+ * 151 fused KDE, 152 KDE normalise.  (bench.py's roofline leg; leaves the loop state as-is.) */
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep);
 
 #ifdef __cplusplus
