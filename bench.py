@@ -105,16 +105,26 @@ def main():
     pool = make_fit_pool(args.fit_workers) if args.fit_workers > 1 else None
     # L-BFGS-B state machines of the final fits advance in worker processes (the objective runs on
     # the GPU); also created before HIP is initialised
-    farm = LockstepFarm(args.lbfgs_workers) if (args.lbfgs_workers > 1 and pool is None) else None
+    n_lbfgs = max(2, min(args.lbfgs_workers, ((os.cpu_count() or 2) - 2) // max(1, world))) if args.lbfgs_workers > 1 else 0
+    farm = LockstepFarm(n_lbfgs) if (n_lbfgs > 1 and pool is None) else None
     import torch
     dist = None
+    # GPET_BENCH_BACKEND=gloo + GPET_BENCH_SHARE_GPU=1: rehearsal of the N>1 path on a one-GPU box
+    # (ranks share device 0, collectives on CPU tensors); the real run uses nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("GPET_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("GPET_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     import gaussian_process_edge_trace_amd as pkg
     L = pkg._lib
-    ctx = L.Context(local_rank)
+    ctx = L.Context(dev_index)
 
     # ---- inputs: one shared gradient image, produced on rank 0's GPU, broadcast over RCCL/xGMI
     N = args.size
@@ -122,7 +132,7 @@ def main():
     init = truth[[0, -1], :][:, [1, 0]]
     t_b = 0.0
     if world > 1:
-        g = torch.empty((N, N), dtype=torch.float32, device="cuda")
+        g = torch.empty((N, N), dtype=torch.float32, device=coll_dev)
         if rank == 0:
             g.copy_(torch.from_numpy(pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)))
         torch.cuda.synchronize()
@@ -164,7 +174,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_traces = E * world * args.steps

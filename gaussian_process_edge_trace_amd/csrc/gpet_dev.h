@@ -39,6 +39,7 @@ struct EdgeDev {
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
   double* Y;             // [S*Lg]
   double* costs;         // [S]
+  double* cost_part;     // [n_tiles][S][2] per-column-tile partial (arc length, line integral) sums
   double* best_costs;    // [n_keep]
   int* best_idx;         // [n_keep]
   // pixel-selection workspaces (f1)

@@ -1406,6 +1406,113 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   if (lane == 0) E.costs[s] = al / li;
 }
 
+// a7, tiled variant (M <= 1100): a workgroup owns 16 Simpson pairs (33 image columns) of up to 512
+// curves.  The 33 x M slab of the gradient image is staged in LDS (column-major, odd stride), so the
+// 4-tap bilinear gathers -- the L1/TA-bound part of the wave-per-curve kernel -- become LDS reads.
+// 16 consecutive lanes share a curve: one coalesced 256-byte read of its samples, successor data
+// by shuffle inside the group, group reduction by shuffle, and one (arc, integral) partial per
+// (tile, curve); k_score_combine adds the partials in tile order (deterministic) and divides.
+#define SC_PAIRS 16
+#define SC_CURVES 512
+#define SC_THREADS 1024
+__device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
+  y = y < 0.0 ? 0.0 : (y > (double)(M - 1) ? (double)(M - 1) : y);
+  int iy = (int)floor(y);
+  if (iy > M - 2) iy = M - 2;
+  if (iy < 0) iy = 0;
+  const double w1 = y - (double)iy, w0 = ((double)iy + 1.0) - y;
+  const int iy1 = (iy + 1 < M) ? iy + 1 : M - 1;
+  return (double)col[iy] * w0 + (double)col[iy1] * w1;
+}
+
+__global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  extern __shared__ float s_img[];  // [2*SC_PAIRS + 1][ldm]
+  const int M = E.M, N = E.N, Lg = E.Lg, S = E.S;
+  const int npair = (Lg - 2) / 2;
+  const int p0 = blockIdx.x * SC_PAIRS;
+  if (p0 >= npair) return;
+  const int c0 = E.x_st + 2 * p0;   // first image column of the slab
+  const int ncol = 2 * SC_PAIRS + 1;
+  const int ldm = M | 1;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < ncol * M; e += SC_THREADS) {
+    const int y = e / ncol, c = e - y * ncol;
+    const int x = c0 + c;
+    s_img[c * ldm + y] = (x < N) ? E.grad[(size_t)y * N + x] : 0.f;
+  }
+  __syncthreads();
+  const int pl = tid & 15;  // pair within the tile
+  const int i = p0 + pl;
+  const int k = 2 * i;
+  const int s_lo = blockIdx.y * SC_CURVES;
+  const int s_hi = (s_lo + SC_CURVES < S) ? (s_lo + SC_CURVES) : S;
+  double* __restrict__ part = E.cost_part + ((size_t)blockIdx.x * S) * 2;
+  for (int s0 = s_lo; s0 < s_hi; s0 += SC_THREADS / 16) {
+    const int s = s0 + (tid >> 4);
+    const bool live = s < s_hi;
+    const double* __restrict__ row = E.Y + (size_t)(live ? s : s_lo) * Lg;
+    double y0 = 0.0, y1 = 0.0;
+    if (k + 1 < Lg) {
+      y0 = row[k];
+      y1 = row[k + 1];
+    }
+    const double d0 = y1 - y0;
+    const double q0 = 1.0 + d0 * d0;
+    const double r0 = rsqrt(q0), l0 = q0 * r0;
+    const double g0 = grad_lds(s_img + (2 * pl) * ldm, M, y0) + 1e-3;
+    const double g1 = grad_lds(s_img + (2 * pl + 1) * ldm, M, y1) + 1e-3;
+    double y2 = __shfl_down(y0, 1, 16), l2 = __shfl_down(l0, 1, 16), r2 = __shfl_down(r0, 1, 16);
+    double g2 = __shfl_down(g0, 1, 16);
+    double al = 0.0, li = 0.0;
+    if (i < npair) {
+      if (pl == 15) {  // successor pair belongs to the next tile
+        y2 = row[k + 2];
+        const double y3 = row[k + 3];
+        const double d2 = y3 - y2;
+        const double q2 = 1.0 + d2 * d2;
+        r2 = rsqrt(q2);
+        l2 = q2 * r2;
+        g2 = grad_lds(s_img + (2 * pl + 2) * ldm, M, y2) + 1e-3;
+      }
+      const double d1 = y2 - y1;
+      const double q1 = 1.0 + d1 * d1;
+      const double r1 = rsqrt(q1), l1 = q1 * r1;
+      al = (2.0 / 6.0) * (l0 + 4.0 * l1 + l2);
+      const double h0 = l1, h1 = l2, ih0 = r1, ih1 = r2;
+      const double hsum = h0 + h1;
+      li = hsum * (1.0 / 6.0) * (g0 * (2.0 - h1 * ih0) + g1 * (hsum * hsum * (ih0 * ih1)) + g2 * (2.0 - h0 * ih1));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      al += __shfl_xor(al, o, 16);
+      li += __shfl_xor(li, o, 16);
+    }
+    if (pl == 0 && live) {
+      part[2 * s] = al;
+      part[2 * s + 1] = li;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_score_combine(EdgeDev* edges, int n_tiles) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= E.S) return;
+  (void)n_tiles;
+  const int my_tiles = ((E.Lg - 2) / 2 + SC_PAIRS - 1) / SC_PAIRS;  // this edge's own tile count
+  double al = 0.0, li = 0.0;
+  for (int t = 0; t < my_tiles; ++t) {
+    al += E.cost_part[((size_t)t * E.S + s) * 2];
+    li += E.cost_part[((size_t)t * E.S + s) * 2 + 1];
+  }
+  E.costs[s] = al / li;
+}
+
 // argsort(costs)[:n_keep] by rank counting (ties -> lower index first)       gpet.py:443
 __global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
@@ -1633,6 +1740,7 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 #define KDE_TX 16
 #define KDE_H 128    // image rows per LDS row-chunk
 #define KDE_NB 128   // curves staged per pass
+#define KDE_THREADS 512
 
 // One workgroup per (16-column tile, edge).  The tile's curve points are staged in LDS once; the
 // rows that can receive weight are the band [ymin-4, ymax+5] of those points, and only that band is
@@ -1644,7 +1752,7 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 //   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
 // columns outside the padded grid never receive weight.
-__global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -1670,7 +1778,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
     const bool single = (E.n_keep <= KDE_NB);  // all kept curves fit one staging pass (the usual case)
     // stage curves [b0, b0+nb) of this tile's columns; returns the rows they touch through (lo, hi)
     auto stage = [&](int b0, int nb, int& lo, int& hi) {
-      for (int e = tid; e < nb * NC; e += 256) {
+      for (int e = tid; e < nb * NC; e += KDE_THREADS) {
         const int bb = e / NC, c = e - bb * NC;
         const int xc = x0 + c - 4;
         double y = -1.0;
@@ -1683,7 +1791,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
           hi = max(hi, iy + 1);
         }
       }
-      for (int e = tid; e < nb; e += 256) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
+      for (int e = tid; e < nb; e += KDE_THREADS) s_wt[e] = ((1.0 / E.best_costs[b0 + e]) / inv_sum) / W;
     };
     // phase A: band of rows that receive weight
     if (tid == 0) {
@@ -1717,7 +1825,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
     for (int r0 = y_lo; r0 <= y_hi; r0 += KDE_H) {
       const int nrow = (y_hi + 1 - r0) < KDE_H ? (y_hi + 1 - r0) : KDE_H;
       // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
-      for (int i = tid; i < NC * ld; i += 256) s_a[i] = 0.0;
+      for (int i = tid; i < NC * ld; i += KDE_THREADS) s_a[i] = 0.0;
       __syncthreads();
       for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
         const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
@@ -1749,7 +1857,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
       }
       __syncthreads();
       {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
-        int nseg = 256 / NC;
+        int nseg = KDE_THREADS / NC;
         if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
         const int seg = tid / NC, c = tid % NC;
         const int R = (nrow + nseg - 1) / nseg;
@@ -1779,7 +1887,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
         }
       }
       __syncthreads();
-      for (int idx = tid; idx < KDE_TX * nrow; idx += 256) {
+      for (int idx = tid; idx < KDE_TX * nrow; idx += KDE_THREADS) {
         const int xl = idx % KDE_TX, yl = idx / KDE_TX;
         const int x = x0 + xl;
         if (x >= N) continue;
@@ -1798,7 +1906,7 @@ __global__ void __launch_bounds__(256) k_kde_fused(EdgeDev* edges) {
   }
   // rows outside the band (all rows for tiles away from the edge): zeros
   bool wrote_zero = false;
-  for (int idx = tid; idx < KDE_TX * M; idx += 256) {
+  for (int idx = tid; idx < KDE_TX * M; idx += KDE_THREADS) {
     const int xl = idx % KDE_TX, y = idx / KDE_TX;
     if (y >= y_lo && y <= y_hi) continue;
     if (x0 + xl < N) {
@@ -2029,7 +2137,7 @@ __device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, doub
 // parallel loops -- depth ~ n^3/(3*256) instead of the n^2/2 serial dot products of a
 // left-looking factorisation, with two barriers per step shared by both recurrences.
 #define PK(i, j) ((i) * ((i) + 1) / 2 + (j))
-__global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+__global__ void __launch_bounds__(512) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                              double* g_out) {
   const int pb = blockIdx.x;
   const EdgeDev E = edges[edge_of[pb]];
@@ -2044,7 +2152,7 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
   double* sy = sa + n;           // y
   double* sal = sy + n;          // scaled pivot column, later z
   const int tid = threadIdx.x, bs = blockDim.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int tx = tid & 15, ty = tid >> 4, TY = bs >> 4;  // thread tile: TY rows x 16 columns
   const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
   for (int i = tid; i < n; i += bs) {
     sa[i] = E.fin_x[i] / ell;
@@ -2053,8 +2161,8 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
   if (tid == 0) s_bad = 0;
   __syncthreads();
   // K (lower, packed) and X = I, 16x16 thread tiles over (i, j), j <= i
-  for (int i0 = 0; i0 < n; i0 += 16)
-    for (int j0 = 0; j0 <= i0; j0 += 16) {
+  for (int i0 = 0; i0 < n; i0 += TY)
+    for (int j0 = 0; j0 < i0 + TY; j0 += 16) {
       const int i = i0 + ty, j = j0 + tx;
       if (i < n && j <= i) {
         double v;
@@ -2091,8 +2199,8 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
     const int m = n - k - 1;
     if (m > 0) {
       //   L: a_ij -= l_ik l_jk for k < j <= i          (lower tiles of the m x m trailing block)
-      for (int a0 = 0; a0 < m; a0 += 16)
-        for (int b0 = 0; b0 <= a0; b0 += 16) {
+      for (int a0 = 0; a0 < m; a0 += TY)
+        for (int b0 = 0; b0 < a0 + TY; b0 += 16) {
           const int ii = a0 + ty, jj = b0 + tx;
           if (ii < m && jj <= ii) {
             const int i = k + 1 + ii, j = k + 1 + jj;
@@ -2137,8 +2245,8 @@ __global__ void __launch_bounds__(256) k_lml(EdgeDev* edges, const int* edge_of,
   yta = block_sum(yta, s_red);
   // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij over 16x16 tiles of the lower triangle
   double gc = 0.0, gl = 0.0, gn = 0.0;
-  for (int i0 = 0; i0 < n; i0 += 16)
-    for (int j0 = 0; j0 <= i0; j0 += 16) {
+  for (int i0 = 0; i0 < n; i0 += TY)
+    for (int j0 = 0; j0 < i0 + TY; j0 += 16) {
       const int i = i0 + ty, j = j0 + tx;
       if (i < n && j <= i) {
         double kinv = 0.0;
@@ -2179,7 +2287,7 @@ hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const 
     (void)hipFuncSetAttribute((const void*)k_lml, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_lml, dim3(P), dim3(256), lds, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+  hipLaunchKernelGGL(k_lml, dim3(P), dim3(512), lds, st, d_edges, d_edge_of, d_theta, d_f, d_g);
   return hipGetLastError();
 }
 
@@ -2321,7 +2429,7 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
     // per-iteration path: one prep kernel + one fused bin/convolve kernel + normalise
     const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
     if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
-    if (parts & 2u) hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(256), lds, st, d_edges);
+    if (parts & 2u) hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges);
     if (parts & 4u) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
@@ -2381,7 +2489,21 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  if (parts & 1u) hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+  if (parts & 1u) {
+    const size_t lds = (size_t)(2 * SC_PAIRS + 1) * (bd.M | 1) * sizeof(float);
+    if (lds <= 150 * 1024 && B * 1 > 0 && bd.S >= 64) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_score_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+      }
+      const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
+      hipLaunchKernelGGL(k_score_tile, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
+      hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
+    } else {
+      hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+    }
+  }
   if (parts & 2u) hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
   return hipGetLastError();
 }
