@@ -683,9 +683,6 @@ int gpet_score_curves(gpet_batch* b) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_samples) return fail(c, GPET_ERR_STATE, "gpet_score_curves before samples exist");
-  for (int e = 0; e < b->B; ++e)
-    if (b->h_edges[e].Lg % 2 != 0)
-      return fail(c, GPET_ERR_UNSUPPORTED, "edge %d: odd edge_length=%d (Simpson on an even sample count is scipy-version dependent)", e, b->h_edges[e].Lg);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
@@ -886,9 +883,6 @@ int gpet_select_pixels_only(gpet_batch* b) {
 int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active) {
   if (!b || !base_seeds || !n_active || max_iters < 0) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
-  for (int e = 0; e < b->B; ++e)
-    if (b->h_edges[e].Lg % 2 != 0)
-      return fail(c, GPET_ERR_UNSUPPORTED, "edge %d: odd edge_length=%d", e, b->h_edges[e].Lg);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
   for (int it = 0; it < max_iters; ++it) {

@@ -1340,6 +1340,29 @@ __device__ __forceinline__ double grad_at(const float* __restrict__ grad, int M,
   return (double)grad[(size_t)iy * N + x] * w0 + (double)grad[(size_t)iy1 * N + x] * w1;
 }
 
+// Even number of Simpson samples (odd edge length): scipy >= 1.11 adds Cartwright's correction for the
+// last interval, alpha*y[-1] + beta*y[-2] - eta*y[-3] with the last two spacings h0, h1
+// (scipy/integrate/_quadrature.py simpson; version dependent in the reference).
+__device__ __forceinline__ void simpson_tail(const EdgeDev& E, const double* __restrict__ row, double& al, double& li) {
+  const int Lg = E.Lg;
+  if ((Lg & 1) == 0 || Lg < 5) return;
+  const int k = Lg - 2;  // index of the last sample (N-1); samples are points 0..Lg-2
+  const double ya = row[k - 2], yb = row[k - 1], yc = row[k], yd = row[k + 1];
+  const double da = yb - ya, db = yc - yb, dc = yd - yc;
+  const double l3 = sqrt(1.0 + da * da), l2 = sqrt(1.0 + db * db), l1 = sqrt(1.0 + dc * dc);  // l_{N-3}, l_{N-2}, l_{N-1}
+  // arc length: unit spacing h0 = h1 = 1
+  al += (5.0 / 12.0) * l1 + (2.0 / 3.0) * l2 - (1.0 / 12.0) * l3;
+  // line integral: abscissae are the cumulative lengths -> h0 = l_{N-2}, h1 = l_{N-1}
+  const double h0 = l2, h1 = l1;
+  const double alpha = (2.0 * h1 * h1 + 3.0 * h0 * h1) / (6.0 * (h1 + h0));
+  const double beta = (h1 * h1 + 3.0 * h0 * h1) / (6.0 * h0);
+  const double eta = (h1 * h1 * h1) / (6.0 * h0 * (h0 + h1));
+  const double g1 = grad_at(E.grad, E.M, E.N, yc, E.x_st + k) + 1e-3;
+  const double g2 = grad_at(E.grad, E.M, E.N, yb, E.x_st + k - 1) + 1e-3;
+  const double g3 = grad_at(E.grad, E.M, E.N, ya, E.x_st + k - 2) + 1e-3;
+  li += alpha * g1 + beta * g2 - eta * g3;
+}
+
 // Lane i of a 64-pair chunk owns curve points 2i and 2i+1 (one 16-byte load, fully coalesced);
 // the third point of its Simpson pair, that point's gradient value and the following segment
 // length are the next lane's own values and arrive by wave shuffle -- each sample, each gather and
@@ -1403,7 +1426,10 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   }
   al = wave_sum(al);
   li = wave_sum(li);
-  if (lane == 0) E.costs[s] = al / li;
+  if (lane == 0) {
+    simpson_tail(E, row, al, li);
+    E.costs[s] = al / li;
+  }
 }
 
 // a7, tiled variant (M <= 1100): a workgroup owns 16 Simpson pairs (33 image columns) of up to 512
@@ -1510,6 +1536,7 @@ __global__ void __launch_bounds__(256) k_score_combine(EdgeDev* edges, int n_til
     al += E.cost_part[((size_t)t * E.S + s) * 2];
     li += E.cost_part[((size_t)t * E.S + s) * 2 + 1];
   }
+  simpson_tail(E, E.Y + (size_t)s * E.Lg, al, li);
   E.costs[s] = al / li;
 }
 

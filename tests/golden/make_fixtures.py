@@ -161,30 +161,46 @@ def kernel_fixture():
 
 
 if __name__ == "__main__":
-    kernel_fixture()
+    only = set(sys.argv[1:])  # optional: names of the fixtures to (re)generate
+
+    def want(name):
+        return not only or name in only
+
+    if want("kernels"):
+        kernel_fixture()
     rbf = {'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}
-    stage_fixture("stage_rbf64", 64, 3, dict(kernel_options=rbf, noise_y=1, N_samples=128, score_thresh=1, delta_x=5,
-                                             keep_ratio=0.1, pixel_thresh=3, seed=1, fix_endpoints=True),
-                  np.array([[20, 40], [41, 25], [10, 30]], dtype=np.int64), 11)
-    stage_fixture("stage_mat128", 128, 5, dict(kernel_options=(1, 3, 3), noise_y=0.5, N_samples=256, score_thresh=0.9,
-                                               delta_x=8, keep_ratio=0.125, pixel_thresh=4, seed=7,
-                                               fix_endpoints=False),
-                  np.array([[30, 70], [64, 60], [100, 50], [90, 66]], dtype=np.int64), 23)
-    stage_fixture("stage_mat15_96", 96, 2, dict(kernel_options=(2, 2, 2), noise_y=1, N_samples=200, score_thresh=1,
-                                                delta_x=6, keep_ratio=0.1, pixel_thresh=2, seed=3,
-                                                fix_endpoints=True),
-                  np.zeros((0, 2), dtype=np.int64), 4)
+    small = dict(kernel_options=rbf, noise_y=1, N_samples=128, score_thresh=1, delta_x=5, keep_ratio=0.1,
+                 pixel_thresh=3, seed=1, fix_endpoints=True)
+    if want("stage_rbf64"):
+        stage_fixture("stage_rbf64", 64, 3, dict(small), np.array([[20, 40], [41, 25], [10, 30]], dtype=np.int64), 11)
+    if want("stage_rbf65"):  # odd edge length: even Simpson sample count (scipy-version dependent rule)
+        stage_fixture("stage_rbf65", 65, 3, dict(small), np.array([[20, 40], [41, 25], [10, 30]], dtype=np.int64), 11)
+    if want("stage_mat128"):
+        stage_fixture("stage_mat128", 128, 5, dict(kernel_options=(1, 3, 3), noise_y=0.5, N_samples=256,
+                                                   score_thresh=0.9, delta_x=8, keep_ratio=0.125, pixel_thresh=4,
+                                                   seed=7, fix_endpoints=False),
+                      np.array([[30, 70], [64, 60], [100, 50], [90, 66]], dtype=np.int64), 23)
+    if want("stage_mat15_96"):
+        stage_fixture("stage_mat15_96", 96, 2, dict(kernel_options=(2, 2, 2), noise_y=1, N_samples=200, score_thresh=1,
+                                                    delta_x=6, keep_ratio=0.1, pixel_thresh=2, seed=3,
+                                                    fix_endpoints=True),
+                      np.zeros((0, 2), dtype=np.int64), 4)
     readme = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, N_samples=1000,
                   score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
-    # obs for the 500^2 stage fixture: the oracle/ref trace's own iteration-6 observation set
-    img, edge, kern, grad = make_image(500, 1)
-    tr = gpet.GP_Edge_Tracing(edge[[0, -1], :][:, [1, 0]], grad, **readme)
-    _, (_, all_obs, _) = tr(return_lines=True)
-    stage_fixture("stage_rbf500", 500, 1, dict(readme), np.asarray(all_obs[6]).reshape(-1, 2), 8,
-                  keep_samples=48, keep_factor_rows=96)
-    trace_fixture("trace_rbf64", 64, 3, dict(kernel_options=rbf, noise_y=1, N_samples=128, score_thresh=1, delta_x=5,
-                                             keep_ratio=0.1, pixel_thresh=3, seed=1, fix_endpoints=True))
-    trace_fixture("trace_mat128", 128, 5, dict(kernel_options=(1, 3, 3), noise_y=0.5, N_samples=256, score_thresh=0.9,
-                                               delta_x=8, keep_ratio=0.125, pixel_thresh=4, seed=7,
-                                               fix_endpoints=False))
-    trace_fixture("trace_rbf500", 500, 1, dict(readme))
+    if want("stage_rbf500"):
+        # obs for the 500^2 stage fixture: the reference trace's own iteration-6 observation set
+        img, edge, kern, grad = make_image(500, 1)
+        tr = gpet.GP_Edge_Tracing(edge[[0, -1], :][:, [1, 0]], grad, **readme)
+        _, (_, all_obs, _) = tr(return_lines=True)
+        stage_fixture("stage_rbf500", 500, 1, dict(readme), np.asarray(all_obs[6]).reshape(-1, 2), 8,
+                      keep_samples=48, keep_factor_rows=96)
+    if want("trace_rbf64"):
+        trace_fixture("trace_rbf64", 64, 3, dict(small))
+    if want("trace_rbf65"):
+        trace_fixture("trace_rbf65", 65, 3, dict(small))
+    if want("trace_mat128"):
+        trace_fixture("trace_mat128", 128, 5, dict(kernel_options=(1, 3, 3), noise_y=0.5, N_samples=256,
+                                                   score_thresh=0.9, delta_x=8, keep_ratio=0.125, pixel_thresh=4,
+                                                   seed=7, fix_endpoints=False))
+    if want("trace_rbf500"):
+        trace_fixture("trace_rbf500", 500, 1, dict(readme))

@@ -74,7 +74,7 @@ def test_pixel_selection_500_from_reference_kde(amd, ctx, golden):
     assert b.scalars().score_thresh == float(g["ref_score_thresh_out"])
 
 
-@pytest.mark.parametrize("name", ["trace_rbf64", "trace_mat128", "trace_rbf500"])
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_rbf500"])
 def test_full_trace_vs_oracle(amd, ctx, golden, name):
     """Whole trace on the device vs the oracle run with the library's eigenvector sign
     convention: observation sets per iteration, iteration count and edge trace bit-exact."""
@@ -145,8 +145,8 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
     """The converged fit driven in lock step with the device objective lands on the reference's
     optimum (theta and CI from the reference run, trace_* fixtures, given its observations)."""
     from gaussian_process_edge_trace_amd.gpet import device_final_fits
-    for name, stage in [("trace_rbf64", "stage_rbf64"), ("trace_mat128", "stage_mat128"),
-                        ("trace_rbf500", "stage_rbf500")]:
+    for name, stage in [("trace_rbf64", "stage_rbf64"), ("trace_rbf65", "stage_rbf65"),
+                        ("trace_mat128", "stage_mat128"), ("trace_rbf500", "stage_rbf500")]:
         g = golden(name)
         grad = golden(stage)["ref_grad"]
         kw = dict(CTOR[stage])
