@@ -373,58 +373,6 @@ __global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) 
   }
 }
 
-// cov = (amp*rho(x*,x*) - V^T V) * y_std^2        sklearn_gpr.py:398-403
-// 32x32 output tile per workgroup (16x16 threads, 2x2 each); symmetric: only bx >= by tiles.
-__global__ void __launch_bounds__(256) k_cov(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.z];
-  const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  const int bx = blockIdx.x, by = blockIdx.y;
-  if (bx < by) return;
-  const int Lg = E.Lg;
-  if (bx * 32 >= Lg || by * 32 >= Lg) return;
-  __shared__ double sa[32][33];
-  __shared__ double sb[32][33];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int n = sc->n;
-  double acc[2][2] = {{0, 0}, {0, 0}};
-  for (int i0 = 0; i0 < n; i0 += 32) {
-    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
-      const int ii = e >> 5, jj = e & 31;
-      const int i = i0 + ii;
-      const int ja = by * 32 + jj, jb = bx * 32 + jj;
-      sa[ii][jj] = (i < n && ja < Lg) ? E.V[(size_t)i * Lg + ja] : 0.0;
-      sb[ii][jj] = (i < n && jb < Lg) ? E.V[(size_t)i * Lg + jb] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int ii = 0; ii < 32; ++ii) {
-      const double a0 = sa[ii][ty], a1 = sa[ii][ty + 16];
-      const double b0 = sb[ii][tx], b1 = sb[ii][tx + 16];
-      acc[0][0] += a0 * b0;
-      acc[0][1] += a0 * b1;
-      acc[1][0] += a1 * b0;
-      acc[1][1] += a1 * b1;
-    }
-    __syncthreads();
-  }
-  const double amp = sc->amp, s2 = sc->y_std * sc->y_std;
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int r = by * 32 + ty + 16 * u, c = bx * 32 + tx + 16 * v;
-      if (r < Lg && c < Lg) {
-        const double k = (r == c) ? amp
-                                  : amp * corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + r) / E.length_scale,
-                                                  (double)(E.x_st + c) / E.length_scale);
-        const double val = (k - acc[u][v]) * s2;
-        E.cov[(size_t)r * Lg + c] = val;
-        E.cov[(size_t)c * Lg + r] = val;
-      }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // a6  factor of the posterior covariance (what numpy's SVD-based multivariate_normal builds)
 //     step 1: pivoted Cholesky  cov ~= G^T G  (G rows = columns of the factor), rank-revealing
@@ -1073,63 +1021,6 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// K6  samples = y_s * (Z[:, :rows] @ A + mean)                 gpet.py:260-261
-//     64x64 output tile per workgroup, 16x16 threads, 4x4 outputs each.
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_sample_gemm(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.z];
-  const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  const int Lg = E.Lg, S = E.S, zc = E.z_cols;
-  const int s0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-  if (s0 >= S || j0 >= Lg) return;
-  const int rows = sc->rank;
-  const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
-  __shared__ double sz[16][65];  // [k][s]
-  __shared__ double sa[16][65];  // [k][j]
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double acc[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-  for (int k0 = 0; k0 < rows; k0 += 16) {
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-      const int kk = e & 15, ss = e >> 4;  // Z is [s][k]: k fastest
-      const int k = k0 + kk, s = s0 + ss;
-      sz[kk][ss] = (k < rows && s < S) ? Zs[(size_t)s * zc + k] : 0.0;
-    }
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-      const int jj = e & 63, kk = e >> 6;
-      const int k = k0 + kk, j = j0 + jj;
-      sa[kk][jj] = (k < rows && j < Lg) ? E.A[(size_t)k * Lg + j] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      double zv[4], av[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) zv[u] = sz[kk][ty + 16 * u];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) av[v] = sa[kk][tx + 16 * v];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] += zv[u] * av[v];
-    }
-    __syncthreads();
-  }
-  const double y_s = sc->y_s;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int s = s0 + ty + 16 * u, j = j0 + tx + 16 * v;
-      if (s < S && j < Lg) E.Y[(size_t)s * Lg + j] = (acc[u][v] + E.mean[j]) * y_s;
-    }
-}
-
 // K6 on the matrix cores: v_mfma_f64_16x16x4_f64.  64x64 output tile per workgroup, 4 waves, wave w
 // owns rows 16w..16w+15 and all 64 columns (4 accumulators of 4 f64 per lane); K streamed through
 // LDS in chunks of 32.  Operand maps (cdna_hip_programming.md section 3): A lane l <- A[l&15][l>>4],
@@ -1590,39 +1481,6 @@ __global__ void __launch_bounds__(256) k_kde_clear(EdgeDev* edges, int mode) {
     }
     for (int i = threadIdx.x; i < E.N; i += blockDim.x) E.colsum[i] = 0.0;
   }
-}
-
-// one thread per grid column: the column receives exactly one point per kept curve, binned in
-// curve order (the order KDEpy's sequential loop sees them, gpet.py:487).
-__global__ void __launch_bounds__(64) k_kde_bin_curves(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
-  gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= E.Lg) return;
-  double inv_sum = 0.0;
-  for (int b = 0; b < E.n_keep; ++b) inv_sum += 1.0 / E.best_costs[b];
-  const int gx = E.x_st + k + 1;
-  double* col = E.bins + (size_t)gx * (E.M + 2);
-  double wsum = 0.0;
-  int removed = 0;
-  const double ymax = (double)(E.M - 1);
-  for (int b = 0; b < E.n_keep; ++b) {
-    const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
-    if (y < 0.0 || y > ymax) {  // gpet.py:498-500
-      ++removed;
-      continue;
-    }
-    const double w = (1.0 / E.best_costs[b]) / inv_sum;
-    const double gy = y + 1.0;
-    const int iy = (int)floor(gy);
-    const double fy = gy - (double)iy;
-    col[iy] += (1.0 - fy) * w;
-    col[iy + 1] += fy * w;
-    wsum += w;
-  }
-  E.colsum[E.x_st + k] = wsum;
-  if (removed) atomicAdd(&sc->n_removed, removed);
 }
 
 // gradient KDE (ctor, gpet.py:505-509): points = pixels with grad > 1e-3, weight = grad
