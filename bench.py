@@ -80,8 +80,8 @@ T_START = time.time()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--edges", type=int, default=256,
                     help="independent edges per GPU (BASELINE config 4 is a batch of 256 independent 500x500 edges)")
     ap.add_argument("--size", type=int, default=500)
@@ -89,6 +89,11 @@ def main():
                     help="0: final fits on the GPU (batched LML kernel); >1: host worker processes instead")
     ap.add_argument("--lbfgs-workers", type=int, default=max(1, min(12, (os.cpu_count() or 2) - 2)),
                     help="worker processes advancing scipy's L-BFGS-B routine in lock step (final fits)")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="trace the steps strictly one after the other (default: the converged fits of step k overlap "
+                         "the device loop of step k+1 on a second batch object / HIP stream)")
     ap.add_argument("--cpu-traces", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -106,7 +111,11 @@ def main():
     # L-BFGS-B state machines of the final fits advance in worker processes (the objective runs on
     # the GPU); also created before HIP is initialised
     n_lbfgs = max(2, min(args.lbfgs_workers, ((os.cpu_count() or 2) - 2) // max(1, world))) if args.lbfgs_workers > 1 else 0
-    farm = LockstepFarm(n_lbfgs) if (n_lbfgs > 1 and pool is None) else None
+    pipeline = (not args.no_pipeline) and pool is None
+    depth = max(1, args.pipeline_depth) if pipeline else 0
+    n_farms = depth + 1 if pipeline else 1
+    farms = [LockstepFarm(max(2, n_lbfgs // n_farms)) if (n_lbfgs > 1 and pool is None) else None for _ in range(n_farms)]
+    farm = farms[0]
     import torch
     dist = None
     # GPET_BENCH_BACKEND=gloo + GPET_BENCH_SHARE_GPU=1: rehearsal of the N>1 path on a one-GPU box
@@ -148,29 +157,56 @@ def main():
     seeds = [1 + rank * E + e for e in range(E)]  # independent edges: distinct RNG streams
     tracer = pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx,
                                        fit_pool=pool, fit_farm=farm)
+    tracers = [tracer]
+    for d_ in range(depth):  # more batch objects, each with its own context (= HIP stream) and worker farm
+        ctx_d = L.Context(dev_index)
+        tracers.append(pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx_d,
+                                                 fit_farm=farms[d_ + 1]))
 
     def barrier():
-        ctx.sync()
+        for tr_ in tracers:
+            tr_._ctx.sync()
         if dist is not None:
             torch.cuda.synchronize()
             dist.barrier()
 
-    log("rank %d: batch of %d edges ready" % (rank, E))
-    for _ in range(args.warmup):
-        tracer.reset()
-        tracer()
-        log("warmup step done: %s" % {k: (round(v, 3) if isinstance(v, float) else v[:4]) for k, v in tracer.timings.items()})
+    from concurrent.futures import ThreadPoolExecutor
+    executor = ThreadPoolExecutor(max_workers=max(1, depth))
+
+    def run_steps(n_steps, timed):
+        """n_steps passes of the hot path.  Pipelined: while the converged fits of step k run (host-driven
+        lock-step L-BFGS-B + LML kernels on stream A) the device loop of step k+1 runs on stream B."""
+        loop_s = fit_s = 0.0
+        iters_, traces_, pending = [], None, []
+        for k in range(n_steps):
+            tr_ = tracers[k % len(tracers)]
+            # a batch object is reused only after its previous fits (depth+1 steps ago) were collected
+            while len(pending) > depth:
+                traces_ = pending.pop(0).result()
+            t_a = time.time()
+            tr_.reset()
+            iters_ = tr_.run_loop()
+            t_b2 = time.time()
+            loop_s += t_b2 - t_a
+            if pipeline:
+                pending.append(executor.submit(tr_.finish, iters_))
+            else:
+                traces_ = tr_.finish(iters_)
+                fit_s += time.time() - t_b2
+        t_c = time.time()
+        while pending:
+            traces_ = pending.pop(0).result()
+        if pipeline:
+            fit_s += time.time() - t_c
+        if timed:
+            log("%d step(s): device loops %.3fs, fits %s" % (n_steps, loop_s, ("%.3fs" % fit_s) if not pipeline else "overlapped (tail %.3fs)" % fit_s))
+        return loop_s, fit_s, iters_, traces_
+
+    log("rank %d: batch of %d edges ready%s" % (rank, E, " (pipelined, %d batch objects)" % len(tracers) if pipeline else ""))
+    run_steps(max(args.warmup, len(tracers) if args.warmup else 0), False)
     barrier()
     t0 = time.time()
-    loop_s = fit_s = 0.0
-    iters = []
-    for _ in range(args.steps):
-        tracer.reset()
-        traces = tracer()
-        loop_s += tracer.timings["loop_s"]
-        fit_s += tracer.timings["final_fit_s"]
-        iters = tracer.timings["iters"]
-        log("timed step done: loop %.3fs final fit %.3fs" % (tracer.timings["loop_s"], tracer.timings["final_fit_s"]))
+    loop_s, fit_s, iters, traces = run_steps(args.steps, True)
     barrier()
     elapsed = time.time() - t0
     if dist is not None:
@@ -183,8 +219,9 @@ def main():
     if rank != 0:
         if pool is not None:
             pool.terminate()
-        if farm is not None:
-            farm.close()
+        for f_ in farms:
+            if f_ is not None:
+                f_.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -273,7 +310,7 @@ def main():
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},
         "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
-        "time_split_s": {"device_loop": loop_s, "final_fit": fit_s, "elapsed": elapsed},
+        "time_split_s": {"device_loop": loop_s, "final_fit_not_overlapped": fit_s, "elapsed": elapsed, "pipelined": pipeline, "pipeline_depth": depth},
         "single_edge": {"traces_per_s": 1.0 / single_s, "ms_per_trace": 1e3 * single_s},
         "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b,
         "roofline": roofline, "cpu_baseline": cpu,
@@ -283,8 +320,9 @@ def main():
     print(json.dumps(out))
     if pool is not None:
         pool.terminate()
-    if farm is not None:
-        farm.close()
+    for f_ in farms:
+        if f_ is not None:
+            f_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

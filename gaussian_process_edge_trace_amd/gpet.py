@@ -346,13 +346,9 @@ class GP_Edge_Tracing_Batch(object):
             return fits
         return [_final_fit_job(j) for j in jobs]  # > 128 training points: host objective
 
-    def __call__(self, max_iter=1000):
-        t0 = t.time()
-        iters = self.run_loop(max_iter)
-        t1 = t.time()
+    def finish(self, iters):
+        """Converged fits + rounding of the means to pixel indices (gpet.py:874-886) for every edge."""
         fits = self.final_fits(iters)
-        t2 = t.time()
-        self.timings = dict(loop_s=t1 - t0, final_fit_s=t2 - t1, iters=iters)
         out = []
         for p, (mean, std, theta) in zip(self._ps, fits):
             curve = np.concatenate([p["x_grid"][:, None], mean[:, None]], axis=1)
@@ -360,6 +356,14 @@ class GP_Edge_Tracing_Batch(object):
             out.append((et, (mean - 1.96 * std, mean + 1.96 * std)) if self.return_std else et)
         return out
 
+    def __call__(self, max_iter=1000):
+        t0 = t.time()
+        iters = self.run_loop(max_iter)
+        t1 = t.time()
+        out = self.finish(iters)
+        t2 = t.time()
+        self.timings = dict(loop_s=t1 - t0, final_fit_s=t2 - t1, iters=iters)
+        return out
 
 
 def make_fit_pool(workers):
