@@ -26,9 +26,13 @@ README_KW = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale':
                  score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
 STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "curve_kde"]
 # gpet_profile_stage ids of the single kernels of one iteration (include/gpet_hip.h)
-KERNEL_IDS = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram", 112: "k_jacobi_lds",
-              113: "k_factor_rows", 130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
-              151: "k_kde_fused", 152: "k_kde_normalise"}
+# structured loop path (prior eigenbasis; what gpet_trace_iterate runs for on-grid batches): 120-123;
+# generic path (per-stage API, off-grid observations, GPET_NO_STRUCT=1): 100-113
+KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_lds", 123: "k_struct_rows"}
+KERNEL_IDS_GENERIC = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram",
+                      112: "k_jacobi_lds", 113: "k_factor_rows"}
+KERNEL_IDS_COMMON = {130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
+                     151: "k_kde_fused", 152: "k_kde_normalise"}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak (spec)
 
@@ -241,7 +245,9 @@ def main():
         d["normals"] = d["normals"] / ring
         return d
     stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
-    kernel_ms = {name: tracer._batch.profile_stage(kid, 20) for kid, name in KERNEL_IDS.items()}
+    structured = bool(tracer._batch.info().get("structured", 0))
+    kernel_ids = dict(KERNEL_IDS_STRUCT if structured else KERNEL_IDS_GENERIC, **KERNEL_IDS_COMMON)
+    kernel_ms = {name: tracer._batch.profile_stage(kid, 20) for kid, name in kernel_ids.items()}
     # single edge (BASELINE config 2): latency view
     one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **README_KW, _ctx=ctx)
     one(); one.reset()
@@ -259,8 +265,10 @@ def main():
         "k_cov_mfma": dict(flops=1.0 * Lg * Lg * n_ + 30.0 * Lg * Lg / 2, bytes=8.0 * (Lg * Lg + n_ * Lg)),
         "k_pchol_reg": dict(flops=2.0 * Lg * r * r / 2 * 2, bytes=8.0 * (2 * r * Lg)),
         "k_gram": dict(flops=1.0 * r * r * Lg, bytes=8.0 * (r * Lg + r * r)),
-        "k_jacobi_lds": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
         "k_factor_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
+        "k_struct_H": dict(flops=1.0 * n_ * n_ * r + 2.0 * r * r * n_ + 2.0 * r * Lg, bytes=8.0 * (n_ * n_ / 2 + r * r + r * Lg)),
+        "k_jacobi_lds": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
+        "k_struct_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
         "k_sample_gemm_mfma_r": dict(flops=2.0 * S * Lg * r, bytes=8.0 * (S * r + r * Lg + S * Lg)),
         "k_score": dict(flops=60.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * M_ * N),
         "k_topk": dict(flops=2.0 * S * S, bytes=16.0 * S),
@@ -287,7 +295,8 @@ def main():
                     unit="TFLOP/s" if use_flops else "GB/s",
                     frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
                     launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
-                    state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid),
+                    state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
+                               loop_path="structured" if structured else "generic"),
                     all_kernels={k: dict(ms=v, GBps=alg[k]["bytes"] * E / (v * 1e-3) / 1e9,
                                          TFLOPps=alg[k]["flops"] * E / (v * 1e-3) / 1e12) for k, v in kernel_ms.items()})
 

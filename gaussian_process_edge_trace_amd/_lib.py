@@ -192,10 +192,10 @@ class Batch:
         self._keep = (grads, inits)
 
     def info(self, e=0):
-        v = (C.c_int32 * 10)()
-        self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 10))
+        v = (C.c_int32 * 12)()
+        self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 12))
         keys = ["Lg", "S", "n_keep", "n_cap", "factor_cap", "z_cols", "factor_rows_cap", "n_bins", "obs_cap",
-                "algo_thresh"]
+                "algo_thresh", "structured", "r0"]
         return dict(zip(keys, list(v)))
 
     def scalars(self, e=0) -> GpetScalars:

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -41,6 +42,7 @@ struct gpet_batch {
   hipEvent_t ev_main = nullptr;
   unsigned int* d_minmax = nullptr;
   int share_image = 0;
+  bool structured = false;  // every edge can take the prior-eigenbasis loop path
   // converged-fit scratch (grown on demand)
   int lml_cap = 0;
   int* d_edge_of = nullptr;
@@ -107,6 +109,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.W = cv.take<double>(rc * rc);
   E.theta = cv.take<double>(rc);
   E.order = cv.take<int>(rc);
+  E.Q0 = cv.take<double>(rc * Lg);
+  E.lam0 = cv.take<double>(rc);
+  E.beta = cv.take<double>(rc);
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1));
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
@@ -135,6 +140,8 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   }
 }
 }  // namespace
+
+static int fetch_all_scalars(gpet_batch* b);
 
 extern "C" {
 
@@ -415,6 +422,44 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   // gradient KDE of every distinct image (gpet.py:127)
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : B, b->bd, 1));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // structured loop path: eigenbasis of the grid's correlation matrix, once per edge.  Usable when the
+  // LDS Jacobi applies (capacity <= 96) and every init x lies on the grid; GPET_NO_STRUCT=1 disables it.
+  b->structured = false;
+  if (!any_big && !getenv("GPET_NO_STRUCT")) {
+    bool ok = true;
+    for (int e = 0; e < B && ok; ++e)
+      for (int i = 0; i < b->h_edges[e].n_init; ++i) {
+        const int64_t x = init_xy[e][2 * i];
+        if (x < b->h_edges[e].x_st || x > b->h_edges[e].x_en) ok = false;
+      }
+    if (ok) {
+      HIPCHK(c, launch_struct_basis(c->stream, b->d_edges, B, b->bd));
+      int rc2 = fetch_all_scalars(b);
+      if (rc2) return rc2;
+      int r0_max = 0;
+      for (int e = 0; e < B; ++e) {
+        EdgeDev& E = b->h_edges[e];
+        const gpet_scalars& s = b->h_scalars[e];
+        if (s.status != GPET_OK || s.rank < 1 || s.rank >= E.r_cap) ok = false;  // rank capacity reached
+        E.r0 = s.rank;
+        if (s.rank > r0_max) r0_max = s.rank;
+      }
+      b->bd.r0_max = r0_max;
+      // back to the pristine scalar state
+      for (int e = 0; e < B; ++e) {
+        EdgeDev& E = b->h_edges[e];
+        E.structured = ok ? 1 : 0;
+        gpet_scalars s0;
+        memset(&s0, 0, sizeof s0);
+        s0.score_thresh = params[e].score_thresh;
+        s0.done = (0 >= E.algo_thresh) ? 1 : 0;
+        HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
+      }
+      HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      b->structured = ok;
+    }
+  }
   *out = b;
   return GPET_OK;
 }
@@ -446,8 +491,9 @@ int gpet_batch_size(const gpet_batch* b) { return b ? b->B : 0; }
 int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count) {
   if (!b || e < 0 || e >= b->B || !out) return GPET_ERR_BAD_ARG;
   const EdgeDev& E = b->h_edges[e];
-  const int32_t v[10] = {E.Lg, E.S, E.n_keep, E.n_cap, E.r_cap, E.z_cols, E.a_rows_cap, E.n_bins, E.obs_cap, E.algo_thresh};
-  for (int i = 0; i < count && i < 10; ++i) out[i] = v[i];
+  const int32_t v[12] = {E.Lg, E.S, E.n_keep, E.n_cap, E.r_cap, E.z_cols, E.a_rows_cap, E.n_bins, E.obs_cap, E.algo_thresh,
+                         b->structured ? 1 : 0, E.r0};
+  for (int i = 0; i < count && i < 12; ++i) out[i] = v[i];
   return GPET_OK;
 }
 
@@ -497,6 +543,12 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.status = GPET_OK;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
+  if (b->structured)
+    for (int i = 0; i < n_obs; ++i)
+      if (obs_xy[2 * i] < E.x_st || obs_xy[2 * i] > E.x_en) {  // off-grid training point: generic path from now on
+        b->structured = false;
+        break;
+      }
   if (n_obs > 0)
     HIPCHK(c, hipMemcpyAsync(E.obs_xy, obs_xy, sizeof(long long) * 2 * n_obs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(E.sc, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
@@ -727,8 +779,16 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int r = 0; r < reps; ++r) {
     switch (stage) {
-      case 0: HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1)); break;
-      case 1: HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 0:
+        if (b->structured) HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u | 2u));
+        else HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
+        break;
+      case 1:
+        if (b->structured) HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 4u | 8u));
+        else HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+        break;
+      case 120: case 121: case 122: case 123:  // structured path: fit, (U, H, mean), Jacobi, factor rows
+        HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
       case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring)); break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
@@ -901,8 +961,12 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         HIPCHK(c, hipEventRecord(b->ev_norm[(it + k) % 16], b->side));
       }
     }
-    HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
-    HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+    if (b->structured) {
+      HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd));
+    } else {
+      HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
+      HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+    }
     HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[it % 16], 0));
     HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));

@@ -33,6 +33,11 @@ struct EdgeDev {
   int* perm;             // [r_cap]
   double *C, *W, *theta; // [r_cap*r_cap], [r_cap*r_cap], [r_cap]
   int* order;            // [r_cap] eigenvalue order (descending)
+  // prior eigenbasis of the unit-amplitude Toeplitz correlation matrix of the grid (structured loop path)
+  double* Q0;            // [r_cap*Lg] orthonormal rows q_a^T
+  double* lam0;          // [r_cap] eigenvalues of rho
+  double* beta;          // [r_cap] c * lam0 * Q0[:, obs] alpha
+  int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k

@@ -5,7 +5,7 @@
 namespace gpet {
 
 struct BatchDims {
-  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap, z_ring, a_rows_cap;
+  int M, N, Lg, S, n_keep, z_cols, r_cap, n_cap, n_bins, obs_cap, z_ring, a_rows_cap, r0_max;
 };
 
 hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,
@@ -17,6 +17,8 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
                               unsigned parts = ~0u);
 hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
+hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
+hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead);
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u);

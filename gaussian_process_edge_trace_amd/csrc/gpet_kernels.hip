@@ -723,6 +723,130 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
 }
 
+// ---- structured loop path (training points on the pixel grid, rank(rho) <= 96) ---------------
+// The prior covariance on the unit-spaced grid is c * rho with rho Toeplitz and FIXED for the whole
+// trace: rho = Q Lam Q^T (rank r0 ~ 2.6 Lg / l for RBF) is factored once per edge at construction.
+// With every training x on the grid, K_o* = c rho[obs, :] and the posterior covariance is
+//     Sigma / y_std^2 = Q (c Lam - U^T U) Q^T,   U = L^-1 (c Q[obs, :] Lam)       (n x r0)
+// so an iteration needs only the r0 x r0 matrix H = c Lam - U^T U and its Jacobi eigen-decomposition
+// H = R Theta R^T:  the singular pairs of Sigma are (y_std^2 theta_k, Q r_k) -- no Lg x Lg covariance,
+// no pivoted Cholesky, no Gram matrix; the posterior mean is y_std * Q (c Lam Q[obs,:]^T alpha) + m.
+__global__ void __launch_bounds__(256) k_rho_fill(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const int Lg = E.Lg;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)Lg * Lg; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / Lg), j = (int)(e - (size_t)i * Lg);
+    E.cov[e] = (i == j) ? 1.0
+                        : corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + i) / E.length_scale,
+                                  (double)(E.x_st + j) / E.length_scale);
+  }
+}
+
+// rows of A = sqrt(lam_a) q_a^T (factor of rho)  ->  Q0 (unit rows) and lam0 = |row|^2
+__global__ void __launch_bounds__(256) k_struct_basis(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  const int a = blockIdx.x;
+  if (a >= sc->rank) return;
+  __shared__ double s_red[16];
+  double part = 0.0;
+  for (int j = threadIdx.x; j < E.Lg; j += blockDim.x) {
+    const double v = E.A[(size_t)a * E.Lg + j];
+    part += v * v;
+  }
+  const double nrm2 = block_sum(part, s_red);
+  const double inv = 1.0 / sqrt(nrm2);
+  for (int j = threadIdx.x; j < E.Lg; j += blockDim.x) E.Q0[(size_t)a * E.Lg + j] = E.A[(size_t)a * E.Lg + j] * inv;
+  if (threadIdx.x == 0) E.lam0[a] = nrm2;
+}
+
+// H = c Lam - U^T U (into E.C, row stride r_cap), beta, posterior mean.  One workgroup per edge;
+// U (n x r0) lives in LDS, one thread per column for the forward substitution, rows of L streamed
+// through LDS.
+__global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  extern __shared__ double s_dyn[];
+  const int n = sc->n, r0 = E.r0, Lg = E.Lg, ldk = E.n_cap, ldc = E.r_cap;
+  const int ldu = r0 | 1;
+  double* U = s_dyn;                        // [n_cap][ldu]
+  double* s_l = U + (size_t)E.n_cap * ldu;  // [n_cap] current row of L
+  double* s_b = s_l + E.n_cap;              // [r_cap] beta
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const double c = sc->amp;
+  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i]
+  for (int e = tid; e < n * r0; e += bs) {
+    const int i = e / r0, a = e - i * r0;
+    const int idx = (int)E.xt[i] - E.x_st;
+    U[i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
+  }
+  __syncthreads();
+  // beta_a = sum_i Bo[i][a] alpha_i
+  for (int a = tid; a < r0; a += bs) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += U[i * ldu + a] * E.alpha[i];
+    s_b[a] = acc;
+    E.beta[a] = acc;
+  }
+  // U = L^-1 Bo  (forward substitution, thread a owns column a)
+  for (int i = 0; i < n; ++i) {
+    __syncthreads();
+    const double* ri = E.K + (size_t)i * ldk;
+    for (int t = tid; t <= i; t += bs) s_l[t] = ri[t];
+    __syncthreads();
+    if (tid < r0) {
+      double acc = U[i * ldu + tid];
+      for (int t = 0; t < i; ++t) acc -= s_l[t] * U[t * ldu + tid];
+      U[i * ldu + tid] = acc / s_l[i];
+    }
+  }
+  __syncthreads();
+  // H[a][b] = c lam0[a] delta_ab - sum_i U[i][a] U[i][b]
+  for (int e = tid; e < r0 * r0; e += bs) {
+    const int a = e / r0, b = e - a * r0;
+    if (b > a) continue;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += U[i * ldu + a] * U[i * ldu + b];
+    const double v = ((a == b) ? c * E.lam0[a] : 0.0) - acc;
+    E.C[(size_t)a * ldc + b] = v;
+    E.C[(size_t)b * ldc + a] = v;
+  }
+  // posterior mean on the grid: y_std * (Q beta) + y_mean        sklearn_gpr.py:382-385
+  for (int j = tid; j < Lg; j += bs) {
+    double acc = 0.0;
+    for (int a = 0; a < r0; ++a) acc += E.Q0[(size_t)a * Lg + j] * s_b[a];
+    E.mean[j] = sc->y_std * acc + sc->y_mean;
+  }
+  if (tid == 0) sc->rank = r0;
+}
+
+// factor rows of the structured path: A[k, :] = y_std * sqrt(theta_k) * (Q r_k)^T, sign convention as above
+__global__ void __launch_bounds__(256) k_struct_rows(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int r = E.r0, Lg = E.Lg, k = blockIdx.x;
+  if (k >= r) return;
+  __shared__ double s_red[16];
+  extern __shared__ double s_w[];  // [r]
+  const int col = E.order[k];
+  const double th = E.theta[col];
+  const double scale = sc->y_std * sqrt(th > 0.0 ? th : 0.0);
+  for (int t = threadIdx.x; t < r; t += blockDim.x) s_w[t] = E.W[(size_t)t * E.r_cap + col] * scale;
+  __syncthreads();
+  double part = 0.0;
+  for (int j = threadIdx.x; j < Lg; j += blockDim.x) {
+    double acc = 0.0;
+    for (int t = 0; t < r; ++t) acc += s_w[t] * E.Q0[(size_t)t * Lg + j];
+    E.A[(size_t)k * Lg + j] = acc;
+    part += acc / (double)(j + 1);
+  }
+  const double dot = block_sum(part, s_red);
+  if (dot < 0.0)
+    for (int j = threadIdx.x; j < Lg; j += blockDim.x) E.A[(size_t)k * Lg + j] = -E.A[(size_t)k * Lg + j];
+}
+
 // ---- large ranks (r_cap > 96: Matern spectra, short RBF length scales) ---------------------
 // Cyclic Jacobi applied directly to the Lg x Lg posterior covariance, spread over the whole GPU:
 // one parameter kernel + one apply kernel per round (the round's Lg/2 disjoint rotations touch
@@ -2298,6 +2422,44 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   if (parts & 8u)
     hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
+}
+
+// structured loop path: fit -> (U, H, mean) -> Jacobi (the LDS kernel, on E.C) -> factor rows
+hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
+  (void)hipGetLastError();
+  fit_predict_attrs();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_struct_H, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  if (parts & 1u)
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
+                       ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
+  if (parts & 2u) {
+    const size_t lds = ((size_t)bd.n_cap * (bd.r0_max | 1) + bd.n_cap + bd.r_cap) * sizeof(double);
+    hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), lds, st, d_edges);
+  }
+  if (parts & 4u) {
+    const int mm = (bd.r_cap + 1) & ~1;
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), (size_t)2 * mm * (mm | 1) * sizeof(double), st, d_edges);
+  }
+  if (parts & 8u)
+    hipLaunchKernelGGL(k_struct_rows, dim3(bd.r0_max, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
+  return hipGetLastError();
+}
+
+// construction: eigenbasis of the grid's correlation matrix through the generic factor pipeline
+hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_rho_fill, dim3(256, B), dim3(256), 0, st, d_edges);
+  hipError_t e = launch_set_force(st, d_edges, B, 1);
+  if (e != hipSuccess) return e;
+  e = launch_factor(st, d_edges, B, bd, ~0u);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_struct_basis, dim3(bd.r_cap, B), dim3(256), 0, st, d_edges);
+  return launch_set_force(st, d_edges, B, 0);
 }
 
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,

@@ -140,7 +140,8 @@ int gpet_batch_create(gpet_ctx* ctx, int B, int M, int N, const float* const* gr
                       const gpet_params* params, const int64_t* const* init_xy, gpet_batch** out);
 void gpet_batch_destroy(gpet_batch* b);
 int gpet_batch_size(const gpet_batch* b);
-/* out[0..count): Lg, S, n_keep, n_cap, factor_cap, z_cols, factor_rows_cap, n_bins, obs_cap, algo_thresh */
+/* out[0..count): Lg, S, n_keep, n_cap, factor_cap, z_cols, factor_rows_cap, n_bins, obs_cap, algo_thresh,
+ * structured (1: the loop uses the prior-eigenbasis path), r0 (rank of the grid's correlation matrix) */
 int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count);
 
 /* Back to the state right after gpet_batch_create: no observations, initial score threshold,
@@ -212,7 +213,7 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
  * GEMM, 4 scoring+top-k, 5 curve KDE; single kernels: 100 fit, 101 predict, 102 covariance, 110 pivoted
  * Cholesky, 111 Gram, 112 Jacobi, 113 factor rows, 130 sample GEMM, 140 scoring, 141 top-k, 150 KDE prep,
- * 151 fused KDE, 152 KDE normalise.  (bench.py's roofline leg; leaves the loop state as-is.) */
+ * 151 fused KDE, 152 KDE normalise; structured loop path: 120 fit, 121 U/H/mean, 122 Jacobi, 123 factor rows.  (bench.py's roofline leg; leaves the loop state as-is.) */
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep);
 
 #ifdef __cplusplus

@@ -159,3 +159,38 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
         np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(mean - 1.96 * std, g["ref_ci_lower"], rtol=1e-5, atol=1e-4)
         assert np.array_equal(np.rint(mean).astype(int), g["ref_edge_trace"][:, 0])
+
+
+def test_structured_loop_path_equals_generic(amd, ctx, golden):
+    """The loop's prior-eigenbasis path (H = c Lam - U^T U in the eigenbasis of the grid's Toeplitz
+    correlation matrix) must produce the factor, mean and samples of the generic path
+    (covariance -> pivoted Cholesky -> Gram -> Jacobi) for the same observations."""
+    L = amd._lib
+    g = golden("stage_rbf500")
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR["stage_rbf500"], _ctx=ctx)
+    b = tr._batch
+    info = b.info()
+    assert info["structured"] == 1 and 40 < info["r0"] < 96
+    # generic path through the per-stage API
+    b.set_obs(0, g["in_obs"])
+    b.fit_predict(want_cov=True)
+    b.factor()
+    A_gen = b.read(L.BUF_FACTOR)
+    ev_gen = b.read(L.BUF_EIGVALS)
+    mean_gen = b.read(L.BUF_MEAN)
+    cov = b.read(L.BUF_COV)
+    # structured path: one loop iteration on the same observation set (stages 120-123)
+    b.set_obs(0, g["in_obs"])
+    for stage in (120, 121, 122, 123):
+        b.profile_stage(stage, 1)
+    A_str = b.read(L.BUF_FACTOR)
+    ev_str = b.read(L.BUF_EIGVALS)
+    np.testing.assert_allclose(b.read(L.BUF_MEAN), mean_gen, rtol=1e-10)
+    scale = ev_gen[0]
+    np.testing.assert_allclose(A_str.T @ A_str, cov, rtol=0, atol=1e-9 * scale)
+    k = min(A_gen.shape[0], A_str.shape[0])
+    y_std = b.scalars().y_std
+    np.testing.assert_allclose(ev_str[:k] * y_std ** 2, ev_gen[:k], rtol=1e-6, atol=1e-11 * scale)
+    sig = ev_gen[:k] > 1e-9 * scale
+    for i in np.nonzero(sig)[0]:
+        np.testing.assert_allclose(A_str[i], A_gen[i], rtol=0, atol=2e-5 * np.sqrt(ev_gen[i]) + 1e-9 * np.sqrt(scale))
