@@ -246,7 +246,8 @@ def main():
         return d
     stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
     structured = bool(tracer._batch.info().get("structured", 0))
-    kernel_ids = dict(KERNEL_IDS_STRUCT if structured else KERNEL_IDS_GENERIC, **KERNEL_IDS_COMMON)
+    kernel_ids = dict(KERNEL_IDS_STRUCT if structured else KERNEL_IDS_GENERIC)
+    kernel_ids.update(KERNEL_IDS_COMMON)
     kernel_ms = {name: tracer._batch.profile_stage(kid, 20) for kid, name in kernel_ids.items()}
     # single edge (BASELINE config 2): latency view
     one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **README_KW, _ctx=ctx)

