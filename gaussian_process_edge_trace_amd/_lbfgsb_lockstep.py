@@ -136,10 +136,8 @@ def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
         _, P, bounds, ftol, gtol, maxiter, maxfun, maxls = msg
         factr = ftol / np.finfo(float).eps
         low, up, nbd = _bound_arrays(bounds)
-        base, rem = divmod(P, W)
-        lo = wid * base + min(wid, rem)
-        hi = lo + base + (1 if wid < rem else 0)
-        cnt = hi - lo
+        mine = list(range(wid, P, W))  # interleaved: the 13 restarts of one edge spread over the workers
+        cnt = len(mine)
         WA = np.zeros((cnt, 2 * m * n + 5 * n + 11 * m * m + 8 * m))
         IWA = np.zeros((cnt, 3 * n), dtype=np.int32)
         TASK = np.zeros((cnt, 2), dtype=np.int32)
@@ -147,12 +145,12 @@ def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
         LSAVE = np.zeros((cnt, 4), dtype=np.int32)
         ISAVE = np.zeros((cnt, 44), dtype=np.int32)
         DSAVE = np.zeros((cnt, 29))
-        rows = {i: (X[i], G[i], WA[i - lo], IWA[i - lo], TASK[i - lo], LSAVE[i - lo], ISAVE[i - lo], DSAVE[i - lo],
-                    LNT[i - lo]) for i in range(lo, hi)}
-        n_iter = dict.fromkeys(range(lo, hi), 0)
-        nfev = dict.fromkeys(range(lo, hi), 0)
+        rows = {i: (X[i], G[i], WA[k], IWA[k], TASK[k], LSAVE[k], ISAVE[k], DSAVE[k], LNT[k])
+                for k, i in enumerate(mine)}
+        n_iter = dict.fromkeys(mine, 0)
+        nfev = dict.fromkeys(mine, 0)
         first = True
-        active = list(range(lo, hi))
+        active = list(mine)
         while True:
             pending = []
             for i in active:

@@ -609,6 +609,19 @@ __global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
 // thread updates it in place (column rotation, then row rotation -- the arithmetic of the
 // sequential algorithm) and the whole round needs two barriers.  Odd ranks are padded with a
 // decoupled zero row/column.  Row stride ld is odd: conflict-free row and column walks.
+__device__ __forceinline__ void rr_pair(int m1, int round, int k, int& p, int& q) {  // m1 = m - 1
+  if (k == 0) {
+    p = round;
+    q = m1;
+    return;
+  }
+  int x = round + k, y = round - k;
+  x = x >= m1 ? x - m1 : x;
+  y = y < 0 ? y + m1 : y;
+  p = x < y ? x : y;
+  q = x < y ? y : x;
+}
+
 __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
@@ -616,7 +629,6 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   extern __shared__ double s_mem[];
   __shared__ double s_red[16];
   __shared__ double s_c[64], s_s[64];
-  __shared__ int s_p[64], s_q[64];
   const int r = sc->rank, ldg = E.r_cap;
   const int m = (r + 1) & ~1;
   const int ld = m | 1;
@@ -629,7 +641,25 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
     W[i * ld + j] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int half = m >> 1;
+  const int half = m >> 1, m1 = m - 1;
+  // fixed roles for the whole factorisation.  A: 2x2 blocks (pair a rows) x (pair b columns) of the UPPER
+  // triangle of pairs, a <= b (the mirrored block is written, not recomputed): half (half + 1) / 2 blocks,
+  // one per thread for m <= 88.  W: (pair b, row segment) items, rows seg, seg + nseg, ...
+  const int nblk = half * (half + 1) / 2;
+  int ba[2], bb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * bs;
+    int b_ = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (b_ * (b_ + 1) / 2 > e) --b_;
+    while ((b_ + 1) * (b_ + 2) / 2 <= e) ++b_;
+    bb[u] = b_;
+    ba[u] = e - b_ * (b_ + 1) / 2;
+    if (e >= nblk) ba[u] = -1;
+  }
+  const int nseg = half > 0 ? min(r, bs / half) : 1;
+  const int wb = tid / nseg, wseg = tid - wb * nseg;
+  const bool w_on = half > 0 && wb < half;
   int sweeps = 0;
   if (r >= 2) {
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -644,62 +674,75 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
       // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
       if (off <= 1e-24 * dg || off == 0.0) break;
       ++sweeps;
-      for (int round = 0; round < m - 1; ++round) {
-        for (int k = tid; k < half; k += bs) {
+      for (int round = 0; round < m1; ++round) {
+        if (tid < half) {
           int p, q;
-          if (k == 0) {
-            p = m - 1;
-            q = round;
-          } else {
-            p = (round + k) % (m - 1);
-            q = (round - k + (m - 1)) % (m - 1);
-          }
-          if (p > q) {
-            const int t = p;
-            p = q;
-            q = t;
-          }
+          rr_pair(m1, round, tid, p, q);
           double c = 1.0, s = 0.0;
           const double apq = A[p * ld + q];
           const double app = A[p * ld + p], aqq = A[q * ld + q];
-          if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
-            const double tau = (aqq - app) / (2.0 * apq);
-            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-            c = 1.0 / sqrt(1.0 + t * t);
+          if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
+            // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
+            // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
+            // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
+            const double d = aqq - app, hh = 2.0 * apq;
+            const double rho2 = d * d + hh * hh;
+            double y = __builtin_amdgcn_rsq(rho2);
+            y = y * (1.5 - 0.5 * rho2 * y * y);
+            const double den = fabs(d) + rho2 * y;
+            double iv = __builtin_amdgcn_rcp(den);
+            iv = iv * (2.0 - den * iv);
+            const double t = (d >= 0.0 ? hh : -hh) * iv;
+            const double u = 1.0 + t * t;
+            c = __builtin_amdgcn_rsq(u);
+            c = c * (1.5 - 0.5 * u * c * c);
+            c = c * (1.5 - 0.5 * u * c * c);
             s = t * c;
           }
-          s_c[k] = c;
-          s_s[k] = s;
-          s_p[k] = p;
-          s_q[k] = q;
+          s_c[tid] = c;
+          s_s[tid] = s;
         }
         __syncthreads();
-        // A: 2x2 blocks (pair a rows) x (pair b columns)
-        for (int e = tid; e < half * half; e += bs) {
-          const int a = e / half, b = e - a * half;
-          const double sa = s_s[a], sb = s_s[b];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int a_ = ba[u], b_ = bb[u];
+          if (a_ < 0) continue;
+          const double sa = s_s[a_], sb = s_s[b_];
           if (sa == 0.0 && sb == 0.0) continue;
-          const double ca = s_c[a], cb = s_c[b];
-          const int pa = s_p[a], qa = s_q[a], pb = s_p[b], qb = s_q[b];
+          const double ca = s_c[a_], cb = s_c[b_];
+          int pa, qa, pb, qb;
+          rr_pair(m1, round, a_, pa, qa);
+          rr_pair(m1, round, b_, pb, qb);
           const double b00 = A[pa * ld + pb], b01 = A[pa * ld + qb];
           const double b10 = A[qa * ld + pb], b11 = A[qa * ld + qb];
           const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
           const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-          A[pa * ld + pb] = ca * t00 - sa * t10;
-          A[qa * ld + pb] = sa * t00 + ca * t10;
-          A[pa * ld + qb] = ca * t01 - sa * t11;
-          A[qa * ld + qb] = sa * t01 + ca * t11;
+          const double n00 = ca * t00 - sa * t10, n10 = sa * t00 + ca * t10;
+          const double n01 = ca * t01 - sa * t11, n11 = sa * t01 + ca * t11;
+          A[pa * ld + pb] = n00;
+          A[qa * ld + pb] = n10;
+          A[pa * ld + qb] = n01;
+          A[qa * ld + qb] = n11;
+          if (a_ != b_) {
+            A[pb * ld + pa] = n00;
+            A[pb * ld + qa] = n10;
+            A[qb * ld + pa] = n01;
+            A[qb * ld + qa] = n11;
+          }
         }
         // W: column rotations only
-        for (int e = tid; e < half * r; e += bs) {
-          const int b = e / r, i = e - b * r;
-          const double sb = s_s[b];
-          if (sb == 0.0) continue;
-          const double cb = s_c[b];
-          const int pb = s_p[b], qb = s_q[b];
-          const double wp = W[i * ld + pb], wq = W[i * ld + qb];
-          W[i * ld + pb] = cb * wp - sb * wq;
-          W[i * ld + qb] = sb * wp + cb * wq;
+        if (w_on) {
+          const double sb = s_s[wb];
+          if (sb != 0.0) {
+            const double cb = s_c[wb];
+            int pb, qb;
+            rr_pair(m1, round, wb, pb, qb);
+            for (int i = wseg; i < r; i += nseg) {
+              const double wp = W[i * ld + pb], wq = W[i * ld + qb];
+              W[i * ld + pb] = cb * wp - sb * wq;
+              W[i * ld + qb] = sb * wp + cb * wq;
+            }
+          }
         }
         __syncthreads();
       }
