@@ -1252,34 +1252,30 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // current column tile sits in LDS (shared by the 8 waves) while the next chunk is already in
 // flight from HBM/L2 into registers, so the matrix pipe does not wait for the staging.
 // The MFMA loop only runs over the actual rank (rounded up to 4).
+// The K extent is a template parameter (KS steps of 4, rank rounded up): a run-time bound inside the
+// unrolled MFMA chain makes the compiler copy the accumulators around every step and drain the pipe.
 #define GEMM_KMAX 96
-#define GEMM_PF ((GEMM_KMAX * 64) / 512)  // prefetch registers per thread
-__global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
-  const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+template <int KS>
+__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa) {
+  constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = blockIdx.x * 128;
-  if (s0 >= S) return;
   const int rows = sc->rank;
   const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
-  extern __shared__ double s_fa[];  // [GEMM_KMAX][65]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int srow = s0 + 16 * w + li;
-  double areg[GEMM_KMAX / 4];
+  double areg[KS];
 #pragma unroll
-  for (int q = 0; q < GEMM_KMAX / 4; ++q) {
+  for (int q = 0; q < KS; ++q) {
     const int k = 4 * q + lq;
     areg[q] = (k < rows && srow < S) ? Zs[(size_t)srow * zc + k] : 0.0;
   }
-  const int ksteps = (rows + 3) >> 2;
-  const int kfill = ksteps * 4;
   const double y_s = sc->y_s;
-  double pf[GEMM_PF];
-  // element e = tid + 512 * u of the [kfill][64] chunk: row kk = e >> 6, column jj = e & 63
+  double pf[PF];
+  // element e = tid + 512 * u of the [4 KS][64] chunk: row kk = e >> 6, column jj = e & 63 (zero beyond the rank)
 #pragma unroll
-  for (int u = 0; u < GEMM_PF; ++u) {
+  for (int u = 0; u < PF; ++u) {
     const int e = tid + 512 * u;
     const int kk = e >> 6, j = e & 63;
     pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
@@ -1287,14 +1283,14 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
   for (int j0 = 0; j0 < Lg; j0 += 64) {
     __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
-    for (int u = 0; u < GEMM_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int e = tid + 512 * u;
-      if (e < kfill * 64) s_fa[(e >> 6) * 65 + (e & 63)] = pf[u];
+      s_fa[(e >> 6) * 65 + (e & 63)] = pf[u];
     }
     __syncthreads();
     if (j0 + 64 < Lg) {  // next tile's chunk: loads stay in flight during the MFMAs below
 #pragma unroll
-      for (int u = 0; u < GEMM_PF; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int e = tid + 512 * u;
         const int kk = e >> 6, j = j0 + 64 + (e & 63);
         pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
@@ -1304,13 +1300,11 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < GEMM_KMAX / 4; ++q) {
-      if (q < ksteps) {
-        const double a = areg[q];
-        const double* brow = s_fa + (4 * q + lq) * 65 + li;
+    for (int q = 0; q < KS; ++q) {
+      const double a = areg[q];
+      const double* brow = s_fa + (4 * q + lq) * 65 + li;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * t], acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * t], acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1324,6 +1318,21 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
       }
     }
   }
+}
+
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  if ((int)blockIdx.x * 128 >= E.S) return;
+  extern __shared__ double s_fa[];  // [GEMM_KMAX][65]
+  const int ks = (sc->rank + 3) >> 2;  // uniform over the workgroup
+  if (ks <= 8) sample_gemm_body<8>(E, sc, s_fa);
+  else if (ks <= 12) sample_gemm_body<12>(E, sc, s_fa);
+  else if (ks <= 16) sample_gemm_body<16>(E, sc, s_fa);
+  else if (ks <= 18) sample_gemm_body<18>(E, sc, s_fa);
+  else if (ks <= 20) sample_gemm_body<20>(E, sc, s_fa);
+  else sample_gemm_body<24>(E, sc, s_fa);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
