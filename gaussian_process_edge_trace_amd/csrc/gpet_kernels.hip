@@ -1807,8 +1807,8 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 // rows that can receive weight are the band [ymin-4, ymax+5] of those points, and only that band is
 // processed, in chunks of KDE_H rows through ONE (KDE_TX+8) x (KDE_H+8) f64 LDS tile (39 KB per
 // workgroup with the staging -> 4 workgroups per CU):
-//   linear binning   24 columns x 8 row-slots; a thread owns the rows l with l % 8 == slot and scans
-//                    the curves in order, so every bin is summed in the sequential (KDEpy) order;
+//   linear binning   one (curve, column) point per thread, 64-bit fixed-point LDS atomics (order-independent
+//                    sums; KDEpy itself convolves by FFT, so no summation order is "the" reference);
 //   vertical 9 taps  in place, register sliding window (halo rows saved before the barrier);
 //   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
@@ -1837,6 +1837,10 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t] = c_gauss9[t];
     const bool single = (E.n_keep <= KDE_NB);  // all kept curves fit one staging pass (the usual case)
+    // fixed-point scale of the binning: a bin holds at most one column's weight, <= 1 / W, so
+    // 2^(62 + floor(log2 W)) keeps every sum below 2^62 with an lsb of ~2^-70 (contributions are ~2^-17)
+    const int kexp = 62 + ilogb(W > 0.0 ? W : 1.0);
+    const double fscale = ldexp(1.0, kexp), finv = ldexp(1.0, -kexp);
     // stage curves [b0, b0+nb) of this tile's columns; returns the rows they touch through (lo, hi)
     auto stage = [&](int b0, int nb, int& lo, int& hi) {
       for (int e = tid; e < nb * NC; e += KDE_THREADS) {
@@ -1896,26 +1900,28 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
           stage(b0, nb, dl, dh);
           __syncthreads();
         }
-        const int bc = tid % NC, slot = tid / NC;
-        if (slot < 8) {
-          double* col = s_a + bc * ld;
-          const int lmax = nrow + 8;
-          for (int bb = 0; bb < nb; ++bb) {
-            const double y = s_y[bb * NC + bc];
-            if (y < 0.0) continue;
-            const double gy = y + 1.0;
-            const int iy = (int)floor(gy);
-            const int l = iy - (r0 - 3);
-            if (l + 1 < 0 || l >= lmax) continue;
-            const bool lo = (l >= 0) && ((l & 7) == slot), hi = (l + 1 < lmax) && (((l + 1) & 7) == slot);
-            if (!(lo || hi)) continue;
-            const double w = s_wt[bb];
-            const double fy = gy - (double)iy;
-            if (lo) col[l] += (1.0 - fy) * w;
-            if (hi) col[l + 1] += fy * w;
-          }
+        // linear binning, one (curve, column) point per thread: 64-bit fixed-point LDS atomics, so the sums do
+        // not depend on the order the points arrive in (deterministic), at the resolution of f64 arithmetic
+        unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_a);
+        const int lmax = nrow + 8;
+        for (int e = tid; e < nb * NC; e += KDE_THREADS) {
+          const double y = s_y[e];
+          if (y < 0.0) continue;
+          const int bb = e / NC, bc = e - bb * NC;
+          const double gy = y + 1.0;
+          const int iy = (int)floor(gy);
+          const int l = iy - (r0 - 3);
+          if (l + 1 < 0 || l >= lmax) continue;
+          const double w = s_wt[bb] * fscale;
+          const double fy = gy - (double)iy;
+          unsigned long long* col = s_bits + bc * ld;
+          if (l >= 0) atomicAdd(&col[l], (unsigned long long)__double2ll_rn((1.0 - fy) * w));
+          if (l + 1 < lmax) atomicAdd(&col[l + 1], (unsigned long long)__double2ll_rn(fy * w));
         }
       }
+      __syncthreads();
+      for (int i = tid; i < NC * ld; i += KDE_THREADS)
+        s_a[i] = (double)(long long)reinterpret_cast<unsigned long long*>(s_a)[i] * finv;
       __syncthreads();
       {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
         int nseg = KDE_THREADS / NC;
