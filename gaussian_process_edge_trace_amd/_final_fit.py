@@ -98,11 +98,12 @@ def prepare(init_sorted, obs_xy, x_grid, fix_endpoints):
 
 def start_points(noise_y, seed, n_restarts=12):
     """theta of the kernel (gpet.py:244-245) + log-uniform restarts (sklearn_gpr.py:283-288)."""
-    th = [np.log(np.array([5.0, 5.0, float(noise_y)]))]
+    th = np.empty((1 + max(0, n_restarts), 3))
+    th[0] = np.log(np.array([5.0, 5.0, float(noise_y)]))
     if n_restarts > 0:
         u = np.random.RandomState(seed).uniform(size=(n_restarts, 3))
-        th += [BOUNDS[:, 0] + (BOUNDS[:, 1] - BOUNDS[:, 0]) * u[r] for r in range(n_restarts)]
-    return th
+        th[1:] = BOUNDS[:, 0] + (BOUNDS[:, 1] - BOUNDS[:, 0]) * u  # same elementwise arithmetic as row by row
+    return list(th)
 
 
 def finish(prep, theta, kernel_type, nu):

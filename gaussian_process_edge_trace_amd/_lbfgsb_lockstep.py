@@ -9,6 +9,8 @@ Falls back to plain ``scipy.optimize.minimize`` per problem if the private routi
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 try:  # private but stable across the scipy versions this image ships
@@ -106,7 +108,7 @@ def minimize_many(eval_batch, x0s, bounds, m=10, ftol=2.2204460492503131e-09, gt
 # The same lock-step scheme spread over worker processes.  A setulb step costs ~5-7 us of real
 # L-BFGS-B arithmetic and holds the GIL, so thousands of problems are advanced by W processes
 # that share X / F / G / state arrays with the parent; the parent only runs the batched GPU
-# objective between two barrier waits per round.
+# objective between two shared-memory hand-offs per round (counters polled, no semaphores).
 # ---------------------------------------------------------------------------------------------
 def _attach(name, shape, dtype):
     from multiprocessing import shared_memory
@@ -114,7 +116,25 @@ def _attach(name, shape, dtype):
     return shm, np.ndarray(shape, dtype=dtype, buffer=shm.buf)
 
 
-def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
+def _spin_until(arr, i, value):
+    """Wait until arr[i] == value: the rounds are ~0.1-1 ms apart, far below what a semaphore hand-off
+    costs, so poll shared memory; yield the core after a short burst (workers may outnumber cores)."""
+    k = 0
+    while arr[i] != value:
+        k += 1
+        if k > 200:
+            os.sched_yield()
+
+
+def _wait_until_all(arr, n, value):
+    """Parent side: same polling, but sleeping between looks -- a pure-Python spin would hold the GIL and
+    starve the thread that is driving the device loop of the next batch."""
+    import time
+    while not (arr[:n] == value).all():
+        time.sleep(2e-5)
+
+
+def _farm_worker(wid, W, pmax, n, m, names, conn):
     try:
         from threadpoolctl import threadpool_limits
         _lim = threadpool_limits(limits=1)  # noqa: F841  (kept alive)
@@ -123,11 +143,11 @@ def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
     shms = []
     arrs = {}
     for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
-                                 S=((pmax,), np.int8), C=((4,), np.int64)).items():
+                                 S=((pmax,), np.int8), C=((4,), np.int64), D=((256,), np.int64)).items():
         shm, a = _attach(names[key], shape, dt)
         shms.append(shm)
         arrs[key] = a
-    X, Fs, G, S, C = arrs["X"], arrs["F"], arrs["G"], arrs["S"], arrs["C"]
+    X, Fs, G, S, C, D = arrs["X"], arrs["F"], arrs["G"], arrs["S"], arrs["C"], arrs["D"]
     setulb = _lbfgsb.setulb
     while True:
         msg = conn.recv()
@@ -151,6 +171,7 @@ def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
         nfev = dict.fromkeys(mine, 0)
         first = True
         active = list(mine)
+        rnd = int(C[1])  # the parent's release counter at the start of this job
         while True:
             pending = []
             for i in active:
@@ -175,8 +196,9 @@ def _farm_worker(wid, W, pmax, n, m, names, barrier, conn):
                 S[i] = 1
                 nfev[i] += 1
             first = False
-            barrier.wait()  # parent may now collect the pending points
-            barrier.wait()  # parent has written F / G (or decided to stop)
+            rnd += 1
+            D[wid] = rnd               # parent may now collect the pending points
+            _spin_until(C, 1, rnd)     # parent has written F / G (or decided to stop)
             if C[0] == 0:
                 break
             active = pending
@@ -196,7 +218,7 @@ class LockstepFarm:
         self._shms = {}
         self._arr = {}
         for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
-                                     S=((pmax,), np.int8), C=((4,), np.int64)).items():
+                                     S=((pmax,), np.int8), C=((4,), np.int64), D=((256,), np.int64)).items():
             shm = shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * np.dtype(dt).itemsize)
             self._shms[key] = shm
             self._arr[key] = np.ndarray(shape, dtype=dt, buffer=shm.buf)
@@ -207,12 +229,11 @@ class LockstepFarm:
         try:
             ctx = mp.get_context("forkserver")
             ctx.set_forkserver_preload(["numpy", "scipy.optimize"])
-            self._barrier = ctx.Barrier(self.W + 1)
             names = {k: s.name for k, s in self._shms.items()}
             self._conns, self._procs = [], []
             for w in range(self.W):
                 a, b = ctx.Pipe()
-                p = ctx.Process(target=_farm_worker, args=(w, self.W, self.pmax, n, m, names, self._barrier, b),
+                p = ctx.Process(target=_farm_worker, args=(w, self.W, self.pmax, n, m, names, b),
                                 daemon=True)
                 p.start()
                 self._conns.append(a)
@@ -230,25 +251,41 @@ class LockstepFarm:
         P = len(x0s)
         if P > self.pmax:
             raise ValueError("too many problems for this farm")
-        X, F, G, S, C = (self._arr[k] for k in "XFGSC")
+        X, F, G, S, C, D = (self._arr[k] for k in "XFGSCD")
         X[:P] = np.clip(np.asarray(x0s, dtype=np.float64).reshape(P, self.n), bounds[:, 0], bounds[:, 1])
         S[:P] = 0
         C[0] = 1
+        rnd = int(C[1])
+        D[:self.W] = rnd
         for c in self._conns:
             c.send(("go", P, bounds, ftol, gtol, maxiter, maxfun, maxls))
         rounds = 0
+        import time
+        st = self.stats = dict(wait_workers=0.0, eval=0.0, wait_release=0.0, host=0.0)
         while True:
-            self._barrier.wait()
+            t0 = time.perf_counter()
+            rnd += 1
+            _wait_until_all(D, self.W, rnd)
+            t1 = time.perf_counter()
             idx = np.nonzero(S[:P] == 1)[0]
             if idx.size == 0:
                 C[0] = 0
-                self._barrier.wait()
+                C[1] = rnd
                 break
-            f, g = eval_batch(idx, X[idx])
+            Xi = X[idx]
+            t2 = time.perf_counter()
+            f, g = eval_batch(idx, Xi)
+            t3 = time.perf_counter()
             F[idx] = f
             G[idx] = g
             S[idx] = 0
-            self._barrier.wait()
+            t4 = time.perf_counter()
+            C[1] = rnd
+            t5 = time.perf_counter()
+            st["wait_workers"] += t1 - t0
+            st["host"] += (t2 - t1) + (t4 - t3)
+            st["eval"] += t3 - t2
+            st["wait_release"] += t5 - t4
             rounds += 1
         return X[:P].copy(), F[:P].copy(), rounds
 

@@ -191,6 +191,13 @@ class Batch:
         self.B = B
         self._keep = (grads, inits)
 
+    def _max_info(self, key):
+        """max over the edges of a creation-time constant of gpet_batch_info (cached)."""
+        cache = self.__dict__.setdefault("_info_max", {})
+        if key not in cache:
+            cache[key] = max(self.info(e)[key] for e in range(self.B))
+        return cache[key]
+
     def info(self, e=0):
         v = (C.c_int32 * 12)()
         self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 12))
@@ -264,24 +271,28 @@ class Batch:
                                                         xs.shape[0]))
 
     def read_obs_all(self):
-        cap = max(self.info(e)["obs_cap"] for e in range(self.B))
+        cap = self._max_info("obs_cap")
         dst = np.zeros((self.B, cap, 2), dtype=np.int64)
         cnt = np.zeros(self.B, dtype=np.int32)
         self.ctx.check(self.lib.gpet_batch_read_obs_all(self.h, dst.ctypes.data, cnt.ctypes.data, cap))
         return [dst[e, :cnt[e]].copy() for e in range(self.B)]
 
     def final_set_training_all(self, xs_list, ys_list, w_list):
-        stride = max(len(x) for x in xs_list)
-        pack = lambda lst: np.ascontiguousarray(np.stack([np.pad(np.asarray(a, dtype=np.float64), (0, stride - len(a)))
-                                                          for a in lst]))
-        xs, ys, w = pack(xs_list), pack(ys_list), pack(w_list)
         n = np.asarray([len(x) for x in xs_list], dtype=np.int32)
+        stride = int(n.max())
+
+        def pack(lst):
+            out = np.zeros((len(lst), stride))
+            for i, a in enumerate(lst):
+                out[i, :n[i]] = a
+            return out
+        xs, ys, w = pack(xs_list), pack(ys_list), pack(w_list)
         self.ctx.check(self.lib.gpet_final_set_training_all(self.h, xs.ctypes.data, ys.ctypes.data, w.ctypes.data,
                                                             n.ctypes.data, stride))
 
     def final_predict_all(self, par):
         par = np.ascontiguousarray(par, dtype=np.float64).reshape(self.B, 12)
-        Lg = max(self.info(e)["Lg"] for e in range(self.B))
+        Lg = self._max_info("Lg")
         mean = np.zeros((self.B, Lg))
         std = np.zeros((self.B, Lg))
         self.ctx.check(self.lib.gpet_final_predict_all(self.h, par.ctypes.data, mean.ctypes.data, std.ctypes.data, Lg))

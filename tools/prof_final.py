@@ -32,6 +32,13 @@ def main():
         t2 = time.time()
         print("W=%d E=%d read_obs %.1f ms | final fits %.1f ms (rounds %d; device objective %.1f ms, %d evals in %d launches)"
               % (W, E, 1e3 * (t1 - t0), 1e3 * (t2 - t1), rounds, 1e3 * dev[0], dev[1], dev[2]), flush=True)
+        if farm:
+            print("   farm ms:", {k: round(1e3 * v, 1) for k, v in farm.stats.items()}, flush=True)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    G.device_final_fits(b, tr._ps, obs, iters, farm)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
     if farm:
         farm.close()
 
