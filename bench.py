@@ -245,7 +245,8 @@ def main():
         d["normals"] = d["normals"] / ring
         return d
     stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
-    structured = bool(tracer._batch.info().get("structured", 0))
+    info0 = tracer._batch.info()
+    structured = bool(info0.get("structured", 0))
     kernel_ids = dict(KERNEL_IDS_STRUCT if structured else KERNEL_IDS_GENERIC)
     kernel_ids.update(KERNEL_IDS_COMMON)
     kernel_ms = {name: tracer._batch.profile_stage(kid, 20) for kid, name in kernel_ids.items()}
@@ -277,7 +278,14 @@ def main():
         "k_kde_fused": dict(flops=36.0 * M_ * N + 10.0 * nk * Lg, bytes=8.0 * nk * Lg + 4.0 * M_ * N),
         "k_kde_normalise": dict(flops=2.0 * M_ * N, bytes=8.0 * M_ * N),
     }
-    dom = max(kernel_ms, key=kernel_ms.get)
+    # the normals kernel fills a ring of `ring` iterations per launch on a side stream: per-iteration share
+    zc = info0["z_cols"]
+    kernel_ms["k_mt_normals"] = stage_ms["normals"] * ring
+    alg["k_mt_normals"] = dict(flops=40.0 * S * zc * ring, bytes=8.0 * S * zc * ring)
+    per_iter = {k: (v / ring if k == "k_mt_normals" else v) for k, v in kernel_ms.items()}
+    # dominant kernel of the timed region: every loop kernel runs once per iteration, so the largest
+    # per-iteration share is the largest total (the LML kernel of the final fits: ~80 launches of ~0.1 ms per step)
+    dom = max(per_iter, key=per_iter.get)
     d_ms = kernel_ms[dom]
     a_bytes = alg[dom]["bytes"] * E
     a_flops = alg[dom]["flops"] * E
@@ -296,9 +304,12 @@ def main():
                     unit="TFLOP/s" if use_flops else "GB/s",
                     frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
                     launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
+                    note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
+                          "bound is LDS bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_lds" else None),
                     state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
                                loop_path="structured" if structured else "generic"),
-                    all_kernels={k: dict(ms=v, GBps=alg[k]["bytes"] * E / (v * 1e-3) / 1e9,
+                    all_kernels={k: dict(ms=v, ms_per_iteration=per_iter[k],
+                                         GBps=alg[k]["bytes"] * E / (v * 1e-3) / 1e9,
                                          TFLOPps=alg[k]["flops"] * E / (v * 1e-3) / 1e12) for k, v in kernel_ms.items()})
 
     log("stage profile done; dominant stage %s %.3f ms" % (dom, d_ms))

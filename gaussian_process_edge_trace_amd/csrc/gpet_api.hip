@@ -38,7 +38,11 @@ struct gpet_batch {
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
+  hipStream_t fit = nullptr;           // high-priority stream of the final-fit objective launches: they are tiny and
+                                       // latency-bound, and run while OTHER batches' loops keep the GPU busy
   hipEvent_t ev_norm[16] = {};
+  hipEvent_t ev_gemm[16] = {};         // sample GEMM of iteration k done: ring slot k % ring may be refilled
+  int norm_issued = 0;                 // iterations whose normals have been enqueued on `side`
   hipEvent_t ev_main = nullptr;
   unsigned int* d_minmax = nullptr;
   int share_image = 0;
@@ -393,7 +397,13 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
   HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
   HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  {
+    int pr_least = 0, pr_greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&b->fit, hipStreamNonBlocking, pr_greatest));
+  }
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_norm[i], hipEventDisableTiming));
+  for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_gemm[i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
   float* d_raw = nullptr;
@@ -472,12 +482,18 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_edges) (void)hipFree(b->d_edges);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->fit) {
+    (void)hipStreamSynchronize(b->fit);
+    (void)hipStreamDestroy(b->fit);
+  }
   if (b->side) {
     (void)hipStreamSynchronize(b->side);
     (void)hipStreamDestroy(b->side);
   }
   for (int i = 0; i < 16; ++i)
     if (b->ev_norm[i]) (void)hipEventDestroy(b->ev_norm[i]);
+  for (int i = 0; i < 16; ++i)
+    if (b->ev_gemm[i]) (void)hipEventDestroy(b->ev_gemm[i]);
   if (b->ev_main) (void)hipEventDestroy(b->ev_main);
   if (b->d_edge_of) (void)hipFree(b->d_edge_of);
   if (b->d_theta) (void)hipFree(b->d_theta);
@@ -543,6 +559,7 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.status = GPET_OK;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
+  b->norm_issued = 0;
   if (b->structured)
     for (int i = 0; i < n_obs; ++i)
       if (obs_xy[2 * i] < E.x_st || obs_xy[2 * i] > E.x_en) {  // off-grid training point: generic path from now on
@@ -760,6 +777,7 @@ int gpet_batch_reset(gpet_batch* b) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   b->iters_issued = 0;
+  b->norm_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));
   for (int e = 0; e < b->B; ++e) {
     gpet_scalars s0;
@@ -919,12 +937,12 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
     HIPCHK(c, hipMalloc(&b->d_g, sizeof(double) * 3 * cap));
     b->lml_cap = cap;
   }
-  HIPCHK(c, hipMemcpyAsync(b->d_edge_of, edge_of, sizeof(int) * P, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(b->d_theta, theta, sizeof(double) * 3 * P, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, launch_lml(c->stream, b->d_edges, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g));
-  HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(b->d_edge_of, edge_of, sizeof(int) * P, hipMemcpyHostToDevice, b->fit));
+  HIPCHK(c, hipMemcpyAsync(b->d_theta, theta, sizeof(double) * 3 * P, hipMemcpyHostToDevice, b->fit));
+  HIPCHK(c, launch_lml(b->fit, b->d_edges, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g));
+  HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, b->fit));
+  HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, b->fit));
+  HIPCHK(c, hipStreamSynchronize(b->fit));
   return GPET_OK;
 }
 
@@ -945,21 +963,25 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
+  // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs ahead of
+  // the loop on its own HIP stream -- one launch per iteration, at most `look` iterations ahead (an edge
+  // that finishes wastes at most that many), never past this call's horizon; a ring slot is refilled
+  // only after the sample GEMM that read it (16 iterations earlier) has completed.
+  const int ring = b->bd.z_ring;
+  const int look = ring > 4 ? 4 : ring - 1;
+  const int first = b->iters_issued, horizon = first + max_iters;
+  if (b->norm_issued < first) b->norm_issued = first;
+  HIPCHK(c, hipEventRecord(b->ev_main, c->stream));  // the seeds are on the device
+  HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_main, 0));
   for (int it = 0; it < max_iters; ++it) {
     // every kernel skips edges whose `done` flag is set, so finished edges cost nothing.
-    // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs
-    // ahead of the loop on its own HIP stream, one launch per iteration, up to one ring ahead;
-    // the sample GEMM of iteration k waits on that iteration's event only.
-    const int ring = b->bd.z_ring;
-    if (it % ring == 0) {
-      // the previous ring's slots must be consumed before they are overwritten
-      HIPCHK(c, hipEventRecord(b->ev_main, c->stream));
-      HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_main, 0));
-      const int ahead = (max_iters - it) < ring ? (max_iters - it) : ring;
-      for (int k = 0; k < ahead; ++k) {
-        HIPCHK(c, launch_normals(b->side, b->d_edges, b->B, b->d_seeds, 1, b->iters_issued + k, 1));
-        HIPCHK(c, hipEventRecord(b->ev_norm[(it + k) % 16], b->side));
-      }
+    const int cur = first + it;
+    while (b->norm_issued <= cur + look && b->norm_issued < horizon) {
+      const int j = b->norm_issued;
+      if (j - ring >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
+      HIPCHK(c, launch_normals(b->side, b->d_edges, b->B, b->d_seeds, 1, j, 1));
+      HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
+      b->norm_issued = j + 1;
     }
     if (b->structured) {
       HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd));
@@ -967,8 +989,9 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
       HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
     }
-    HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[it % 16], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
     HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
     HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
