@@ -35,9 +35,14 @@ struct gpet_batch {
   unsigned int* d_seeds = nullptr;
   gpet_scalars* d_scalars = nullptr;   // [B] contiguous: one copy reads every edge's state
   double* d_fin_out = nullptr;         // [B][2][Lg_max] contiguous results of the converged fits
+  double* d_fin_par = nullptr;         // [B][12] contiguous hyper-parameters / transforms of the converged fits
+  long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
+  double* d_fin_stage = nullptr;       // staging of the converged fits' training sets (x | y | w blocks)
+  int* d_fin_n = nullptr;
+  size_t fin_stage_cap = 0;
   hipStream_t fit = nullptr;           // high-priority stream of the final-fit objective launches: they are tiny and
                                        // latency-bound, and run while OTHER batches' loops keep the GPU busy
   hipEvent_t ev_norm[16] = {};
@@ -364,6 +369,8 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   }
   (void)meas.take<gpet_scalars>((size_t)B);
   (void)meas.take<double>((size_t)B * 2 * bd.Lg);
+  (void)meas.take<double>((size_t)B * 12);
+  (void)meas.take<long long>((size_t)B * 2 * bd.obs_cap);
   for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image);
   (void)shared_grad;
   (void)shared_kde;
@@ -382,12 +389,16 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   }
   b->d_scalars = cv.take<gpet_scalars>((size_t)B);
   b->d_fin_out = cv.take<double>((size_t)B * 2 * bd.Lg);
+  b->d_fin_par = cv.take<double>((size_t)B * 12);
+  b->d_obs = cv.take<long long>((size_t)B * 2 * bd.obs_cap);
   b->h_scalars.resize(B);
   for (int e = 0; e < B; ++e) {
     EdgeDev& E = b->h_edges[e];
     E.sc = b->d_scalars + e;
     E.fin_out = b->d_fin_out + (size_t)e * 2 * bd.Lg;
     carve_edge(cv, E, !b->share_image);
+    E.fin_par = b->d_fin_par + (size_t)e * 12;                 // (batch-contiguous; the per-edge carve is unused)
+    E.obs_xy = b->d_obs + (size_t)e * 2 * bd.obs_cap;
     if (b->share_image) {
       E.grad = shared_grad;
       E.grad_kde = shared_kde;
@@ -482,6 +493,8 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_edges) (void)hipFree(b->d_edges);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->d_fin_stage) (void)hipFree(b->d_fin_stage);
+  if (b->d_fin_n) (void)hipFree(b->d_fin_n);
   if (b->fit) {
     (void)hipStreamSynchronize(b->fit);
     (void)hipStreamDestroy(b->fit);
@@ -780,12 +793,12 @@ int gpet_batch_reset(gpet_batch* b) {
   b->norm_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));
   for (int e = 0; e < b->B; ++e) {
-    gpet_scalars s0;
+    gpet_scalars& s0 = b->h_scalars[e];
     memset(&s0, 0, sizeof s0);
     s0.score_thresh = b->params[e].score_thresh;
     s0.done = (0 >= b->h_edges[e].algo_thresh) ? 1 : 0;
-    HIPCHK(c, hipMemcpyAsync(b->h_edges[e].sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
   }
+  HIPCHK(c, hipMemcpyAsync(b->d_scalars, b->h_scalars.data(), sizeof(gpet_scalars) * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GPET_OK;
 }
@@ -862,15 +875,16 @@ int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int st
   HIPCHK(c, hipSetDevice(c->device));
   int rc = fetch_all_scalars(b);
   if (rc) return rc;
+  const int cap = b->bd.obs_cap;
+  std::vector<long long> host((size_t)b->B * 2 * cap);
+  HIPCHK(c, hipMemcpyAsync(host.data(), b->d_obs, host.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int e = 0; e < b->B; ++e) {
     const int n = b->h_scalars[e].n_obs;
     counts[e] = n;
     if (n > stride_obs) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_read_obs_all: edge %d has %d observations > stride %d", e, n, stride_obs);
-    if (n > 0)
-      HIPCHK(c, hipMemcpyAsync(dst + (size_t)e * stride_obs * 2, b->h_edges[e].obs_xy, sizeof(int64_t) * 2 * n,
-                               hipMemcpyDeviceToHost, c->stream));
+    if (n > 0) memcpy(dst + (size_t)e * stride_obs * 2, host.data() + (size_t)e * 2 * cap, sizeof(int64_t) * 2 * n);
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   return GPET_OK;
 }
 
@@ -882,12 +896,25 @@ int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* y
   for (int e = 0; e < b->B; ++e) {
     EdgeDev& E = b->h_edges[e];
     if (n[e] < 1 || n[e] > E.n_cap || n[e] > stride) return fail(c, GPET_ERR_BAD_ARG, "final fit: edge %d n=%d out of range", e, n[e]);
-    HIPCHK(c, hipMemcpyAsync(E.fin_x, xs + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(E.fin_y, ys + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(E.fin_w, w + (size_t)e * stride, sizeof(double) * n[e], hipMemcpyHostToDevice, c->stream));
     E.fin_n = n[e];
   }
-  HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * b->B, hipMemcpyHostToDevice, c->stream));
+  // three block copies + one scatter kernel (which also sets fin_n on the device) instead of 3 B small copies
+  const size_t blk = (size_t)b->B * stride;
+  if (3 * blk > b->fin_stage_cap) {
+    if (b->d_fin_stage) (void)hipFree(b->d_fin_stage);
+    if (b->d_fin_n) (void)hipFree(b->d_fin_n);
+    b->d_fin_stage = nullptr;
+    b->d_fin_n = nullptr;
+    b->fin_stage_cap = 0;
+    HIPCHK(c, hipMalloc(&b->d_fin_stage, sizeof(double) * 3 * blk));
+    HIPCHK(c, hipMalloc(&b->d_fin_n, sizeof(int) * b->B));
+    b->fin_stage_cap = 3 * blk;
+  }
+  HIPCHK(c, hipMemcpyAsync(b->d_fin_stage, xs, sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b->d_fin_stage + blk, ys, sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b->d_fin_stage + 2 * blk, w, sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b->d_fin_n, n, sizeof(int) * b->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_fin_scatter(c->stream, b->d_edges, b->B, b->d_fin_stage, b->d_fin_n, stride));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GPET_OK;
 }
@@ -896,11 +923,9 @@ int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, d
   if (!b || !par || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
-  for (int e = 0; e < b->B; ++e) {
+  for (int e = 0; e < b->B; ++e)
     if (b->h_edges[e].fin_n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_predict_all before the training sets are set");
-    HIPCHK(c, hipMemcpyAsync(b->h_edges[e].fin_par, par + (size_t)e * 12, sizeof(double) * 12, hipMemcpyHostToDevice,
-                             c->stream));
-  }
+  HIPCHK(c, hipMemcpyAsync(b->d_fin_par, par, sizeof(double) * 12 * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_final_predict(c->stream, b->d_edges, b->B, b->bd));
   std::vector<double> host((size_t)b->B * 2 * b->bd.Lg);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -24,6 +24,7 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
+hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);

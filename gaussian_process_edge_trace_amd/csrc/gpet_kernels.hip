@@ -2208,7 +2208,7 @@ __device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, doub
 // total and n barriers, against the ~3n barriers and the LDS-resident L / L^-1 (2 x 66 KB, one
 // workgroup per CU) of a Cholesky + triangular inverse; LDS use is ~3 KB so several problems share a CU.
 #define LML_MAXD 136  // 4 * ceil((128 + 1) / 4) + slack
-__global__ void __launch_bounds__(576) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+__global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                              double* g_out) {
   const int pb = blockIdx.x;
   const EdgeDev E = edges[edge_of[pb]];
@@ -2572,6 +2572,25 @@ __global__ void __launch_bounds__(256) k_pix_reset(EdgeDev* edges) {
 }
 
 __global__ void k_set_force(EdgeDev* edges, int v) { edges[blockIdx.x].sc->force = v; }
+
+// training sets of the converged fits: staged as three [B][stride] blocks (x | y | w), scattered to the edges
+__global__ void __launch_bounds__(128) k_fin_scatter(EdgeDev* edges, const double* stage, const int* n, int stride, int B) {
+  const int e = blockIdx.x;
+  EdgeDev& E = edges[e];
+  const int ne = n[e];
+  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+    E.fin_x[i] = stage[(size_t)e * stride + i];
+    E.fin_y[i] = stage[((size_t)B + e) * stride + i];
+    E.fin_w[i] = stage[((size_t)2 * B + e) * stride + i];
+  }
+  if (threadIdx.x == 0) E.fin_n = ne;
+}
+
+hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_fin_scatter, dim3(B), dim3(128), 0, st, d_edges, d_stage, d_n, stride, B);
+  return hipGetLastError();
+}
 
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v) {
   (void)hipGetLastError();
