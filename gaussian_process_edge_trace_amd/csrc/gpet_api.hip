@@ -121,6 +121,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.Q0 = cv.take<double>(rc * Lg);
   E.lam0 = cv.take<double>(rc);
   E.beta = cv.take<double>(rc);
+  E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1));
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);

@@ -629,6 +629,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
   extern __shared__ double s_mem[];
   __shared__ double s_red[16];
   __shared__ double s_c[64], s_s[64];
+  __shared__ int s_pos[96];
   const int r = sc->rank, ldg = E.r_cap;
   const int m = (r + 1) & ~1;
   const int ld = m | 1;
@@ -762,6 +763,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
       pos += (u > v) || (u == v && j < k);
     }
     E.order[pos] = k;
+    s_pos[k] = pos;
+  }
+  __syncthreads();
+  // C (consumed above) <- eigenvectors in descending eigenvalue order, scaled by y_std sqrt(theta): column pos of
+  // row t is the coefficient of basis vector t in factor row pos (what k_struct_rows multiplies with Q0)
+  for (int e = tid; e < r * r; e += bs) {
+    const int i = e / r, j = e - i * r;
+    const double th = A[j * ld + j];
+    E.C[(size_t)i * ldg + s_pos[j]] = W[i * ld + j] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
   }
   if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
 }
@@ -864,29 +874,103 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
   if (tid == 0) sc->rank = r0;
 }
 
-// factor rows of the structured path: A[k, :] = y_std * sqrt(theta_k) * (Q r_k)^T, sign convention as above
+// factor rows of the structured path: A[k, :] = y_std * sqrt(theta_k) * (Q r_k)^T as a column-tiled product
+// (r0 x r0) . (r0 x 64) on v_mfma_f64_16x16x4_f64: the Q0 tile and the scaled, ordered eigenvectors sit in
+// LDS, wave w owns 16 of the 64 columns and all MT row tiles, so Q0 is read from HBM once per iteration.
+// The sign convention needs whole-row sums: per-tile partials here, the flip in k_struct_sign (fixed order).
+// MT (row tiles of 16) is a template parameter for the same reason as the K extent of the sample GEMM.
+#define SR_TJ 64
+typedef double v4f64_ __attribute__((ext_vector_type(4)));
+template <int MT, int KS>
+__device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w) {
+  const int r = E.r0, Lg = E.Lg;
+  const int j0 = blockIdx.x * SR_TJ;
+  constexpr int kpad = 4 * KS;
+  constexpr int ldw = 16 * MT + 1;  // [kpad][ldw]: s_w[t][k] = scaled coefficient of basis vector t in row k
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int j = j0 + 16 * w + li;
+  // B operand (Q0[t][j], this wave's 16 columns) straight into registers; A operand (E.C, written by the Jacobi
+  // kernel) through LDS, shared by the four waves
+  double breg[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int t = 4 * q + lq;
+    breg[q] = (t < r && j < Lg) ? E.Q0[(size_t)t * Lg + j] : 0.0;
+  }
+#pragma unroll 4
+  for (int e = tid; e < kpad * 16 * MT; e += 256) {
+    const int t = e / (16 * MT), k = e - t * (16 * MT);
+    s_w[t * ldw + k] = (t < r && k < r) ? E.C[(size_t)t * E.r_cap + k] : 0.0;
+  }
+  __syncthreads();
+  v4f64_ acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f64_){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const double* wr = s_w + (4 * q + lq) * ldw + li;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[16 * mt], breg[q], acc[mt], 0, 0, 0);
+  }
+  __syncthreads();  // s_w is reused, as [r][64], for the products A[k][j] / (j + 1)
+  double* s_p = s_w;
+  const double inv_j = 1.0 / (double)(j + 1);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k = 16 * mt + lq + 4 * g;
+      if (k < r) {
+        const double v = acc[mt][g];
+        if (j < Lg) E.A[(size_t)k * Lg + j] = v;
+        s_p[k * 64 + 16 * w + li] = (j < Lg) ? v * inv_j : 0.0;
+      }
+    }
+  __syncthreads();
+  const int ntile = (Lg + SR_TJ - 1) / SR_TJ;
+  // row sums of the tile: 4 independent accumulators per row (fixed order), rows strided over the threads
+  for (int k = tid; k < r; k += 256) {
+    const double* row = s_p + k * 64;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+      d0 += row[(c + k) & 63];
+      d1 += row[(c + 1 + k) & 63];
+      d2 += row[(c + 2 + k) & 63];
+      d3 += row[(c + 3 + k) & 63];
+    }
+    E.row_part[(size_t)k * ntile + blockIdx.x] = (d0 + d1) + (d2 + d3);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_struct_rows(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
-  const int r = E.r0, Lg = E.Lg, k = blockIdx.x;
-  if (k >= r) return;
-  __shared__ double s_red[16];
-  extern __shared__ double s_w[];  // [r]
-  const int col = E.order[k];
-  const double th = E.theta[col];
-  const double scale = sc->y_std * sqrt(th > 0.0 ? th : 0.0);
-  for (int t = threadIdx.x; t < r; t += blockDim.x) s_w[t] = E.W[(size_t)t * E.r_cap + col] * scale;
-  __syncthreads();
-  double part = 0.0;
-  for (int j = threadIdx.x; j < Lg; j += blockDim.x) {
-    double acc = 0.0;
-    for (int t = 0; t < r; ++t) acc += s_w[t] * E.Q0[(size_t)t * Lg + j];
-    E.A[(size_t)k * Lg + j] = acc;
-    part += acc / (double)(j + 1);
-  }
-  const double dot = block_sum(part, s_red);
-  if (dot < 0.0)
+  if ((int)blockIdx.x * SR_TJ >= E.Lg || E.r0 < 1) return;
+  extern __shared__ __attribute__((aligned(16))) double s_rows[];
+  const int r = E.r0;  // uniform over the workgroup
+  if (r <= 32) struct_rows_body<2, 8>(E, s_rows);
+  else if (r <= 48) struct_rows_body<3, 12>(E, s_rows);
+  else if (r <= 64) struct_rows_body<4, 16>(E, s_rows);
+  else if (r <= 72) struct_rows_body<5, 18>(E, s_rows);
+  else if (r <= 80) struct_rows_body<5, 20>(E, s_rows);
+  else struct_rows_body<6, 24>(E, s_rows);
+}
+
+// sign convention sum_j A[k][j] / (j + 1) >= 0 from the per-tile partials
+__global__ void __launch_bounds__(128) k_struct_sign(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int k = blockIdx.x, Lg = E.Lg;
+  if (k >= E.r0) return;
+  const int ntile = (Lg + SR_TJ - 1) / SR_TJ;
+  double d = 0.0;
+  for (int c = 0; c < ntile; ++c) d += E.row_part[(size_t)k * ntile + c];
+  if (d < 0.0)
     for (int j = threadIdx.x; j < Lg; j += blockDim.x) E.A[(size_t)k * Lg + j] = -E.A[(size_t)k * Lg + j];
 }
 
@@ -2507,6 +2591,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_struct_H, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_struct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
   if (parts & 1u)
@@ -2520,8 +2605,17 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     const int mm = (bd.r_cap + 1) & ~1;
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), (size_t)2 * mm * (mm | 1) * sizeof(double), st, d_edges);
   }
-  if (parts & 8u)
-    hipLaunchKernelGGL(k_struct_rows, dim3(bd.r0_max, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
+  if (parts & 8u) {
+    // the variant k_struct_rows picks for r0_max: [4 KS][16 MT + 1] eigenvector tile, reused as [r][64] products
+    const int rm = bd.r0_max;
+    const int mt = rm <= 32 ? 2 : rm <= 48 ? 3 : rm <= 64 ? 4 : rm <= 80 ? 5 : 6;
+    const int ks = rm <= 32 ? 8 : rm <= 48 ? 12 : rm <= 64 ? 16 : rm <= 72 ? 18 : rm <= 80 ? 20 : 24;
+    size_t words = (size_t)4 * ks * (16 * mt + 1);
+    if (words < (size_t)4 * ks * 64) words = (size_t)4 * ks * 64;
+    const size_t lds = words * sizeof(double);
+    hipLaunchKernelGGL(k_struct_rows, dim3(cdiv(bd.Lg, SR_TJ), B), dim3(256), lds, st, d_edges);
+    hipLaunchKernelGGL(k_struct_sign, dim3(bd.r0_max, B), dim3(128), 0, st, d_edges);
+  }
   return hipGetLastError();
 }
 
