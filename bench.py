@@ -32,7 +32,7 @@ KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_lds", 123: 
 KERNEL_IDS_GENERIC = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram",
                       112: "k_jacobi_lds", 113: "k_factor_rows"}
 KERNEL_IDS_COMMON = {130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
-                     151: "k_kde_fused", 152: "k_kde_normalise"}
+                     151: "k_kde_fused"}  # (152 k_kde_normalise: stage API only; the loop normalises inside the pixel kernels)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak (spec)
 
@@ -276,7 +276,6 @@ def main():
         "k_topk": dict(flops=2.0 * S * S, bytes=16.0 * S),
         "k_kde_prep": dict(flops=2.0 * nk * Lg, bytes=8.0 * nk * Lg),
         "k_kde_fused": dict(flops=36.0 * M_ * N + 10.0 * nk * Lg, bytes=8.0 * nk * Lg + 4.0 * M_ * N),
-        "k_kde_normalise": dict(flops=2.0 * M_ * N, bytes=8.0 * M_ * N),
     }
     # the normals kernel fills a ring of `ring` iterations per launch on a side stream: per-iteration share
     zc = info0["z_cols"]

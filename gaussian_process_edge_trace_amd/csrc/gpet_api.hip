@@ -134,6 +134,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.bins = cv.take<double>(gpx);
   E.tmpk = cv.take<double>(gpx);
   E.kde = cv.take<float>(px);
+  E.kde_band = cv.take<int>(2 * ((size_t)E.N / 16 + 2));
   E.colsum = cv.take<double>((size_t)E.N);
   E.colbest = cv.take<double>((size_t)E.N);
   E.colbest_y = cv.take<int>((size_t)E.N);
@@ -824,7 +825,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring)); break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
-      case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0)); break;
+      case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1)); break;  // (the loop form: raw, band only)
       case 6: HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd)); break;  // (reset only: selection mutates the loop state)
       // single kernels: 100+ fit/predict/cov, 110+ pchol/gram/jacobi/rows, 130 gemm, 140+ score/topk, 150+ kde prep/fused/normalise
       case 100: case 101: case 102:
@@ -833,7 +834,8 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 110))); break;
       case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
       case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
-      case 150: case 151: case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150))); break;
+      case 150: case 151: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150), 1)); break;
+      case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 4u, 0)); break;  // (stage-API form only)
       default: return fail(c, GPET_ERR_BAD_ARG, "gpet_profile_stage: unknown stage %d", stage);
     }
   }
@@ -1019,8 +1021,9 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
     HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
-    HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
-    HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd));
+    // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
+    HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1));
+    HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd, 1));
     b->iters_issued += 1;
   }
   b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = (max_iters > 0) || b->have_fit;

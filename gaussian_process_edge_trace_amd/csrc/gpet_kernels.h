@@ -21,8 +21,9 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
 hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead);
-hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u);
-hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u,
+                      int raw_band = 0);
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);

@@ -1897,7 +1897,7 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
 //   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
 // columns outside the padded grid never receive weight.
-__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -2055,14 +2055,23 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
       __syncthreads();
     }
   }
-  // rows outside the band (all rows for tiles away from the edge): zeros
+  // rows outside the band (all rows for tiles away from the edge): zeros.  raw_band (the loop form): they are
+  // not written -- the pixel kernels take the band from kde_band and treat everything outside it as zero.
   bool wrote_zero = false;
-  for (int idx = tid; idx < KDE_TX * M; idx += KDE_THREADS) {
-    const int xl = idx % KDE_TX, y = idx / KDE_TX;
-    if (y >= y_lo && y <= y_hi) continue;
-    if (x0 + xl < N) {
-      out[(size_t)y * N + x0 + xl] = 0.f;
-      wrote_zero = true;
+  if (raw_band) {
+    if (tid == 0) {
+      E.kde_band[2 * blockIdx.x] = y_lo;
+      E.kde_band[2 * blockIdx.x + 1] = y_hi;
+    }
+    wrote_zero = (tid == 0) && (y_hi - y_lo + 1 < M);
+  } else {
+    for (int idx = tid; idx < KDE_TX * M; idx += KDE_THREADS) {
+      const int xl = idx % KDE_TX, y = idx / KDE_TX;
+      if (y >= y_lo && y <= y_hi) continue;
+      if (x0 + xl < N) {
+        out[(size_t)y * N + x0 + xl] = 0.f;
+        wrote_zero = true;
+      }
     }
   }
   if (wrote_zero) {
@@ -2081,6 +2090,15 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges) {
   }
 }
 
+// normalised curve KDE at a pixel.  raw_band: E.kde holds the raw density of the band rows only; the min-max
+// normalisation of k_kde_normalise ((v - min) / span in float32, gpet_utils.py:81-91) is applied here instead.
+__device__ __forceinline__ double kde_at(const EdgeDev& E, int x, int y, int raw_band, float mn, float span) {
+  if (!raw_band) return (double)E.kde[(size_t)y * E.N + x];
+  const int t = x / KDE_TX;
+  const float raw = (y >= E.kde_band[2 * t] && y <= E.kde_band[2 * t + 1]) ? E.kde[(size_t)y * E.N + x] : 0.f;
+  return (double)((raw - mn) / span);
+}
+
 // pixel_scores = 1/3 * (i*g + i + g) with numpy's rounding order (gpet.py:582)
 __device__ __forceinline__ double pixel_score(double iv, double gv) {
 #pragma clang fp contract(off)
@@ -2097,7 +2115,7 @@ __device__ __forceinline__ int bin_of(const EdgeDev& E, int x) {
 // best new candidate of every admissible column (first in row-major order among equals).
 // 16 columns x 16 row-lanes per workgroup: each thread scans every 16th row of its column
 // (independent, column-coalesced loads), then the 16 lanes of a column reduce in LDS.
-__global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
+__global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges, int raw_band) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -2108,9 +2126,18 @@ __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
   double best = -1.0;
   int by = -1;
   const bool admissible = (x < E.N) && (E.fix_endpoints ? (x > E.x_st && x < E.x_en) : true);  // gpet.py:655-657
+  const float mn = f32_from_key(E.mm[0]);
+  const float span = f32_from_key(E.mm[1]) - mn;
+  // raw_band: rows outside the tile's band hold density 0 -> normalised 0 <= 1e-3 unless the minimum of the
+  // whole image is negative (it is not: densities are sums of non-negative terms), so only the band is scanned
+  int y_first = 0, y_last = E.M - 1;
+  if (raw_band) {
+    y_first = E.kde_band[2 * blockIdx.x];
+    y_last = E.kde_band[2 * blockIdx.x + 1];
+  }
   if (admissible) {
-    for (int y = ry; y < E.M; y += 16) {
-      const double iv = (double)E.kde[(size_t)y * E.N + x];
+    for (int y = y_first + ry; y <= y_last; y += 16) {
+      const double iv = raw_band ? (double)((E.kde[(size_t)y * E.N + x] - mn) / span) : (double)E.kde[(size_t)y * E.N + x];
       if (iv > 1e-3) {  // gpet.py:651
         const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
         if (sv > best) {  // rows visited in increasing order: first maximum kept
@@ -2139,14 +2166,15 @@ __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges) {
 }
 
 // previously accepted observations are re-scored and compete first (gpet.py:568-579)
-__global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges) {
+__global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges, int raw_band) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sc->n_obs) return;
   const long long x = E.obs_xy[2 * i], y = E.obs_xy[2 * i + 1];
-  const double iv = (double)E.kde[(size_t)y * E.N + x];
+  const float mn = f32_from_key(E.mm[0]);
+  const double iv = kde_at(E, (int)x, (int)y, raw_band, mn, f32_from_key(E.mm[1]) - mn);
   if (iv > 1e-3) {
     const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
     atomicMax(&E.binbest[bin_of(E, (int)x)], (unsigned long long)__double_as_longlong(sv));
@@ -2155,7 +2183,7 @@ __global__ void __launch_bounds__(256) k_pix_old(EdgeDev* edges) {
 
 // among the candidates that reach their bin's best score, the first in the reference's candidate
 // order wins (np.argmax): old observations in their order, then new pixels in row-major order.
-__global__ void __launch_bounds__(256) k_pix_argbest(EdgeDev* edges) {
+__global__ void __launch_bounds__(256) k_pix_argbest(EdgeDev* edges, int raw_band) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -2163,7 +2191,8 @@ __global__ void __launch_bounds__(256) k_pix_argbest(EdgeDev* edges) {
   const int n_obs = sc->n_obs;
   if (t < n_obs) {
     const long long x = E.obs_xy[2 * t], y = E.obs_xy[2 * t + 1];
-    const double iv = (double)E.kde[(size_t)y * E.N + x];
+    const float mn = f32_from_key(E.mm[0]);
+    const double iv = kde_at(E, (int)x, (int)y, raw_band, mn, f32_from_key(E.mm[1]) - mn);
     if (iv > 1e-3) {
       const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
       const int b = bin_of(E, (int)x);
@@ -2639,14 +2668,16 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
 }
 
 // mode 0: KDE of the best curves -> E.kde ; mode 1: KDE of the gradient image -> E.grad_kde
-hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts) {
+hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts,
+                      int raw_band) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   if (mode == 0) {
     // per-iteration path: one prep kernel + one fused bin/convolve kernel + normalise
     const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
     if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
-    if (parts & 2u) hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges);
-    if (parts & 4u) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
+    if (parts & 2u)
+      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band);
+    if ((parts & 4u) && !raw_band) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_kde_clear, dim3(64, B), dim3(256), 0, st, d_edges, mode);
@@ -2699,12 +2730,12 @@ hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   return hipGetLastError();
 }
 
-hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 16), B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 16), B), dim3(256), 0, st, d_edges, raw_band);
   const int nt = bd.N > bd.obs_cap ? bd.N : bd.obs_cap;
-  hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges);
-  hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges, raw_band);
+  hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges, raw_band);
   hipLaunchKernelGGL(k_pix_select, dim3(1, B), dim3(64), 0, st, d_edges);
   return hipGetLastError();
 }

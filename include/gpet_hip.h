@@ -84,7 +84,9 @@ typedef enum gpet_buf {
   GPET_BUF_BEST_COSTS = 13, /* f64 [n_keep]                                gpet.py:445 */
   GPET_BUF_SCALARS = 14,  /* gpet_scalars                                  */
   GPET_BUF_OBS = 15,      /* i64 [n_obs*2] xy                              gpet.py:857 */
-  GPET_BUF_KDE = 16,      /* f32 [M*N]      normalised curve KDE           gpet.py:648 */
+  GPET_BUF_KDE = 16,      /* f32 [M*N]      normalised curve KDE           gpet.py:648
+                           *                (as left by gpet_select_pixels; gpet_trace_iterate keeps the raw density of
+                           *                 the band rows only and normalises inside its pixel kernels) */
   GPET_BUF_GRAD_KDE = 17, /* f32 [M*N]      normalised gradient KDE        gpet.py:127 */
   GPET_BUF_GRAD = 18,     /* f32 [M*N]      normalised gradient image      gpet.py:97 */
   GPET_BUF_NOISE_W = 19   /* f64 [n]        per-point noise weights        gpet.py:209-213 */
@@ -213,7 +215,9 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
  * GEMM, 4 scoring+top-k, 5 curve KDE; single kernels: 100 fit, 101 predict, 102 covariance, 110 pivoted
  * Cholesky, 111 Gram, 112 Jacobi, 113 factor rows, 130 sample GEMM, 140 scoring, 141 top-k, 150 KDE prep,
- * 151 fused KDE, 152 KDE normalise; structured loop path: 120 fit, 121 U/H/mean, 122 Jacobi, 123 factor rows.  (bench.py's roofline leg; leaves the loop state as-is.) */
+ * 151 fused KDE (5, 150, 151: the loop form -- raw density, band rows only), 152 KDE normalise (stage-API form);
+ * structured loop path: 120 fit, 121 U/H/mean, 122 Jacobi, 123 factor rows + sign pass.
+ * (bench.py's roofline leg; leaves the loop state as-is.) */
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep);
 
 #ifdef __cplusplus
