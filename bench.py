@@ -118,7 +118,9 @@ def main():
     pipeline = (not args.no_pipeline) and pool is None
     depth = max(1, args.pipeline_depth) if pipeline else 0
     n_farms = depth + 1 if pipeline else 1
-    farms = [LockstepFarm(max(2, n_lbfgs // n_farms)) if (n_lbfgs > 1 and pool is None) else None for _ in range(n_farms)]
+    # one farm, one job slot per batch object: a fit running alone (the last of a run) gets every worker
+    big_farm = LockstepFarm(n_lbfgs, slots=n_farms) if (n_lbfgs > 1 and pool is None) else None
+    farms = [big_farm.slot(i) if big_farm is not None else None for i in range(n_farms)]
     farm = farms[0]
     import torch
     dist = None
@@ -223,9 +225,8 @@ def main():
     if rank != 0:
         if pool is not None:
             pool.terminate()
-        for f_ in farms:
-            if f_ is not None:
-                f_.close()
+        if big_farm is not None:
+            big_farm.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -340,9 +341,8 @@ def main():
     print(json.dumps(out))
     if pool is not None:
         pool.terminate()
-    for f_ in farms:
-        if f_ is not None:
-            f_.close()
+    if big_farm is not None:
+        big_farm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -134,7 +134,41 @@ def _wait_until_all(arr, n, value):
         time.sleep(2e-5)
 
 
-def _farm_worker(wid, W, pmax, n, m, names, conn):
+def _advance(job, X, Fs, G, S, wid):
+    """One lock-step round of a job's problems owned by this worker: run setulb on every active
+    problem until it asks for f/g (S=1) or stops (S=2)."""
+    setulb = _lbfgsb.setulb
+    m, low, up, nbd, factr, gtol, maxiter, maxfun, maxls = job["consts"]
+    rows, n_iter, nfev, first = job["rows"], job["n_iter"], job["nfev"], job["first"]
+    pending = []
+    for i in job["active"]:
+        x, g, wa, iwa, task, lsave, isave, dsave, lnt = rows[i]
+        f = 0.0 if first else float(Fs[i])
+        while True:
+            setulb(m, x, low, up, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, lnt)
+            t0 = task[0]
+            if t0 == 3:
+                pending.append(i)
+                break
+            if t0 == 1:
+                n_iter[i] += 1
+                if n_iter[i] >= maxiter:
+                    task[0], task[1] = 5, 504
+                elif nfev[i] > maxfun:
+                    task[0], task[1] = 5, 502
+                continue
+            S[i] = 2
+            break
+    for i in pending:
+        S[i] = 1
+        nfev[i] += 1
+    job["first"] = False
+    job["active"] = pending
+
+
+def _farm_worker(wid, W, slots, pmax, n, m, names, conn):
+    """Worker of a LockstepFarm: serves up to `slots` concurrent jobs (one per parent thread), taking the
+    problems i = wid (mod W) of each; a job alone in the farm therefore gets all W workers."""
     try:
         from threadpoolctl import threadpool_limits
         _lim = threadpool_limits(limits=1)  # noqa: F841  (kept alive)
@@ -142,83 +176,96 @@ def _farm_worker(wid, W, pmax, n, m, names, conn):
         pass
     shms = []
     arrs = {}
-    for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
-                                 S=((pmax,), np.int8), C=((4,), np.int64), D=((256,), np.int64)).items():
+    for key, (shape, dt) in dict(X=((slots, pmax, n), np.float64), F=((slots, pmax), np.float64),
+                                 G=((slots, pmax, n), np.float64), S=((slots, pmax), np.int8),
+                                 C=((slots, 4), np.int64), D=((slots, 256), np.int64)).items():
         shm, a = _attach(names[key], shape, dt)
         shms.append(shm)
         arrs[key] = a
     X, Fs, G, S, C, D = arrs["X"], arrs["F"], arrs["G"], arrs["S"], arrs["C"], arrs["D"]
-    setulb = _lbfgsb.setulb
-    while True:
-        msg = conn.recv()
-        if msg[0] == "quit":
-            break
-        _, P, bounds, ftol, gtol, maxiter, maxfun, maxls = msg
-        factr = ftol / np.finfo(float).eps
-        low, up, nbd = _bound_arrays(bounds)
-        mine = list(range(wid, P, W))  # interleaved: the 13 restarts of one edge spread over the workers
-        cnt = len(mine)
-        WA = np.zeros((cnt, 2 * m * n + 5 * n + 11 * m * m + 8 * m))
-        IWA = np.zeros((cnt, 3 * n), dtype=np.int32)
-        TASK = np.zeros((cnt, 2), dtype=np.int32)
-        LNT = np.zeros((cnt, 2), dtype=np.int32)
-        LSAVE = np.zeros((cnt, 4), dtype=np.int32)
-        ISAVE = np.zeros((cnt, 44), dtype=np.int32)
-        DSAVE = np.zeros((cnt, 29))
-        rows = {i: (X[i], G[i], WA[k], IWA[k], TASK[k], LSAVE[k], ISAVE[k], DSAVE[k], LNT[k])
-                for k, i in enumerate(mine)}
-        n_iter = dict.fromkeys(mine, 0)
-        nfev = dict.fromkeys(mine, 0)
-        first = True
-        active = list(mine)
-        rnd = int(C[1])  # the parent's release counter at the start of this job
-        while True:
-            pending = []
-            for i in active:
-                x, g, wa, iwa, task, lsave, isave, dsave, lnt = rows[i]
-                f = 0.0 if first else float(Fs[i])
-                while True:
-                    setulb(m, x, low, up, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, lnt)
-                    t0 = task[0]
-                    if t0 == 3:
-                        pending.append(i)
-                        break
-                    if t0 == 1:
-                        n_iter[i] += 1
-                        if n_iter[i] >= maxiter:
-                            task[0], task[1] = 5, 504
-                        elif nfev[i] > maxfun:
-                            task[0], task[1] = 5, 502
-                        continue
-                    S[i] = 2
-                    break
-            for i in pending:
-                S[i] = 1
-                nfev[i] += 1
-            first = False
-            rnd += 1
-            D[wid] = rnd               # parent may now collect the pending points
-            _spin_until(C, 1, rnd)     # parent has written F / G (or decided to stop)
-            if C[0] == 0:
+    jobs = {}
+    quit_ = False
+    while not quit_:
+        # new jobs: block when idle, poll when busy
+        while (not jobs) or conn.poll(0):
+            msg = conn.recv()
+            if msg[0] == "quit":
+                quit_ = True
                 break
-            active = pending
+            _, slot, P, bounds, ftol, gtol, maxiter, maxfun, maxls = msg
+            factr = ftol / np.finfo(float).eps
+            low, up, nbd = _bound_arrays(bounds)
+            mine = list(range(wid, P, W))  # interleaved: the 13 restarts of one edge spread over the workers
+            cnt = len(mine)
+            WA = np.zeros((cnt, 2 * m * n + 5 * n + 11 * m * m + 8 * m))
+            IWA = np.zeros((cnt, 3 * n), dtype=np.int32)
+            TASK = np.zeros((cnt, 2), dtype=np.int32)
+            LNT = np.zeros((cnt, 2), dtype=np.int32)
+            LSAVE = np.zeros((cnt, 4), dtype=np.int32)
+            ISAVE = np.zeros((cnt, 44), dtype=np.int32)
+            DSAVE = np.zeros((cnt, 29))
+            Xs, Gs = X[slot], G[slot]
+            job = dict(consts=(m, low, up, nbd, factr, gtol, maxiter, maxfun, maxls),
+                       rows={i: (Xs[i], Gs[i], WA[k], IWA[k], TASK[k], LSAVE[k], ISAVE[k], DSAVE[k], LNT[k])
+                             for k, i in enumerate(mine)},
+                       n_iter=dict.fromkeys(mine, 0), nfev=dict.fromkeys(mine, 0), first=True, active=list(mine),
+                       rnd=int(C[slot, 1]))  # the parent's release counter at the start of this job
+            _advance(job, Xs, Fs[slot], Gs, S[slot], wid)
+            job["rnd"] += 1
+            D[slot, wid] = job["rnd"]  # parent may now collect the pending points
+            jobs[slot] = job
+        if quit_:
+            break
+        progressed = False
+        for slot in list(jobs):
+            job = jobs[slot]
+            if C[slot, 1] != job["rnd"]:
+                continue  # parent has not yet written F / G for this round
+            progressed = True
+            if C[slot, 0] == 0:
+                del jobs[slot]
+                continue
+            _advance(job, X[slot], Fs[slot], G[slot], S[slot], wid)
+            job["rnd"] += 1
+            D[slot, wid] = job["rnd"]
+        if not progressed:
+            os.sched_yield()
     for shm in shms:
         shm.close()
 
 
-class LockstepFarm:
-    """W worker processes advancing L-BFGS-B problems in lock step (see minimize_many).
-    Create it BEFORE the process initialises HIP: the fork server is exec'ed here."""
+class _FarmSlot:
+    """One job lane of a LockstepFarm (use one per concurrently running parent thread)."""
 
-    def __init__(self, workers, pmax=16384, n=3, m=10):
+    def __init__(self, farm, slot):
+        self.farm, self.slot = farm, slot
+        self.stats = {}
+
+    def minimize(self, eval_batch, x0s, bounds, **kw):
+        out = self.farm.minimize(eval_batch, x0s, bounds, slot=self.slot, **kw)
+        self.stats = self.farm.stats_of[self.slot]
+        return out
+
+
+class LockstepFarm:
+    """W worker processes advancing L-BFGS-B problems in lock step (see minimize_many), shared by up to
+    `slots` concurrent jobs.  Create it BEFORE the process initialises HIP: the fork server is exec'ed here."""
+
+    def __init__(self, workers, pmax=16384, n=3, m=10, slots=1):
         import multiprocessing as mp
-        import os
+        import threading
         from multiprocessing import shared_memory
-        self.W, self.pmax, self.n, self.m = int(workers), int(pmax), n, m
+        self.W, self.pmax, self.n, self.m, self.slots = int(workers), int(pmax), n, m, int(slots)
+        if self.W > 256:
+            raise ValueError("at most 256 workers")
         self._shms = {}
         self._arr = {}
-        for key, (shape, dt) in dict(X=((pmax, n), np.float64), F=((pmax,), np.float64), G=((pmax, n), np.float64),
-                                     S=((pmax,), np.int8), C=((4,), np.int64), D=((256,), np.int64)).items():
+        self._send_lock = threading.Lock()
+        self.stats_of = [dict() for _ in range(self.slots)]
+        self.stats = self.stats_of[0]
+        for key, (shape, dt) in dict(X=((self.slots, pmax, n), np.float64), F=((self.slots, pmax), np.float64),
+                                     G=((self.slots, pmax, n), np.float64), S=((self.slots, pmax), np.int8),
+                                     C=((self.slots, 4), np.int64), D=((self.slots, 256), np.int64)).items():
             shm = shared_memory.SharedMemory(create=True, size=int(np.prod(shape)) * np.dtype(dt).itemsize)
             self._shms[key] = shm
             self._arr[key] = np.ndarray(shape, dtype=dt, buffer=shm.buf)
@@ -233,7 +280,7 @@ class LockstepFarm:
             self._conns, self._procs = [], []
             for w in range(self.W):
                 a, b = ctx.Pipe()
-                p = ctx.Process(target=_farm_worker, args=(w, self.W, self.pmax, n, m, names, b),
+                p = ctx.Process(target=_farm_worker, args=(w, self.W, self.slots, self.pmax, n, m, names, b),
                                 daemon=True)
                 p.start()
                 self._conns.append(a)
@@ -245,23 +292,31 @@ class LockstepFarm:
                 else:
                     os.environ[k] = v
 
+    def slot(self, i):
+        if not 0 <= i < self.slots:
+            raise ValueError("no such slot")
+        return _FarmSlot(self, i)
+
     def minimize(self, eval_batch, x0s, bounds, ftol=2.2204460492503131e-09, gtol=1e-5, maxiter=15000,
-                 maxfun=15000, maxls=20):
+                 maxfun=15000, maxls=20, slot=0):
+        import time
         bounds = np.asarray(bounds, dtype=np.float64)
         P = len(x0s)
         if P > self.pmax:
             raise ValueError("too many problems for this farm")
-        X, F, G, S, C, D = (self._arr[k] for k in "XFGSCD")
+        X, F, G, S, C, D = (self._arr[k][slot] for k in "XFGSCD")
         X[:P] = np.clip(np.asarray(x0s, dtype=np.float64).reshape(P, self.n), bounds[:, 0], bounds[:, 1])
         S[:P] = 0
         C[0] = 1
         rnd = int(C[1])
         D[:self.W] = rnd
-        for c in self._conns:
-            c.send(("go", P, bounds, ftol, gtol, maxiter, maxfun, maxls))
+        with self._send_lock:
+            for c in self._conns:
+                c.send(("go", slot, P, bounds, ftol, gtol, maxiter, maxfun, maxls))
         rounds = 0
-        import time
-        st = self.stats = dict(wait_workers=0.0, eval=0.0, wait_release=0.0, host=0.0)
+        st = self.stats_of[slot] = dict(wait_workers=0.0, eval=0.0, wait_release=0.0, host=0.0)
+        if slot == 0:
+            self.stats = st
         while True:
             t0 = time.perf_counter()
             rnd += 1
@@ -290,11 +345,12 @@ class LockstepFarm:
         return X[:P].copy(), F[:P].copy(), rounds
 
     def close(self):
-        for c in self._conns:
-            try:
-                c.send(("quit",))
-            except Exception:
-                pass
+        with self._send_lock:
+            for c in self._conns:
+                try:
+                    c.send(("quit",))
+                except Exception:
+                    pass
         for p in self._procs:
             p.join(timeout=2)
             if p.is_alive():

@@ -104,3 +104,40 @@ def test_host_final_fit_matches_oracle(golden):
     np.testing.assert_allclose(mean, mo, rtol=1e-9)
     np.testing.assert_allclose(theta, g["ref_final_theta"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-6, atol=1e-6)
+
+
+def _quartic_problems(seed, P):
+    r = np.random.default_rng(seed)
+    A, c, x0 = r.uniform(0.5, 5, (P, 3)), r.uniform(-2, 2, (P, 3)), r.uniform(-3, 3, (P, 3))
+
+    def ev(idx, X):
+        d = X - c[idx]
+        return np.sum(A[idx] * d ** 4 + d * d, axis=1), 4 * A[idx] * d ** 3 + 2 * d
+    return list(x0), ev
+
+
+def test_lockstep_farm_two_concurrent_jobs_equal_the_in_process_driver():
+    """Worker processes shared by two job slots (as the pipelined bench uses them): each job follows exactly the
+    iterates of the in-process lock-step driver (= scipy.optimize.minimize, previous test), also when a slot is reused."""
+    import threading
+    from gaussian_process_edge_trace_amd._lbfgsb_lockstep import LockstepFarm, minimize_many
+    bounds = np.array([[-3.0, 3.0]] * 3)
+    farm = LockstepFarm(3, slots=2)
+    try:
+        res = {}
+
+        def run(slot, seed, P):
+            x0, ev = _quartic_problems(seed, P)
+            res[slot] = farm.slot(slot).minimize(ev, x0, bounds)
+        ts = [threading.Thread(target=run, args=(0, 1, 40)), threading.Thread(target=run, args=(1, 2, 55))]
+        [t.start() for t in ts]
+        [t.join(timeout=60) for t in ts]
+        assert not any(t.is_alive() for t in ts)
+        run(0, 3, 20)  # slot reuse
+        for slot, (seed, P) in {1: (2, 55), 0: (3, 20)}.items():
+            x0, ev = _quartic_problems(seed, P)
+            Xr, Fr, _ = minimize_many(ev, x0, bounds)
+            X, F, rounds = res[slot]
+            assert rounds > 3 and np.array_equal(X, Xr) and np.array_equal(F, Fr)
+    finally:
+        farm.close()
