@@ -2329,7 +2329,6 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
   const int nb = (n + 1 + 3) >> 2;  // 4x4 tiles per side of the bordered matrix
   const int ntile = nb * (nb + 1) / 2;
   __shared__ __attribute__((aligned(16))) double s_col[2][LML_MAXD];
-  __shared__ double s_inv[2];
   __shared__ double s_x[LML_MAXD], s_y[LML_MAXD], s_w[LML_MAXD];  // x / l, y, noise weights at index 1..n
   __shared__ double s_piv[LML_MAXD];
   __shared__ double s_red[16];
@@ -2382,10 +2381,7 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
         if (tj == kb) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) s_col[buf][4 * ti + a] = T[a][kk];
-          if (ti == kb) {
-            s_inv[buf] = 1.0 / T[kk][kk];
-            s_piv[k] = T[kk][kk];
-          }
+          if (ti == kb) s_piv[k] = T[kk][kk];
         } else if (ti == kb) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) s_col[buf][4 * tj + b] = T[kk][b];
@@ -2399,7 +2395,11 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
         break;
       }
       if (active) {
-        const double inv = s_inv[buf];
+        // 1 / d by every thread from the hardware reciprocal + two Newton steps: keeps the division off the
+        // critical path in front of the barrier (the pivot owner would otherwise hold everyone up)
+        double inv = __builtin_amdgcn_rcp(d);
+        inv = inv * (2.0 - d * inv);
+        inv = inv * (2.0 - d * inv);
         double ci[4], cj[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
