@@ -244,51 +244,104 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
   }
   __syncthreads();
 
-  // 4. left-looking Cholesky, in place
+  // 4. Cholesky, in place.  K in LDS: right-looking -- per step the pivot column is scaled, then every trailing
+  //    entry takes its rank-1 update independently (flat loop over the lower triangle of the trailing block):
+  //    two barriers and no serial dot products per step.  K in HBM (n > 128): left-looking (read-mostly).
   bool bad = false;
-  for (int j = 0; j < n; ++j) {
-    const double* rj = K + (size_t)j * ld;
-    for (int i = j + tid; i < n; i += bs) {
-      const double* ri = K + (size_t)i * ld;
-      double s = ri[j];
-      for (int t = 0; t < j; ++t) s -= ri[t] * rj[t];
-      if (i == j) s_diag = s; else K[(size_t)i * ld + j] = s;
+  if (K_IN_LDS) {
+    for (int k = 0; k < n; ++k) {
+      const double d = K[(size_t)k * ld + k];
+      if (!(d > 0.0)) {  // (same value for every thread: read before anyone rewrites it)
+        bad = true;
+        break;
+      }
+      const double dk = sqrt(d);
+      __syncthreads();
+      for (int i = k + tid; i < n; i += bs) K[(size_t)i * ld + k] = (i == k) ? dk : K[(size_t)i * ld + k] / dk;
+      __syncthreads();
+      const int m = n - k - 1;
+      // trailing entry e of the packed lower triangle of the m x m block: row ii = floor((sqrt(8e+1)-1)/2)
+      for (int e = tid; e < m * (m + 1) / 2; e += bs) {
+        int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while (ii * (ii + 1) / 2 > e) --ii;
+        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+        const int jj = e - ii * (ii + 1) / 2;
+        const int i = k + 1 + ii, j = k + 1 + jj;
+        K[(size_t)i * ld + j] -= K[(size_t)i * ld + k] * K[(size_t)j * ld + k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    const double d = s_diag;
-    if (!(d > 0.0)) {
-      bad = true;
-      break;
+  } else {
+    for (int j = 0; j < n; ++j) {
+      const double* rj = K + (size_t)j * ld;
+      for (int i = j + tid; i < n; i += bs) {
+        const double* ri = K + (size_t)i * ld;
+        double s = ri[j];
+        for (int t = 0; t < j; ++t) s -= ri[t] * rj[t];
+        if (i == j) s_diag = s; else K[(size_t)i * ld + j] = s;
+      }
+      __syncthreads();
+      const double d = s_diag;
+      if (!(d > 0.0)) {
+        bad = true;
+        break;
+      }
+      const double dj = sqrt(d);
+      for (int i = j + tid; i < n; i += bs) {
+        if (i == j) K[(size_t)i * ld + j] = dj; else K[(size_t)i * ld + j] = K[(size_t)i * ld + j] / dj;
+      }
+      __syncthreads();
     }
-    const double dj = sqrt(d);
-    for (int i = j + tid; i < n; i += bs) {
-      if (i == j) K[(size_t)i * ld + j] = dj; else K[(size_t)i * ld + j] = K[(size_t)i * ld + j] / dj;
-    }
-    __syncthreads();
   }
   if (bad) {
     if (tid == 0) sc->status = GPET_ERR_NOT_PD;
     return;
   }
 
-  // 5. alpha = L^-T L^-1 y   (single wave, no barriers; z lives in LDS)
+  // 5. alpha = L^-T L^-1 y by one wave in column (axpy) form: the solution vector lives in registers
+  //    (rows lane, lane + 64), each step broadcasts one solved component -- no reductions, no barriers
   if (tid < WAVE) {
-    double* z = s_dyn;
     const int lane = tid;
-    for (int j = 0; j < n; ++j) {
-      const double* rj = K + (size_t)j * ld;
-      double p = 0.0;
-      for (int t = lane; t < j; t += WAVE) p += rj[t] * z[t];
-      p = wave_sum(p);
-      if (lane == 0) z[j] = (E.yt[j] - p) / rj[j];
+    double z0 = (lane < n) ? E.yt[lane] : 0.0, z1 = (lane + WAVE < n) ? E.yt[lane + WAVE] : 0.0;
+    // (n <= 2 * WAVE on this path: n_cap <= 128 whenever K fits LDS; larger n takes the generic loop below)
+    if (n <= 2 * WAVE) {
+      for (int j = 0; j < n; ++j) {  // forward: z_j = y_j / l_jj, then y_i -= l_ij z_j for i > j
+        const double ljj = K[(size_t)j * ld + j];
+        const double zj = __shfl((j < WAVE) ? z0 : z1, j & (WAVE - 1), WAVE) / ljj;
+        if (lane == (j & (WAVE - 1))) {
+          if (j < WAVE) z0 = zj; else z1 = zj;
+        }
+        if (lane > j && lane < n) z0 -= K[(size_t)lane * ld + j] * zj;
+        if (lane + WAVE > j && lane + WAVE < n) z1 -= K[(size_t)(lane + WAVE) * ld + j] * zj;
+      }
+      for (int j = n - 1; j >= 0; --j) {  // backward: a_j = z_j / l_jj, then z_i -= l_ji a_j for i < j
+        const double* rj = K + (size_t)j * ld;
+        const double aj = __shfl((j < WAVE) ? z0 : z1, j & (WAVE - 1), WAVE) / rj[j];
+        if (lane == (j & (WAVE - 1))) {
+          if (j < WAVE) z0 = aj; else z1 = aj;
+        }
+        if (lane < j) z0 -= rj[lane] * aj;
+        if (lane + WAVE < j) z1 -= rj[lane + WAVE] * aj;
+      }
+      if (lane < n) E.alpha[lane] = z0;
+      if (lane + WAVE < n) E.alpha[lane + WAVE] = z1;
+    } else {
+      double* z = s_dyn;
+      for (int j = 0; j < n; ++j) {
+        const double* rj = K + (size_t)j * ld;
+        double p = 0.0;
+        for (int t = lane; t < j; t += WAVE) p += rj[t] * z[t];
+        p = wave_sum(p);
+        if (lane == 0) z[j] = (E.yt[j] - p) / rj[j];
+      }
+      for (int j = n - 1; j >= 0; --j) {
+        double p = 0.0;
+        for (int t = j + 1 + lane; t < n; t += WAVE) p += K[(size_t)t * ld + j] * z[t];
+        p = wave_sum(p);
+        if (lane == 0) z[j] = (z[j] - p) / K[(size_t)j * ld + j];
+      }
+      for (int i = lane; i < n; i += WAVE) E.alpha[i] = z[i];
     }
-    for (int j = n - 1; j >= 0; --j) {
-      double p = 0.0;
-      for (int t = j + 1 + lane; t < n; t += WAVE) p += K[(size_t)t * ld + j] * z[t];
-      p = wave_sum(p);
-      if (lane == 0) z[j] = (z[j] - p) / K[(size_t)j * ld + j];
-    }
-    for (int i = lane; i < n; i += WAVE) E.alpha[i] = z[i];
   }
   if (K_IN_LDS) {  // publish the factor for k_predict / readers (row stride n_cap in HBM)
     for (int idx = tid; idx < n * n; idx += bs) {
