@@ -823,7 +823,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 120: case 121: case 122: case 123:  // structured path: fit, (U, H, mean), Jacobi, factor rows
         HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
       case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring)); break;
-      case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1)); break;  // (the loop form: raw, band only)
       case 6: HIPCHK(c, launch_pixels_reset(c->stream, b->d_edges, b->B, b->bd)); break;  // (reset only: selection mutates the loop state)
@@ -832,7 +832,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1, 1u << (stage - 100))); break;
       case 110: case 111: case 112: case 113:
         HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 110))); break;
-      case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd)); break;
+      case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
       case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
       case 150: case 151: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150), 1)); break;
       case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 4u, 0)); break;  // (stage-API form only)
@@ -1018,7 +1018,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
-    HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd));
+    HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0));
     HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
     HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
     // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly

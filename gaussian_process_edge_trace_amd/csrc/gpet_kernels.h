@@ -27,7 +27,7 @@ hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
-hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int rank_max = 0);
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
 
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,

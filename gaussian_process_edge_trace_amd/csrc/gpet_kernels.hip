@@ -1457,19 +1457,26 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
   }
 }
 
-__global__ void __launch_bounds__(512) k_sample_gemm_mfma_r(EdgeDev* edges) {
+// One kernel per K extent (the launcher picks it from the batch's largest possible rank; an edge of smaller
+// rank multiplies a few zero rows): register allocation is per kernel, and the variants up to K = 72 fit the
+// 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
+template <int KS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if ((int)blockIdx.x * 128 >= E.S) return;
-  extern __shared__ double s_fa[];  // [GEMM_KMAX][65]
-  const int ks = (sc->rank + 3) >> 2;  // uniform over the workgroup
-  if (ks <= 8) sample_gemm_body<8>(E, sc, s_fa);
-  else if (ks <= 12) sample_gemm_body<12>(E, sc, s_fa);
-  else if (ks <= 16) sample_gemm_body<16>(E, sc, s_fa);
-  else if (ks <= 18) sample_gemm_body<18>(E, sc, s_fa);
-  else if (ks <= 20) sample_gemm_body<20>(E, sc, s_fa);
-  else sample_gemm_body<24>(E, sc, s_fa);
+  extern __shared__ double s_fa[];  // [4 KS][65]
+  sample_gemm_body<KS>(E, sc, s_fa);
+}
+template <int KS>
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  // (K > 72: one workgroup per CU)
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  if ((int)blockIdx.x * 128 >= E.S) return;
+  extern __shared__ double s_fa[];
+  sample_gemm_body<KS>(E, sc, s_fa);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -2793,13 +2800,23 @@ hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   return hipGetLastError();
 }
 
-hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int rank_max) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   // rank <= 96 everywhere in the batch (factor capacity): Z rows stay in registers; otherwise
-  // (full factors injected by tests, Matern ranks) the K-chunked kernel
+  // (full factors injected by tests, Matern ranks) the K-chunked kernel.  rank_max: the largest rank any
+  // edge can have in this launch (r0_max inside the structured loop, else the factor capacity).
   if (bd.r_cap <= GEMM_KMAX && bd.a_rows_cap <= GEMM_KMAX) {
-    hipLaunchKernelGGL(k_sample_gemm_mfma_r, dim3(cdiv(bd.S, 128), B), dim3(512),
-                       (size_t)GEMM_KMAX * 65 * sizeof(double), st, d_edges);
+    const int rm = rank_max > 0 && rank_max <= bd.r_cap ? rank_max : (bd.r_cap > bd.a_rows_cap ? bd.r_cap : bd.a_rows_cap);
+    const int ks = (rm + 3) >> 2;
+    const dim3 grid(cdiv(bd.S, 128), B), block(512);
+#define GPET_GEMM_LAUNCH(KERNEL, KS_) hipLaunchKernelGGL((KERNEL<KS_>), grid, block, (size_t)4 * KS_ * 65 * sizeof(double), st, d_edges)
+    if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
+    else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
+    else if (ks <= 16) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 16);
+    else if (ks <= 18) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 18);
+    else if (ks <= 20) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_rl, 20);
+    else GPET_GEMM_LAUNCH(k_sample_gemm_mfma_rl, 24);
+#undef GPET_GEMM_LAUNCH
   } else {
     hipLaunchKernelGGL(k_sample_gemm_mfma, dim3(cdiv(bd.Lg, 64), cdiv(bd.S, 64), B), dim3(256), 0, st, d_edges);
   }
