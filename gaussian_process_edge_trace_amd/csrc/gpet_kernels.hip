@@ -1756,18 +1756,22 @@ __global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  __shared__ double s_c[1024];
+  __shared__ __attribute__((aligned(16))) double s_c[1024];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double ci = (i < E.S) ? E.costs[i] : 0.0;
   int rank = 0;
   for (int j0 = 0; j0 < E.S; j0 += 1024) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += blockDim.x) s_c[e] = (j0 + e < E.S) ? E.costs[j0 + e] : 0.0;
+    // (entries beyond S are +inf: they never rank before a finite cost, and a tie on +inf needs a smaller index)
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) s_c[e] = (j0 + e < E.S) ? E.costs[j0 + e] : INFINITY;
     __syncthreads();
     const int lim = (E.S - j0) < 1024 ? (E.S - j0) : 1024;
-    for (int e = 0; e < lim; ++e) {
-      const double cj = s_c[e];
-      rank += (cj < ci) || (cj == ci && (j0 + e) < i);
+    const int lim2 = (lim + 1) & ~1;  // two costs per (broadcast) LDS read
+#pragma unroll 4
+    for (int e = 0; e < lim2; e += 2) {
+      const double2 cj = *reinterpret_cast<const double2*>(&s_c[e]);
+      rank += (cj.x < ci) || (cj.x == ci && (j0 + e) < i);
+      rank += (cj.y < ci) || (cj.y == ci && (j0 + e + 1) < i && (j0 + e + 1) < E.S);
     }
   }
   if (i < E.S && rank < E.n_keep) {
@@ -1903,7 +1907,7 @@ __global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode)
 // ---- fused curve KDE (per-iteration path) ----------------------------------------------
 // k_kde_prep: total kept weight W (KDEpy normalises the weights by their sum), points removed
 // for lying outside the image (gpet.py:498-500), and the per-iteration resets.
-__global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
+__global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -1924,14 +1928,15 @@ __global__ void __launch_bounds__(256) k_kde_prep(EdgeDev* edges) {
   const double inv_sum = s_inv, ymax = (double)(E.M - 1);
   double wsum = 0.0;
   int removed = 0;
-  // all (curve, column) points in parallel: independent coalesced loads, no serial chain
-  for (int b = 0; b < E.n_keep; ++b) {
-    const double* __restrict__ row = E.Y + (size_t)E.best_idx[b] * E.Lg;
+  // all (curve, column) points as one flat index space: every load is independent of the previous one, so
+  // many are in flight per thread (per-thread sums in a fixed order -> deterministic block sum)
+  const int total = E.n_keep * E.Lg;
+#pragma unroll 4
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int b = e / E.Lg, k = e - b * E.Lg;
+    const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
     const double wb = (1.0 / E.best_costs[b]) / inv_sum;
-    for (int k = threadIdx.x; k < E.Lg; k += blockDim.x) {
-      const double y = row[k];
-      if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
-    }
+    if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
   }
   wsum = block_sum(wsum, s_red);
   const double rem = block_sum((double)removed, s_red);
@@ -2734,7 +2739,7 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
   if (mode == 0) {
     // per-iteration path: one prep kernel + one fused bin/convolve kernel + normalise
     const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
-    if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(256), 0, st, d_edges);
+    if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(1024), 0, st, d_edges);
     if (parts & 2u)
       hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band);
     if ((parts & 4u) && !raw_band) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
