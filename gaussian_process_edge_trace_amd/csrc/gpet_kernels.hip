@@ -876,16 +876,20 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
   extern __shared__ double s_dyn[];
   const int n = sc->n, r0 = E.r0, Lg = E.Lg, ldk = E.n_cap, ldc = E.r_cap;
   const int ldu = r0 | 1;
-  double* U = s_dyn;                        // [n_cap][ldu]
-  double* s_l = U + (size_t)E.n_cap * ldu;  // [n_cap] current row of L
-  double* s_b = s_l + E.n_cap;              // [r_cap] beta
+  double* U = s_dyn;                                            // [n_cap][ldu]
+  double* Lp = U + (size_t)E.n_cap * ldu;                       // packed lower triangle of L: row i at i (i + 1) / 2
+  double* s_b = Lp + (size_t)E.n_cap * (E.n_cap + 1) / 2;       // [r_cap] beta
   const int tid = threadIdx.x, bs = blockDim.x;
   const double c = sc->amp;
-  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i]
+  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once
   for (int e = tid; e < n * r0; e += bs) {
     const int i = e / r0, a = e - i * r0;
     const int idx = (int)E.xt[i] - E.x_st;
     U[i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
+  }
+  for (int e = tid; e < n * n; e += bs) {
+    const int i = e / n, t = e - i * n;
+    if (t <= i) Lp[i * (i + 1) / 2 + t] = E.K[(size_t)i * ldk + t];
   }
   __syncthreads();
   // beta_a = sum_i Bo[i][a] alpha_i
@@ -895,16 +899,13 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
     s_b[a] = acc;
     E.beta[a] = acc;
   }
-  // U = L^-1 Bo  (forward substitution, thread a owns column a)
-  for (int i = 0; i < n; ++i) {
-    __syncthreads();
-    const double* ri = E.K + (size_t)i * ldk;
-    for (int t = tid; t <= i; t += bs) s_l[t] = ri[t];
-    __syncthreads();
-    if (tid < r0) {
+  // U = L^-1 Bo: thread a owns column a entirely (its own entries of U, read-only L) -- no barriers inside
+  if (tid < r0) {
+    for (int i = 0; i < n; ++i) {
+      const double* li = Lp + i * (i + 1) / 2;
       double acc = U[i * ldu + tid];
-      for (int t = 0; t < i; ++t) acc -= s_l[t] * U[t * ldu + tid];
-      U[i * ldu + tid] = acc / s_l[i];
+      for (int t = 0; t < i; ++t) acc -= li[t] * U[t * ldu + tid];
+      U[i * ldu + tid] = acc / li[i];
     }
   }
   __syncthreads();
@@ -2692,7 +2693,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   if (parts & 2u) {
-    const size_t lds = ((size_t)bd.n_cap * (bd.r0_max | 1) + bd.n_cap + bd.r_cap) * sizeof(double);
+    const size_t lds = ((size_t)bd.n_cap * (bd.r0_max | 1) + (size_t)bd.n_cap * (bd.n_cap + 1) / 2 + bd.r_cap) * sizeof(double);
     hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), lds, st, d_edges);
   }
   if (parts & 4u) {
