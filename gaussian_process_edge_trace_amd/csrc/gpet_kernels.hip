@@ -675,7 +675,7 @@ __device__ __forceinline__ void rr_pair(int m1, int round, int k, int& p, int& q
   q = x < y ? y : x;
 }
 
-__global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
+__global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_out) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
@@ -819,12 +819,15 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges) {
     s_pos[k] = pos;
   }
   __syncthreads();
-  // C (consumed above) <- eigenvectors in descending eigenvalue order, scaled by y_std sqrt(theta): column pos of
-  // row t is the coefficient of basis vector t in factor row pos (what k_struct_rows multiplies with Q0)
-  for (int e = tid; e < r * r; e += bs) {
-    const int i = e / r, j = e - i * r;
-    const double th = A[j * ld + j];
-    E.C[(size_t)i * ldg + s_pos[j]] = W[i * ld + j] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+  // structured path (scaled_out): G (unused there) <- eigenvectors in descending eigenvalue order, scaled by
+  // y_std sqrt(theta): column pos of row t is the coefficient of basis vector t in factor row pos -- what
+  // k_struct_rows multiplies with Q0.  (C stays intact: repeated launches see the same matrix.)
+  if (scaled_out) {
+    for (int e = tid; e < r * r; e += bs) {
+      const int i = e / r, j = e - i * r;
+      const double th = A[j * ld + j];
+      E.G[(size_t)i * ldg + s_pos[j]] = W[i * ld + j] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+    }
   }
   if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
 }
@@ -944,7 +947,7 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w) 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int j = j0 + 16 * w + li;
-  // B operand (Q0[t][j], this wave's 16 columns) straight into registers; A operand (E.C, written by the Jacobi
+  // B operand (Q0[t][j], this wave's 16 columns) straight into registers; A operand (E.G, written by the Jacobi
   // kernel) through LDS, shared by the four waves
   double breg[KS];
 #pragma unroll
@@ -955,7 +958,7 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w) 
 #pragma unroll 4
   for (int e = tid; e < kpad * 16 * MT; e += 256) {
     const int t = e / (16 * MT), k = e - t * (16 * MT);
-    s_w[t * ldw + k] = (t < r && k < r) ? E.C[(size_t)t * E.r_cap + k] : 0.0;
+    s_w[t * ldw + k] = (t < r && k < r) ? E.G[(size_t)t * E.r_cap + k] : 0.0;
   }
   __syncthreads();
   v4f64_ acc[MT];
@@ -2671,7 +2674,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges, 0);
   }
   if (parts & 8u)
     hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
@@ -2698,7 +2701,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   }
   if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), (size_t)2 * mm * (mm | 1) * sizeof(double), st, d_edges);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), (size_t)2 * mm * (mm | 1) * sizeof(double), st, d_edges, 1);
   }
   if (parts & 8u) {
     // the variant k_struct_rows picks for r0_max: [4 KS][16 MT + 1] eigenvector tile, reused as [r][64] products
