@@ -314,7 +314,7 @@ def main():
 
     log("stage profile done; dominant stage %s %.3f ms" % (dom, d_ms))
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # (reported at N=1 only)
         cpu = cpu_baseline(N, 3, args.cpu_traces)
 
     out = {
