@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
   if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
   extern __shared__ double s_mem[];
   __shared__ double s_red[16];
-  __shared__ double s_c[64], s_s[64];
+  __shared__ __attribute__((aligned(16))) double2 s_cs[64];  // (c, s) of the round: one 16-byte read per pair
   __shared__ int s_pos[96];
   const int r = sc->rank, ldg = E.r_cap;
   const int m = (r + 1) & ~1;
@@ -753,17 +753,16 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
             c = c * (1.5 - 0.5 * u * c * c);
             s = t * c;
           }
-          s_c[tid] = c;
-          s_s[tid] = s;
+          s_cs[tid] = make_double2(c, s);
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int a_ = ba[u], b_ = bb[u];
           if (a_ < 0) continue;
-          const double sa = s_s[a_], sb = s_s[b_];
+          const double2 ra = s_cs[a_], rb = s_cs[b_];
+          const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
           if (sa == 0.0 && sb == 0.0) continue;
-          const double ca = s_c[a_], cb = s_c[b_];
           int pa, qa, pb, qb;
           rr_pair(m1, round, a_, pa, qa);
           rr_pair(m1, round, b_, pb, qb);
@@ -786,9 +785,9 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
         }
         // W: column rotations only
         if (w_on) {
-          const double sb = s_s[wb];
+          const double2 rb = s_cs[wb];
+          const double cb = rb.x, sb = rb.y;
           if (sb != 0.0) {
-            const double cb = s_c[wb];
             int pb, qb;
             rr_pair(m1, round, wb, pb, qb);
             for (int i = wseg; i < r; i += nseg) {
