@@ -1,0 +1,97 @@
+"""Edge cases of the hot path on the device, each against the oracle run on the same inputs (the oracle is pinned
+by the reference-generated fixtures in test_oracle_vs_golden.py): constructor quirks, degenerate inputs, batching."""
+import numpy as np
+import pytest
+
+from oracle import gpet_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gaussian_process_edge_trace_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def ctx(amd):
+    return amd._lib.Context(0)
+
+
+def _image(N, seed, M=None):
+    img, truth = orc.synth_sinusoid_image(N, seed)
+    grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+    return grad, truth
+
+
+CASES = {
+    # both endpoints float (weights 0.5), Matern nu=1.5 preset, threshold below 1
+    "free_endpoints_matern15": dict(kernel_options=(2, 2, 2), noise_y=0.7, N_samples=150, score_thresh=0.8, delta_x=6,
+                                    keep_ratio=0.2, pixel_thresh=3, seed=5, fix_endpoints=False),
+    # Matern nu=0.5 through the dict form, even/odd mixes of delta_x and pixel_thresh
+    "matern05_dict": dict(kernel_options={'kernel': 'Matern', 'nu': 0.5, 'sigma_f': 12, 'length_scale': 20}, noise_y=1,
+                          N_samples=128, score_thresh=1, delta_x=4, keep_ratio=0.1, pixel_thresh=2, seed=11,
+                          fix_endpoints=True),
+    # clamped constructor arguments (Q5): N_samples <= 100 -> 1000 draws but N_keep from the raw value,
+    # delta_x <= 3 -> 2, pixel_thresh < 2 -> 2, keep_ratio / score_thresh out of range -> 0.1 / 1
+    "clamped_arguments": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 10}, noise_y=1,
+                              N_samples=80, score_thresh=3.0, delta_x=3, keep_ratio=1.5, pixel_thresh=1, seed=2,
+                              fix_endpoints=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_quirk_cases_trace_equals_oracle(amd, ctx, name):
+    kw = CASES[name]
+    grad, truth = _image(64, 4)
+    init = truth[[0, -1], :][:, [1, 0]]
+    et_o, ci_o, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    et = tr()
+    assert tr._n_iter == info["n_iter"]
+    assert np.array_equal(et, et_o)
+
+
+def test_unsorted_init_and_same_row_endpoints(amd, ctx):
+    """x_st / x_en come from the UNSORTED init argument (Q4): the reversed order gives an empty x-grid in the reference;
+    with the sorted order but both endpoints on one image row the first fit has std(y) == 0 (sklearn's scalar
+    _handle_zeros_in_scale path) -- the trace must still equal the oracle's."""
+    grad, truth = _image(64, 6)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 8, 'length_scale': 8}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=3, fix_endpoints=True)
+    init = np.array([[0, 30], [63, 30]])
+    et_o, _, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    assert np.array_equal(tr(), et_o) and tr._n_iter == info["n_iter"]
+
+
+def test_warm_start_observations_with_duplicate_columns(amd, ctx):
+    """User-supplied obs (the image-sequence warm start, gpet.py:57-61) including two observations in one image column:
+    the stable argsort and the per-point noise keep K positive definite; trace equals the oracle's."""
+    grad, truth = _image(64, 8)
+    init = truth[[0, -1], :][:, [1, 0]]
+    obs = np.array([[20, int(truth[20, 0])], [20, int(truth[20, 0]) + 2], [41, int(truth[41, 0])]])
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=9, fix_endpoints=True, obs=obs)
+    et_o, _, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    assert np.array_equal(tr(), et_o) and tr._n_iter == info["n_iter"]
+
+
+def test_batch_of_edges_equals_single_edge_runs(amd, ctx):
+    """The batched form (blockIdx = edge) must give every edge exactly what a batch of one gives it: different seeds,
+    different inits, one shared image (what the multi-GPU sharding relies on for bit-identical results)."""
+    grad, truth = _image(64, 4)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True, return_std=True)
+    base = truth[[0, -1], :][:, [1, 0]]
+    inits = [base, base + np.array([[0, 1], [0, -1]]), base + np.array([[0, -2], [0, 2]]), base]
+    seeds = [1, 2, 3, 77]
+    batch = amd.GP_Edge_Tracing_Batch(inits, grad.astype(np.float32), seeds, **kw, _ctx=ctx)
+    out = batch()
+    for e, (init, seed) in enumerate(zip(inits, seeds)):
+        single = amd.GP_Edge_Tracing(init, grad, seed=seed, **kw, _ctx=ctx)
+        et, ci = single()
+        assert np.array_equal(out[e][0], et), "edge %d" % e
+        assert np.array_equal(out[e][1][0], ci[0]) and np.array_equal(out[e][1][1], ci[1])
