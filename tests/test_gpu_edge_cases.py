@@ -95,3 +95,29 @@ def test_batch_of_edges_equals_single_edge_runs(amd, ctx):
         et, ci = single()
         assert np.array_equal(out[e][0], et), "edge %d" % e
         assert np.array_equal(out[e][1][0], ci[0]) and np.array_equal(out[e][1][1], ci[1])
+
+
+def test_error_codes_rank_cap_unsupported_nu_bad_state(amd, ctx):
+    """Error behaviour of the boundary: factor capacity exceeded -> 5; general-nu Matern
+    (needs Bessel K_nu) -> 6; stage called out of order -> 8; bad arguments -> 1.  Each leaves the context usable."""
+    L = amd._lib
+    grad, truth = _image(64, 4)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 2}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=1, fix_endpoints=True)
+    with pytest.raises(L.GpetError) as ei:  # l = 2 on 64 px: rank ~ 60 > the 8 rows allowed
+        tr = amd.GP_Edge_Tracing(init, grad, **kw, factor_cap=8, _ctx=ctx)
+        tr()
+    assert ei.value.code == L.ERR_RANK_CAP
+    with pytest.raises(L.GpetError) as ei:
+        amd.GP_Edge_Tracing(init, grad, **dict(kw, kernel_options={'kernel': 'Matern', 'nu': 0.9, 'sigma_f': 10,
+                                                                   'length_scale': 8}), _ctx=ctx)
+    assert ei.value.code == L.ERR_UNSUPPORTED
+    ok = amd.GP_Edge_Tracing(init, grad, **dict(kw, kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}),
+                             _ctx=ctx)
+    with pytest.raises(L.GpetError) as ei:  # sampling before any fit / factor
+        ok._batch.ctx.check(ok._batch.lib.gpet_gp_sample(ok._batch.h))
+    assert ei.value.code == L.ERR_STATE
+    assert ok._batch.lib.gpet_trace_iterate(ok._batch.h, None, 1, None) == L.ERR_BAD_ARG
+    et = ok()  # the context and the batch still work
+    assert et.shape == (64, 2)
