@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(256) k_struct_basis(EdgeDev* edges) {
 // H = c Lam - U^T U (into E.C, row stride r_cap), beta, posterior mean.  One workgroup per edge;
 // U (n x r0) lives in LDS, one thread per column for the forward substitution, rows of L streamed
 // through LDS.
-__global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
+__global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
@@ -879,19 +879,22 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
   const int n = sc->n, r0 = E.r0, Lg = E.Lg, ldk = E.n_cap, ldc = E.r_cap;
   const int ldu = r0 | 1;
   double* U = s_dyn;                                            // [n_cap][ldu]
-  double* Lp = U + (size_t)E.n_cap * ldu;                       // packed lower triangle of L: row i at i (i + 1) / 2
-  double* s_b = Lp + (size_t)E.n_cap * (E.n_cap + 1) / 2;       // [r_cap] beta
+  double* Lp = U + (size_t)E.n_cap * ldu;                       // l_in_lds: packed lower triangle of L (row i at i (i + 1) / 2);
+                                                                // otherwise [n_cap]: the current row of L
+  double* s_b = Lp + (l_in_lds ? (size_t)E.n_cap * (E.n_cap + 1) / 2 : (size_t)E.n_cap);  // [r_cap] beta
   const int tid = threadIdx.x, bs = blockDim.x;
   const double c = sc->amp;
-  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once
+  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once if it fits
   for (int e = tid; e < n * r0; e += bs) {
     const int i = e / r0, a = e - i * r0;
     const int idx = (int)E.xt[i] - E.x_st;
     U[i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
   }
-  for (int e = tid; e < n * n; e += bs) {
-    const int i = e / n, t = e - i * n;
-    if (t <= i) Lp[i * (i + 1) / 2 + t] = E.K[(size_t)i * ldk + t];
+  if (l_in_lds) {
+    for (int e = tid; e < n * n; e += bs) {
+      const int i = e / n, t = e - i * n;
+      if (t <= i) Lp[i * (i + 1) / 2 + t] = E.K[(size_t)i * ldk + t];
+    }
   }
   __syncthreads();
   // beta_a = sum_i Bo[i][a] alpha_i
@@ -901,13 +904,28 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges) {
     s_b[a] = acc;
     E.beta[a] = acc;
   }
-  // U = L^-1 Bo: thread a owns column a entirely (its own entries of U, read-only L) -- no barriers inside
-  if (tid < r0) {
+  if (l_in_lds) {
+    // U = L^-1 Bo: thread a owns column a entirely (its own entries of U, read-only L) -- no barriers inside
+    if (tid < r0) {
+      for (int i = 0; i < n; ++i) {
+        const double* li = Lp + i * (i + 1) / 2;
+        double acc = U[i * ldu + tid];
+        for (int t = 0; t < i; ++t) acc -= li[t] * U[t * ldu + tid];
+        U[i * ldu + tid] = acc / li[i];
+      }
+    }
+  } else {
+    // (many training points: L does not fit next to U; its rows are streamed through LDS one at a time)
     for (int i = 0; i < n; ++i) {
-      const double* li = Lp + i * (i + 1) / 2;
-      double acc = U[i * ldu + tid];
-      for (int t = 0; t < i; ++t) acc -= li[t] * U[t * ldu + tid];
-      U[i * ldu + tid] = acc / li[i];
+      __syncthreads();
+      const double* ri = E.K + (size_t)i * ldk;
+      for (int t = tid; t <= i; t += bs) Lp[t] = ri[t];
+      __syncthreads();
+      if (tid < r0) {
+        double acc = U[i * ldu + tid];
+        for (int t = 0; t < i; ++t) acc -= Lp[t] * U[t * ldu + tid];
+        U[i * ldu + tid] = acc / Lp[i];
+      }
     }
   }
   __syncthreads();
@@ -2691,12 +2709,17 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     (void)hipFuncSetAttribute((const void*)k_struct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  if (parts & 1u)
+  if (!(parts & 1u)) {
+  } else if (bd.n_cap <= 128)
     hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
+  else  // (more possible training points than K fits LDS for: the factorisation works in HBM)
+    hipLaunchKernelGGL((k_fit<false, false>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
   if (parts & 2u) {
-    const size_t lds = ((size_t)bd.n_cap * (bd.r0_max | 1) + (size_t)bd.n_cap * (bd.n_cap + 1) / 2 + bd.r_cap) * sizeof(double);
-    hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), lds, st, d_edges);
+    const size_t full = ((size_t)bd.n_cap * (bd.r0_max | 1) + (size_t)bd.n_cap * (bd.n_cap + 1) / 2 + bd.r_cap) * sizeof(double);
+    const size_t rowm = ((size_t)bd.n_cap * (bd.r0_max | 1) + bd.n_cap + bd.r_cap) * sizeof(double);
+    const int l_in_lds = full <= (size_t)STRUCT_H_LDS_MAX ? 1 : 0;  // (gpet_batch_create checked that `rowm` fits)
+    hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), l_in_lds ? full : rowm, st, d_edges, l_in_lds);
   }
   if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;

@@ -121,3 +121,18 @@ def test_error_codes_rank_cap_unsupported_nu_bad_state(amd, ctx):
     assert ok._batch.lib.gpet_trace_iterate(ok._batch.h, None, 1, None) == L.ERR_BAD_ARG
     et = ok()  # the context and the batch still work
     assert et.shape == (64, 2)
+
+
+def test_many_observations_take_the_streamed_factor_path(amd, ctx):
+    """delta_x <= 3 is clamped to 2 (Q5): up to N/2 observations.  On a 320-px edge that is 162 training points:
+    K no longer fits LDS in k_fit and L no longer fits next to U in k_struct_H (rows of L are streamed) -- the
+    structured loop must still trace exactly what the oracle traces."""
+    grad, truth = _image(320, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 12}, noise_y=1, N_samples=200,
+              score_thresh=1, delta_x=2, keep_ratio=0.1, pixel_thresh=20, seed=4, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    info = tr._batch.info()
+    assert info["structured"] == 1 and info["n_cap"] > 128
+    et_o, _, oinfo = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    assert np.array_equal(tr(), et_o) and tr._n_iter == oinfo["n_iter"]
