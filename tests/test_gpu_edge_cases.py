@@ -136,3 +136,36 @@ def test_many_observations_take_the_streamed_factor_path(amd, ctx):
     assert info["structured"] == 1 and info["n_cap"] > 128
     et_o, _, oinfo = orc.trace(init, grad, sign_convention="harmonic", **kw)
     assert np.array_equal(tr(), et_o) and tr._n_iter == oinfo["n_iter"]
+
+
+@pytest.mark.parametrize("shape,init", [((48, 64), [[7, 20], [55, 30]]),     # edge strictly inside a non-square image
+                                        ((80, 50), [[0, 60], [49, 15]]),     # taller than wide, steep edge
+                                        ((64, 64), [[3, 10], [40, 50]])])    # x_st > 0 and x_en < N - 1
+def test_partial_width_edges_and_non_square_images(amd, ctx, shape, init):
+    """x_st > 0, x_en < N - 1 and M != N: every kernel that mixes grid indices (0..Lg-1) with image columns
+    (x_st..x_en) or rows with columns is exercised; the trace equals the oracle's."""
+    M, N = shape
+    big, _ = _image(96, 7)
+    grad = np.ascontiguousarray(big[:M, :N])
+    init = np.array(init)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 6}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=4, keep_ratio=0.1, pixel_thresh=3, seed=6, fix_endpoints=True, return_std=True)
+    et_o, ci_o, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    et, ci = tr()
+    assert tr._n_iter == info["n_iter"]
+    assert np.array_equal(et, et_o)
+    np.testing.assert_allclose(ci[0], ci_o[0], rtol=1e-6, atol=1e-6)
+
+
+def test_many_samples_and_kept_curves(amd, ctx):
+    """N_samples = 1500 (top-k over more than one 1024-cost chunk) and N_keep = 300 (the fused KDE stages its curves in
+    more than one pass of 128): whole trace vs the oracle."""
+    grad, truth = _image(64, 9)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1, N_samples=1500,
+              score_thresh=1, delta_x=5, keep_ratio=0.2, pixel_thresh=3, seed=12, fix_endpoints=True)
+    et_o, _, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    assert tr._batch.info()["n_keep"] == 300
+    assert np.array_equal(tr(), et_o) and tr._n_iter == info["n_iter"]
