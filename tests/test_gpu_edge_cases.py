@@ -169,3 +169,47 @@ def test_many_samples_and_kept_curves(amd, ctx):
     tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
     assert tr._batch.info()["n_keep"] == 300
     assert np.array_equal(tr(), et_o) and tr._n_iter == info["n_iter"]
+
+
+def test_batch_with_one_image_per_edge(amd, ctx):
+    """Each edge of a batch may bring its own gradient image (no sharing): results equal the single-edge runs."""
+    g1, t1 = _image(64, 4)
+    g2, t2 = _image(64, 10)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    inits = [t1[[0, -1], :][:, [1, 0]], t2[[0, -1], :][:, [1, 0]]]
+    out = amd.GP_Edge_Tracing_Batch(inits, [g1, g2], [5, 6], **kw, _ctx=ctx)()
+    for e, (g, init, seed) in enumerate(zip([g1, g2], inits, [5, 6])):
+        assert np.array_equal(out[e], amd.GP_Edge_Tracing(init, g, seed=seed, **kw, _ctx=ctx)())
+
+
+def test_observations_outside_the_init_span_use_the_generic_path(amd, ctx):
+    """A warm-start observation left of x_st is off the prediction grid: the prior-eigenbasis path does not apply, the
+    batch falls back to covariance -> pivoted Cholesky -> Gram -> Jacobi, and still equals the oracle."""
+    grad, truth = _image(64, 4)
+    init = np.array([[8, int(truth[8, 0])], [60, int(truth[60, 0])]])
+    obs = np.array([[3, int(truth[3, 0])], [30, int(truth[30, 0])]])
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=2, fix_endpoints=True, obs=obs)
+    et_o, _, info = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    assert np.array_equal(tr(), et_o) and tr._n_iter == info["n_iter"]
+
+
+def test_long_edge_1024_columns_structured(amd, ctx):
+    """A 1024-column edge with a long RBF length scale (rank of the prior ~ 60 <= 96): the structured path on a grid
+    longer than 512 (generic pivoted Cholesky for the basis, 16 column tiles in the row and sample kernels)."""
+    M, N = 128, 1024
+    x = np.arange(N)
+    edge = (64 + 25 * np.sin(x / 90.0)).astype(int)
+    img = (np.arange(M)[:, None] > edge[None, :]).astype(np.float64)
+    img = np.clip(img * 0.6 + 0.05 * np.random.default_rng(1).standard_normal((M, N)) + 0.2, 0, 1)
+    grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+    init = np.array([[0, edge[0]], [N - 1, edge[-1]]])
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 30, 'length_scale': 45}, noise_y=1, N_samples=200,
+              score_thresh=1, delta_x=32, keep_ratio=0.1, pixel_thresh=4, seed=3, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    info = tr._batch.info()
+    assert info["structured"] == 1 and info["Lg"] == 1024
+    et_o, _, oinfo = orc.trace(init, grad, sign_convention="harmonic", **kw)
+    assert np.array_equal(tr(), et_o) and tr._n_iter == oinfo["n_iter"]
