@@ -12,6 +12,8 @@ namespace gpet {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -349,6 +351,289 @@ __global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
       if (j <= i) E.K[(size_t)i * E.n_cap + j] = K[(size_t)i * ld + j];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// a2-a4 for MANY training points (n_cap > 128, e.g. config 3's 1500): K and its factor live in HBM and the
+// work is spread over the GPU in 64-wide blocks -- head (sort, scaling) -> K tiles -> right-looking blocked
+// Cholesky (diagonal block in LDS / row-panel solve / trailing update on the f64 matrix cores) -> blocked solves
+// for alpha.  The panel kernels are enqueued for every 64-block of n_cap and return at once past the actual n.
+// ---------------------------------------------------------------------------------------
+#define CB 64
+__global__ void __launch_bounds__(256) k_fit_head(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  __shared__ double s_red[16];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const int n = E.n_init + sc->n_obs;
+  // 1. gather + stable rank sort by x (np.argsort, gpet.py:212)
+  const double w_init = E.fix_endpoints ? 1e-7 : 0.5;  // gpet.py:161
+  for (int i = tid; i < n; i += bs) {
+    const long long* pi = (i < E.n_init) ? (E.init_xy + 2 * i) : (E.obs_xy + 2 * (i - E.n_init));
+    const long long xi = pi[0], yi = pi[1];
+    int r = 0;
+    for (int j = 0; j < n; ++j) {
+      const long long xj = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+      r += (xj < xi) || (xj == xi && j < i);
+    }
+    E.xt[r] = (double)xi;
+    E.yt[r] = (double)yi;
+    E.wt[r] = (i < E.n_init) ? w_init : 1.0;
+  }
+  __syncthreads();
+  // 2. y scaling (gpet.py:228-230) then centring (sklearn_gpr.py:222-227) -- same arithmetic as k_fit
+  double part = 0.0;
+  for (int i = tid; i < n; i += bs) part += E.yt[i];
+  const double m1 = block_sum(part, s_red) / n;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double d = E.yt[i] - m1;
+    part += d * d;
+  }
+  const double y_s = sqrt(block_sum(part, s_red) / n) + 1.0;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double v = E.yt[i] / y_s;
+    E.yt[i] = v;
+    part += v;
+  }
+  const double m2 = block_sum(part, s_red) / n;
+  part = 0.0;
+  for (int i = tid; i < n; i += bs) {
+    const double d = E.yt[i] - m2;
+    part += d * d;
+  }
+  double sd2 = sqrt(block_sum(part, s_red) / n);
+  if (sd2 == 0.0) sd2 = 1.0;  // _handle_zeros_in_scale scalar path
+  for (int i = tid; i < n; i += bs) E.yt[i] -= m2;
+  if (tid == 0) {
+    sc->y_s = y_s;
+    sc->amp = E.sigma_f * E.sigma_f / (y_s * y_s);
+    sc->y_mean = m2;
+    sc->y_std = sd2;
+    sc->n = n;
+  }
+}
+
+// K = amp * rho + diag(noise_y * w) + jitter, lower 64x64 tiles (as step 3 of k_fit)
+__global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  const int i0 = blockIdx.y * CB, j0 = blockIdx.x * CB;
+  if (j0 > i0 || i0 >= n) return;
+  const double amp = sc->amp, length = E.length_scale;
+  const bool zero_noise = (n == E.Lg);  // sklearn_gpr.py:673-677
+  for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+    const int i = i0 + (e >> 6), j = j0 + (e & 63);
+    if (i >= n || j > i) continue;
+    double v;
+    if (i == j) {
+      v = amp;
+      v = v + (zero_noise ? 0.0 : E.noise_y * E.wt[i]);
+      v = v + E.jitter;
+    } else {
+      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length);
+    }
+    E.K[(size_t)i * ld + j] = v;
+  }
+}
+
+// diagonal block k0: Cholesky in LDS (right-looking), written back in place
+__global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  if (k0 >= n) return;
+  const int nb = (n - k0) < CB ? (n - k0) : CB;
+  __shared__ double s[CB][CB + 1];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  for (int e = tid; e < nb * nb; e += bs) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) s[i][j] = E.K[(size_t)(k0 + i) * ld + k0 + j];
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < nb; ++k) {
+    const double d = s[k][k];
+    if (!(d > 0.0)) {
+      bad = true;
+      break;
+    }
+    const double dk = sqrt(d);
+    __syncthreads();
+    for (int i = k + tid; i < nb; i += bs) s[i][k] = (i == k) ? dk : s[i][k] / dk;
+    __syncthreads();
+    const int m = nb - k - 1;
+    for (int e = tid; e < m * m; e += bs) {
+      const int ii = e / m, jj = e - ii * m;
+      if (jj <= ii) s[k + 1 + ii][k + 1 + jj] -= s[k + 1 + ii][k] * s[k + 1 + jj][k];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) sc->status = GPET_ERR_NOT_PD;
+    return;
+  }
+  for (int e = tid; e < nb * nb; e += bs) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) E.K[(size_t)(k0 + i) * ld + k0 + j] = s[i][j];
+  }
+}
+
+// row blocks below the diagonal block: X L_kk^T = A_ik, one row per lane of the first wave
+__global__ void __launch_bounds__(256) k_chol_trsm(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  const int i0 = k0 + CB * ((int)blockIdx.x + 1);
+  if (i0 >= n) return;
+  const int nb = CB;  // (a block below exists only under a full diagonal block)
+  const int rows = (n - i0) < CB ? (n - i0) : CB;
+  __shared__ double sL[CB][CB + 1];
+  __shared__ double sA[CB][CB + 1];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  for (int e = tid; e < CB * CB; e += bs) {
+    const int i = e >> 6, j = e & 63;
+    sL[i][j] = (j <= i) ? E.K[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+    sA[i][j] = (i < rows) ? E.K[(size_t)(i0 + i) * ld + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  if (tid < rows) {
+    for (int j = 0; j < nb; ++j) {
+      double acc = sA[tid][j];
+      for (int t = 0; t < j; ++t) acc -= sA[tid][t] * sL[j][t];
+      sA[tid][j] = acc / sL[j][j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * CB; e += bs) {
+    const int i = e >> 6, j = e & 63;
+    E.K[(size_t)(i0 + i) * ld + k0 + j] = sA[i][j];
+  }
+}
+
+// trailing update A_ij -= X_i X_j^T for the 64x64 tiles (bj <= bi) behind panel k0, v_mfma_f64_16x16x4_f64
+typedef double v4f64c __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int i0 = k0 + CB * (bi + 1), j0 = k0 + CB * (bj + 1);
+  if (i0 >= n) return;
+  __shared__ double sI[CB][CB + 1];
+  __shared__ double sJ[CB][CB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    sI[i][j] = (i0 + i < n) ? E.K[(size_t)(i0 + i) * ld + k0 + j] : 0.0;
+    sJ[i][j] = (j0 + i < n) ? E.K[(size_t)(j0 + i) * ld + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64c acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < CB; kk += 4) {
+    const double a = sI[16 * w + li][kk + lq];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sJ[16 * t + li][kk + lq], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = i0 + 16 * w + lq + 4 * g, j = j0 + 16 * t + li;
+      if (i < n && j <= i) E.K[(size_t)i * ld + j] -= acc[t][g];
+    }
+}
+
+// alpha = L^-T L^-1 y on the factor in HBM, blocked by 64: diagonal blocks through LDS (column form, one wave),
+// the updates of the remaining rows as 64-long dot products spread over the workgroup; the vector stays in LDS
+__global__ void __launch_bounds__(256) k_chol_solve(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  extern __shared__ double s_z[];  // [n_cap]
+  __shared__ double sL[CB][CB + 1];
+  const int n = sc->n, ld = E.n_cap;
+  const int tid = threadIdx.x, bs = blockDim.x;
+  for (int i = tid; i < n; i += bs) s_z[i] = E.yt[i];
+  __syncthreads();
+  for (int k0 = 0; k0 < n; k0 += CB) {  // forward
+    const int nb = (n - k0) < CB ? (n - k0) : CB;
+    for (int e = tid; e < nb * nb; e += bs) {
+      const int i = e / nb, j = e - i * nb;
+      if (j <= i) sL[i][j] = E.K[(size_t)(k0 + i) * ld + k0 + j];
+    }
+    __syncthreads();
+    if (tid < WAVE) {
+      double z = (tid < nb) ? s_z[k0 + tid] : 0.0;
+      for (int j = 0; j < nb; ++j) {
+        const double zj = __shfl(z, j, WAVE) / sL[j][j];
+        if (tid == j) z = zj;
+        if (tid > j && tid < nb) z -= sL[tid][j] * zj;
+      }
+      if (tid < nb) s_z[k0 + tid] = z;
+    }
+    __syncthreads();
+    for (int i = k0 + nb + tid; i < n; i += bs) {
+      const double* ri = E.K + (size_t)i * ld + k0;
+      double acc = 0.0;
+      for (int t = 0; t < nb; ++t) acc += ri[t] * s_z[k0 + t];
+      s_z[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int k0 = ((n - 1) / CB) * CB; k0 >= 0; k0 -= CB) {  // backward (L^T)
+    const int nb = (n - k0) < CB ? (n - k0) : CB;
+    for (int e = tid; e < nb * nb; e += bs) {
+      const int i = e / nb, j = e - i * nb;
+      if (j <= i) sL[i][j] = E.K[(size_t)(k0 + i) * ld + k0 + j];
+    }
+    __syncthreads();
+    if (tid < WAVE) {
+      double z = (tid < nb) ? s_z[k0 + tid] : 0.0;
+      for (int j = nb - 1; j >= 0; --j) {
+        const double aj = __shfl(z, j, WAVE) / sL[j][j];
+        if (tid == j) z = aj;
+        if (tid < j) z -= sL[j][tid] * aj;
+      }
+      if (tid < nb) s_z[k0 + tid] = z;
+    }
+    __syncthreads();
+    for (int i = tid; i < k0; i += bs) {
+      double acc = 0.0;
+      for (int t = 0; t < nb; ++t) acc += E.K[(size_t)(k0 + t) * ld + i] * s_z[k0 + t];
+      s_z[i] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += bs) E.alpha[i] = s_z[i];
+}
+
+// the whole fit for n_cap > 128
+static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  const int nt = cdiv(bd.n_cap, CB);
+  hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
+  for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0);
+    const int below = cdiv(bd.n_cap - k0 - CB, CB);
+    if (below > 0) {
+      hipLaunchKernelGGL(k_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0);
+    }
+  }
+  hipLaunchKernelGGL(k_chol_solve, dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2577,7 +2862,6 @@ hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const 
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 hipError_t launch_conv(hipStream_t st, const double* d_img, int M, int N, const double* d_wf, int kh, int kw, int oy,
                        int ox, float* d_tmp, unsigned int* d_minmax) {
@@ -2621,7 +2905,7 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
     hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else
-    hipLaunchKernelGGL((k_fit<false, false>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+    launch_fit_blocked(st, d_edges, B, bd);
   const size_t plds = ((size_t)bd.n_cap * 64 + 3 * (size_t)bd.n_cap) * sizeof(double);
   if (!(parts & 2u)) {
   } else if (plds <= 150 * 1024)
@@ -2713,8 +2997,8 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   } else if (bd.n_cap <= 128)
     hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
-  else  // (more possible training points than K fits LDS for: the factorisation works in HBM)
-    hipLaunchKernelGGL((k_fit<false, false>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  else  // (more possible training points than K fits LDS for: blocked factorisation in HBM)
+    launch_fit_blocked(st, d_edges, B, bd);
   if (parts & 2u) {
     const size_t full = ((size_t)bd.n_cap * (bd.r0_max | 1) + (size_t)bd.n_cap * (bd.n_cap + 1) / 2 + bd.r_cap) * sizeof(double);
     const size_t rowm = ((size_t)bd.n_cap * (bd.r0_max | 1) + bd.n_cap + bd.r_cap) * sizeof(double);
