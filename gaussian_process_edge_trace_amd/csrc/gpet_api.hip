@@ -468,8 +468,10 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
         if (s.rank > r0_max) r0_max = s.rank;
       }
       b->bd.r0_max = r0_max;
-      // k_struct_H keeps U (n_cap x r0) in LDS: many possible observations (small delta_x on a long edge) do not fit
-      if (((size_t)b->bd.n_cap * (r0_max | 1) + b->bd.n_cap + b->bd.r_cap) * sizeof(double) > (size_t)STRUCT_H_LDS_MAX) ok = false;
+      // (n_cap <= 128: k_struct_H keeps U in LDS -- it fits with L streamed row by row; larger: U in HBM, blocked)
+      if (b->bd.n_cap <= 128 &&
+          ((size_t)b->bd.n_cap * (r0_max | 1) + b->bd.n_cap + b->bd.r_cap) * sizeof(double) > (size_t)STRUCT_H_LDS_MAX)
+        ok = false;
       // back to the pristine scalar state
       for (int e = 0; e < B; ++e) {
         EdgeDev& E = b->h_edges[e];

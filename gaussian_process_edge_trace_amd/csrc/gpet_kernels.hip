@@ -1233,6 +1233,144 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
   if (tid == 0) sc->rank = r0;
 }
 
+// ---- structured path with MANY training points (n_cap > 128): U lives in HBM (the V buffer, row stride r_cap) ----
+// B rows -> blocked forward substitution U = L^-1 B (left-looking: block k subtracts the blocks before it, then
+// solves against its diagonal block in LDS; the r0 columns are split over workgroups of 16) -> H, beta, mean.
+#define SB_COLS 16
+__global__ void __launch_bounds__(256) k_structB_build(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int n = sc->n, r0 = E.r0, Lg = E.Lg, ldu = E.r_cap;
+  const double c = sc->amp;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * r0; e += gridDim.x * blockDim.x) {
+    const int i = e / r0, a = e - i * r0;
+    const int idx = (int)E.xt[i] - E.x_st;
+    E.V[(size_t)i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
+  }
+}
+
+// beta_a = sum_i B[i][a] alpha_i  (before the substitution overwrites B)
+__global__ void __launch_bounds__(128) k_struct_beta(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int n = sc->n, r0 = E.r0, ldu = E.r_cap;
+  for (int a = threadIdx.x; a < r0; a += blockDim.x) {
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += E.V[(size_t)i * ldu + a] * E.alpha[i];
+    E.beta[a] = acc;
+  }
+}
+
+// block k0 of U = L^-1 B for the 16 columns of this workgroup
+__global__ void __launch_bounds__(256) k_struct_trsm(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int n = sc->n, r0 = E.r0, ld = E.n_cap, ldu = E.r_cap;
+  const int a0 = blockIdx.x * SB_COLS;
+  if (k0 >= n || a0 >= r0) return;
+  const int nb = (n - k0) < CB ? (n - k0) : CB;
+  __shared__ double sL[CB][CB + 1];       // L[k0 + i][j0 + t] of the block being subtracted, then the diagonal block
+  __shared__ double sU[CB][SB_COLS + 1];  // U[j0 + t][a0 + a]
+  __shared__ double sX[CB][SB_COLS + 1];  // the block being solved
+  const int tid = threadIdx.x;
+  const int ca = tid & (SB_COLS - 1), ri = tid >> 4;  // thread tile: column ca, rows ri, ri + 16, ri + 32, ri + 48
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j0 = 0; j0 < k0; j0 += CB) {
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) {
+      const int i = e >> 6, t = e & 63;
+      sL[i][t] = (i < nb) ? E.K[(size_t)(k0 + i) * ld + j0 + t] : 0.0;
+    }
+    for (int e = tid; e < CB * SB_COLS; e += 256) {
+      const int t = e >> 4, a = e & 15;
+      sU[t][a] = (a0 + a < r0) ? E.V[(size_t)(j0 + t) * ldu + a0 + a] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {
+      const double u = sU[t][ca];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += sL[ri + 16 * q][t] * u;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int i = e >> 6, t = e & 63;
+    sL[i][t] = (i < nb && t <= i) ? E.K[(size_t)(k0 + i) * ld + k0 + t] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = ri + 16 * q;
+    sX[i][ca] = (i < nb && a0 + ca < r0) ? E.V[(size_t)(k0 + i) * ldu + a0 + ca] - acc[q] : 0.0;
+  }
+  __syncthreads();
+  if (tid < SB_COLS) {  // forward substitution against the diagonal block, one column per thread
+    for (int i = 0; i < nb; ++i) {
+      double x = sX[i][tid];
+      for (int t = 0; t < i; ++t) x -= sL[i][t] * sX[t][tid];
+      sX[i][tid] = x / sL[i][i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = ri + 16 * q;
+    if (i < nb && a0 + ca < r0) E.V[(size_t)(k0 + i) * ldu + a0 + ca] = sX[i][ca];
+  }
+}
+
+// H = c Lam - U^T U (lower 16x16 tiles, mirrored) from U in HBM
+__global__ void __launch_bounds__(256) k_struct_Hbig(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int n = sc->n, r0 = E.r0, ldu = E.r_cap, ldc = E.r_cap;
+  const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+  if (b0 > a0 || a0 >= r0) return;
+  __shared__ double sA[64][17], sB[64][17];
+  const int tid = threadIdx.x, ta = tid >> 4, tb = tid & 15;
+  double acc = 0.0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * 16; e += 256) {
+      const int i = e >> 4, q = e & 15;
+      const bool in = i0 + i < n;
+      sA[i][q] = (in && a0 + q < r0) ? E.V[(size_t)(i0 + i) * ldu + a0 + q] : 0.0;
+      sB[i][q] = (in && b0 + q < r0) ? E.V[(size_t)(i0 + i) * ldu + b0 + q] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) acc += sA[i][ta] * sB[i][tb];
+  }
+  const int a = a0 + ta, b = b0 + tb;
+  if (a < r0 && b < r0 && b <= a) {
+    const double v = ((a == b) ? sc->amp * E.lam0[a] : 0.0) - acc;
+    E.C[(size_t)a * ldc + b] = v;
+    E.C[(size_t)b * ldc + a] = v;
+  }
+}
+
+// posterior mean on the grid: y_std * (Q beta) + y_mean, and the rank of the factorisation to come
+__global__ void __launch_bounds__(256) k_struct_mean(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
+  const int r0 = E.r0, Lg = E.Lg;
+  __shared__ double s_b[96];
+  for (int a = threadIdx.x; a < r0; a += blockDim.x) s_b[a] = E.beta[a];
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < Lg) {
+    double acc = 0.0;
+    for (int a = 0; a < r0; ++a) acc += E.Q0[(size_t)a * Lg + j] * s_b[a];
+    E.mean[j] = sc->y_std * acc + sc->y_mean;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc->rank = r0;
+}
+
 // factor rows of the structured path: A[k, :] = y_std * sqrt(theta_k) * (Q r_k)^T as a column-tiled product
 // (r0 x r0) . (r0 x 64) on v_mfma_f64_16x16x4_f64: the Q0 tile and the scaled, ordered eigenvectors sit in
 // LDS, wave w owns 16 of the 64 columns and all MT row tiles, so Q0 is read from HBM once per iteration.
@@ -2999,7 +3137,17 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else  // (more possible training points than K fits LDS for: blocked factorisation in HBM)
     launch_fit_blocked(st, d_edges, B, bd);
-  if (parts & 2u) {
+  if ((parts & 2u) && bd.n_cap > 128) {
+    // many training points: U through HBM, blocked substitution
+    hipLaunchKernelGGL(k_structB_build, dim3(64, B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_struct_beta, dim3(1, B), dim3(128), 0, st, d_edges);
+    const int cgroups = cdiv(bd.r0_max, SB_COLS);
+    for (int k0 = 0; k0 < bd.n_cap; k0 += CB)
+      hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, B), dim3(256), 0, st, d_edges, k0);
+    const int t16 = cdiv(bd.r0_max, 16);
+    hipLaunchKernelGGL(k_struct_Hbig, dim3(t16, t16, B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_struct_mean, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
+  } else if (parts & 2u) {
     const size_t full = ((size_t)bd.n_cap * (bd.r0_max | 1) + (size_t)bd.n_cap * (bd.n_cap + 1) / 2 + bd.r_cap) * sizeof(double);
     const size_t rowm = ((size_t)bd.n_cap * (bd.r0_max | 1) + bd.n_cap + bd.r_cap) * sizeof(double);
     const int l_in_lds = full <= (size_t)STRUCT_H_LDS_MAX ? 1 : 0;  // (gpet_batch_create checked that `rowm` fits)

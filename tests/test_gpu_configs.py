@@ -84,3 +84,44 @@ def test_config5_matern_frame_with_warm_start(amd, ctx):
     for i, r in enumerate(rec):
         assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
     assert np.array_equal(et, et_o)
+
+
+def test_large_n_structured_path_equals_generic(amd, ctx):
+    """900 on-grid observations on a 2048-column edge (delta_x = 2 keeps the trace unfinished): the structured loop
+    path for many training points (blocked fit in HBM, U = L^-1 B by blocked substitution through HBM, H from U)
+    must give the factor and mean of the generic path (predict -> covariance -> pivoted Cholesky -> Gram -> Jacobi)."""
+    L = amd._lib
+    N = 2048
+    img, truth = orc.synth_sinusoid_image(N, 0)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=900, replace=False))
+    obs = np.stack([cols, truth[cols, 0] + rng.integers(-2, 3, size=cols.size)], axis=1).astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=200,
+              score_thresh=1, delta_x=2, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    b = tr._batch
+    info = b.info()
+    assert info["structured"] == 1 and info["n_cap"] > 1000
+    b.set_obs(0, obs)
+    b.fit_predict(want_cov=True)
+    b.factor()
+    A_gen, ev_gen, mean_gen, cov = b.read(L.BUF_FACTOR), b.read(L.BUF_EIGVALS), b.read(L.BUF_MEAN), b.read(L.BUF_COV)
+    alpha_gen = b.read(L.BUF_ALPHA)
+    b.set_obs(0, obs)
+    for stage in (120, 121, 122, 123):
+        b.profile_stage(stage, 1)
+    assert b.scalars().n == 902
+    np.testing.assert_allclose(b.read(L.BUF_ALPHA), alpha_gen, rtol=1e-12)
+    np.testing.assert_allclose(b.read(L.BUF_MEAN), mean_gen, rtol=1e-9)
+    A_str = b.read(L.BUF_FACTOR)
+    scale = ev_gen[0]
+    np.testing.assert_allclose(A_str.T @ A_str, cov, rtol=0, atol=1e-9 * scale)
+    # against the oracle too (T1 on the mean)
+    p = orc.resolve_params(init, grad, obs=obs, **kw)
+    x, y, w = orc.assemble_training(p["init"], obs, True)
+    y_s = np.std(y) + 1.0
+    fit = orc.gp_fit(x, y / y_s, w, p["sigma_f"] ** 2 / y_s ** 2, p["length_scale"], "RBF", 2.5, 1, N)
+    pred = orc.gp_predict(fit, p["x_grid"].astype(float), want_cov=False)
+    np.testing.assert_allclose(b.read(L.BUF_MEAN), pred["mean"], rtol=1e-7)
