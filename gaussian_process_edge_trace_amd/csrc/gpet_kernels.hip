@@ -1264,11 +1264,13 @@ __global__ void __launch_bounds__(128) k_struct_beta(EdgeDev* edges) {
 }
 
 // block k0 of U = L^-1 B for the 16 columns of this workgroup
-__global__ void __launch_bounds__(256) k_struct_trsm(EdgeDev* edges, int k0) {
+// (predict != 0: the same substitution on the Lg columns of V = K_*^T, row stride Lg -- the generic path's
+//  V = L^-1 K_*^T for many training points)
+__global__ void __launch_bounds__(256) k_struct_trsm(EdgeDev* edges, int k0, int predict) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
-  const int n = sc->n, r0 = E.r0, ld = E.n_cap, ldu = E.r_cap;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || (!predict && !E.structured)) return;
+  const int n = sc->n, r0 = predict ? E.Lg : E.r0, ld = E.n_cap, ldu = predict ? E.Lg : E.r_cap;
   const int a0 = blockIdx.x * SB_COLS;
   if (k0 >= n || a0 >= r0) return;
   const int nb = (n - k0) < CB ? (n - k0) : CB;
@@ -3025,6 +3027,49 @@ hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, con
   return hipGetLastError();
 }
 
+// ---- a5 for many training points (generic path): K_*^T rows into V, mean, blocked V = L^-1 K_*^T, std ----
+__global__ void __launch_bounds__(256) k_kstar_build(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, Lg = E.Lg;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const double amp = sc->amp, length = E.length_scale;
+  if (j >= Lg) return;
+  const double xq = (double)(E.x_st + j) / length;
+  for (int i = blockIdx.y * 4 + (threadIdx.x >> 6); i < n; i += gridDim.y * 4)
+    E.V[(size_t)i * Lg + j] = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / length);
+}
+// mean_j = y_std * sum_i K_*[i][j] alpha_i + y_mean   (sklearn_gpr.py:381-385; before V is overwritten)
+__global__ void __launch_bounds__(256) k_pred_mean_big(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, Lg = E.Lg;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Lg) return;
+  double msum = 0.0;
+  for (int i = 0; i < n; ++i) msum += E.V[(size_t)i * Lg + j] * E.alpha[i];
+  E.mean[j] = sc->y_std * msum + sc->y_mean;
+}
+// std_j = sqrt(max(amp - sum_i V[i][j]^2, 0) * y_std^2)   (sklearn_gpr.py:414-436)
+__global__ void __launch_bounds__(256) k_pred_std_big(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, Lg = E.Lg;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Lg) return;
+  double vsum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double v = E.V[(size_t)i * Lg + j];
+    vsum += v * v;
+  }
+  double var = sc->amp - vsum;
+  if (var < 0.0) var = 0.0;
+  E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
+}
+
 static void fit_predict_attrs() {
   static bool attr_set = false;
   if (attr_set) return;
@@ -3046,6 +3091,14 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
     launch_fit_blocked(st, d_edges, B, bd);
   const size_t plds = ((size_t)bd.n_cap * 64 + 3 * (size_t)bd.n_cap) * sizeof(double);
   if (!(parts & 2u)) {
+  } else if (bd.n_cap > 128 && plds > 150 * 1024) {
+    // many training points: V through HBM, blocked substitution with the panel kernel of the structured path
+    hipLaunchKernelGGL(k_kstar_build, dim3(cdiv(bd.Lg, 64), 64, B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_pred_mean_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
+    const int cgroups = cdiv(bd.Lg, SB_COLS);
+    for (int k0 = 0; k0 < bd.n_cap; k0 += CB)
+      hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, B), dim3(256), 0, st, d_edges, k0, 1);
+    hipLaunchKernelGGL(k_pred_std_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
   } else if (plds <= 150 * 1024)
     hipLaunchKernelGGL((k_predict<true, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, 0);
   else
@@ -3143,7 +3196,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     hipLaunchKernelGGL(k_struct_beta, dim3(1, B), dim3(128), 0, st, d_edges);
     const int cgroups = cdiv(bd.r0_max, SB_COLS);
     for (int k0 = 0; k0 < bd.n_cap; k0 += CB)
-      hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, B), dim3(256), 0, st, d_edges, k0);
+      hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, B), dim3(256), 0, st, d_edges, k0, 0);
     const int t16 = cdiv(bd.r0_max, 16);
     hipLaunchKernelGGL(k_struct_Hbig, dim3(t16, t16, B), dim3(256), 0, st, d_edges);
     hipLaunchKernelGGL(k_struct_mean, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
