@@ -50,6 +50,7 @@ class GpetError(RuntimeError):
 _P = C.c_void_p
 SYMBOLS = {
     "gpet_abi_version": (C.c_int, []),
+    "gpet_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gpet_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     "gpet_ctx_destroy": (None, [_P]),
     "gpet_last_error": (C.c_char_p, [_P]),
@@ -87,6 +88,14 @@ SYMBOLS = {
 }
 
 _lib = None
+
+
+def set_option(name, value):
+    """Process-wide tuning switch of the library (gpet_set_option); returns the previous value."""
+    old = load().gpet_set_option(name.encode(), int(value))
+    if old < 0:
+        raise ValueError("unknown option %r" % (name,))
+    return old
 
 
 def load():

@@ -158,6 +158,16 @@ extern "C" {
 
 int gpet_abi_version(void) { return GPET_ABI_VERSION; }
 
+int gpet_set_option(const char* name, int value) {
+  if (name && strcmp(name, "block_jacobi") == 0) {
+    int& v = gpet_opt_block_jacobi();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
+  return -1;
+}
+
 int gpet_ctx_create(int device, void* stream, gpet_ctx** out) {
   if (!out) return GPET_ERR_BAD_ARG;
   *out = nullptr;

@@ -26,6 +26,8 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u,
                       int raw_band = 0);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
+// process-wide switch (gpet_set_option "block_jacobi"; initial value from the environment GPET_JB_BLOCK)
+int& gpet_opt_block_jacobi();
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);

@@ -115,6 +115,13 @@ typedef struct gpet_batch gpet_batch;
 
 /* ---- context ------------------------------------------------------------------------ */
 int gpet_abi_version(void);
+
+/* Process-wide tuning switches (no reference counterpart).  name = "block_jacobi": 1 selects the two-level Jacobi
+ * for full-rank posterior covariances (Matern: ~5x faster per iteration at 1024 columns, an equally valid eigen-
+ * decomposition, but traces stop matching a LAPACK-based run after a few iterations -- the sampler is chaotic in
+ * 1e-12 perturbations there); 0 (default, or environment GPET_JB_BLOCK unset) keeps the scalar rounds the parity
+ * tests are passed with.  Returns the previous value, or -1 for an unknown name. */
+int gpet_set_option(const char* name, int value);
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
  * to let the library create its own. */
 int gpet_ctx_create(int device, void* stream, gpet_ctx** out);

@@ -125,3 +125,31 @@ def test_large_n_structured_path_equals_generic(amd, ctx):
     fit = orc.gp_fit(x, y / y_s, w, p["sigma_f"] ** 2 / y_s ** 2, p["length_scale"], "RBF", 2.5, 1, N)
     pred = orc.gp_predict(fit, p["x_grid"].astype(float), want_cov=False)
     np.testing.assert_allclose(b.read(L.BUF_MEAN), pred["mean"], rtol=1e-7)
+
+
+def test_block_jacobi_option_gives_a_valid_factor(amd, ctx):
+    """gpet_set_option("block_jacobi", 1) (two-level Jacobi for full-rank posteriors, opt-in): the factor of a
+    1024-wide Matern-5/2 posterior covariance must reconstruct it and have orthogonal rows and LAPACK's eigenvalues."""
+    L = amd._lib
+    N = 1024
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    warm = truth[16:-16:16][:, [1, 0]].astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41}, noise_y=1,
+              N_samples=300, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, warm)
+    b.fit_predict(want_cov=True)
+    old = L.set_option("block_jacobi", 1)
+    try:
+        b.factor()
+    finally:
+        L.set_option("block_jacobi", old)
+    A, cov, ev = b.read(L.BUF_FACTOR), b.read(L.BUF_COV), b.read(L.BUF_EIGVALS)
+    w = np.linalg.eigvalsh(cov)[::-1]
+    G = A @ A.T
+    assert np.abs(A.T @ A - cov).max() < 1e-10 * np.abs(cov).max()
+    assert np.abs(ev[:len(w)] - w).max() < 1e-10 * w[0]
+    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-11 * w[0]
