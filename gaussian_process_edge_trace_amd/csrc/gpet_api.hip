@@ -122,6 +122,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.lam0 = cv.take<double>(rc);
   E.beta = cv.take<double>(rc);
   E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
+  E.bj_R = cv.take<double>((size_t)(E.bj_pairs > 0 ? E.bj_pairs : 0) * 4096 + 1);
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1));
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
@@ -369,6 +370,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
   }
   b->bd = bd;
+  for (int e = 0; e < B; ++e) b->h_edges[e].bj_pairs = any_big ? (bd.Lg + 63) / 64 : 0;
   // measure, allocate, carve
   const size_t px = (size_t)M * N;
   Carver meas;

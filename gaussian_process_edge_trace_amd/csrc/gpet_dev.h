@@ -39,6 +39,8 @@ struct EdgeDev {
   double* beta;          // [r_cap] c * lam0 * Q0[:, obs] alpha
   double* row_part;      // [r_cap][Lg/64 + 1] per-column-tile partial sums of the sign convention
   int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
+  double* bj_R;          // [bj_pairs][64*64] rotations of the block pairs of a block-Jacobi round (large ranks)
+  int bj_pairs;          // pairs per block round of the BATCH (largest edge): ceil(Lg_max / 64); 0 for small ranks
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k

@@ -1716,8 +1716,8 @@ __global__ void __launch_bounds__(1024) k_bj_solve(EdgeDev* edges, int round, in
       __syncthreads();
     }
   }
-  // R of this pair -> G (unused on this path), [pair][64][64]
-  double* R = E.G + (size_t)blockIdx.x * (m * m);
+  // R of this pair -> [pair][64][64]
+  double* R = E.bj_R + (size_t)blockIdx.x * (m * m);
   for (int e = tid; e < m * m; e += bs) R[e] = W[(e / m) * ld + (e % m)];
 }
 
@@ -1734,7 +1734,7 @@ __global__ void __launch_bounds__(256) k_bj_rows(EdgeDev* edges, int round, int 
   if (c0 >= N) return;
   __shared__ double sR[64][65];  // sR[a][b] = R[b][a]
   __shared__ double sX[64][65];  // sX[b][c] = Sigma[idx[b]][c0 + c]
-  const double* R = E.G + (size_t)blockIdx.y * 4096;
+  const double* R = E.bj_R + (size_t)blockIdx.y * 4096;
   const int tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 256) {
     const int b = e >> 6, q = e & 63;
@@ -1776,7 +1776,7 @@ __global__ void __launch_bounds__(256) k_bj_cols(EdgeDev* edges, int round, int 
   if (r0 >= N) return;
   __shared__ double sR[64][65];  // sR[b][a] = R[b][a]
   __shared__ double sX[64][65];  // sX[r][b] = M[r0 + r][idx[b]]
-  const double* R = E.G + (size_t)blockIdx.y * 4096;
+  const double* R = E.bj_R + (size_t)blockIdx.y * 4096;
   const int tid = threadIdx.x;
   for (int e = tid; e < 4096; e += 256) {
     const int q = e >> 6, b = e & 63;
