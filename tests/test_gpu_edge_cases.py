@@ -213,3 +213,18 @@ def test_long_edge_1024_columns_structured(amd, ctx):
     assert info["structured"] == 1 and info["Lg"] == 1024
     et_o, _, oinfo = orc.trace(init, grad, sign_convention="harmonic", **kw)
     assert np.array_equal(tr(), et_o) and tr._n_iter == oinfo["n_iter"]
+
+
+def test_batch_with_edges_of_different_length(amd, ctx):
+    """Edges of one batch may span different column ranges (Lg, rank, bins and capacities differ per edge while the
+    launches are sized for the largest): every edge must still equal its single-edge run."""
+    grad, truth = _image(96, 4)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 7}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=4, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    spans = [(0, 95), (10, 60), (30, 90), (5, 40)]
+    inits = [np.array([[a, int(truth[a, 0])], [b, int(truth[b, 0])]]) for a, b in spans]
+    seeds = [3, 4, 5, 6]
+    out = amd.GP_Edge_Tracing_Batch(inits, grad, seeds, **kw, _ctx=ctx)()
+    for e, (init, seed) in enumerate(zip(inits, seeds)):
+        single = amd.GP_Edge_Tracing(init, grad, seed=seed, **kw, _ctx=ctx)()
+        assert out[e].shape == single.shape and np.array_equal(out[e], single), "edge %d" % e
