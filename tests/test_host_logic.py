@@ -141,3 +141,28 @@ def test_lockstep_farm_two_concurrent_jobs_equal_the_in_process_driver():
             assert rounds > 3 and np.array_equal(X, Xr) and np.array_equal(F, Fr)
     finally:
         farm.close()
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r01_bench_n1.json is a bench.py output committed this round: it must carry every field of the
+    driver's contract (metric/value/unit/..., roofline{...}, cpu_baseline{...}) with sane types."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r01_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "edge-traces/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 50 * c["value"]  # north_star target: >= 50x the CPU path on one GPU
