@@ -93,7 +93,7 @@ def main():
                     help="0: final fits on the GPU (batched LML kernel); >1: host worker processes instead")
     ap.add_argument("--lbfgs-workers", type=int, default=max(1, min(12, (os.cpu_count() or 2) - 2)),
                     help="worker processes advancing scipy's L-BFGS-B routine in lock step (final fits)")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace the steps strictly one after the other (default: the converged fits of step k overlap "
@@ -179,11 +179,14 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     executor = ThreadPoolExecutor(max_workers=max(1, depth))
 
+    fit_walls = []  # wall time of every step's converged fits (they run concurrently with later device loops)
+
     def run_steps(n_steps, timed):
         """n_steps passes of the hot path.  Pipelined: while the converged fits of step k run (host-driven
         lock-step L-BFGS-B + LML kernels on stream A) the device loop of step k+1 runs on stream B."""
         loop_s = fit_s = 0.0
         iters_, traces_, pending = [], None, []
+        fit_walls.clear()
         for k in range(n_steps):
             tr_ = tracers[k % len(tracers)]
             # a batch object is reused only after its previous fits (depth+1 steps ago) were collected
@@ -195,7 +198,12 @@ def main():
             t_b2 = time.time()
             loop_s += t_b2 - t_a
             if pipeline:
-                pending.append(executor.submit(tr_.finish, iters_))
+                def timed_finish(tr__=tr_, it__=iters_):
+                    t_f = time.time()
+                    out_ = tr__.finish(it__)
+                    fit_walls.append(time.time() - t_f)
+                    return out_
+                pending.append(executor.submit(timed_finish))
             else:
                 traces_ = tr_.finish(iters_)
                 fit_s += time.time() - t_b2
@@ -331,7 +339,8 @@ def main():
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},
         "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
-        "time_split_s": {"device_loop": loop_s, "final_fit_not_overlapped": fit_s, "elapsed": elapsed, "pipelined": pipeline, "pipeline_depth": depth},
+        "time_split_s": {"device_loop": loop_s, "final_fit_not_overlapped": fit_s, "elapsed": elapsed, "pipelined": pipeline, "pipeline_depth": depth,
+                         "fit_wall_mean": (sum(fit_walls) / len(fit_walls)) if fit_walls else None},
         "single_edge": {"traces_per_s": 1.0 / single_s, "ms_per_trace": 1e3 * single_s},
         "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b,
         "roofline": roofline, "cpu_baseline": cpu,
