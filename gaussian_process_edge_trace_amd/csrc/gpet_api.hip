@@ -123,7 +123,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.beta = cv.take<double>(rc);
   E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
   E.bj_R = cv.take<double>((size_t)(E.bj_pairs > 0 ? E.bj_pairs : 0) * 4096 + 1);
-  E.jb_cs = cv.take<double>(2 * (rc / 2 + 1));
+  E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);

@@ -1581,6 +1581,9 @@ __global__ void __launch_bounds__(256) k_jb_apply(EdgeDev* edges, int round) {
   }
 }
 
+// off-diagonal / diagonal square sums of the current matrix, in two steps: 64 workgroups write partial sums
+// (into the rotation-parameter buffer, idle between sweeps), one wave adds them in a fixed order
+#define JBN_PARTS 64
 __global__ void __launch_bounds__(1024) k_jb_norms(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
@@ -1588,7 +1591,7 @@ __global__ void __launch_bounds__(1024) k_jb_norms(EdgeDev* edges) {
   __shared__ double s_red[16];
   const int r = E.Lg, ld = E.r_cap;
   double off = 0.0, dg = 0.0;
-  for (size_t e = threadIdx.x; e < (size_t)r * r; e += blockDim.x) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)r * r; e += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(e / r), j = (int)(e - (size_t)i * r);
     const double v = E.C[(size_t)i * ld + j];
     if (i == j) dg += v * v; else off += v * v;
@@ -1596,12 +1599,25 @@ __global__ void __launch_bounds__(1024) k_jb_norms(EdgeDev* edges) {
   off = block_sum(off, s_red);
   dg = block_sum(dg, s_red);
   if (threadIdx.x == 0) {
+    E.jb_cs[2 * blockIdx.x] = off;
+    E.jb_cs[2 * blockIdx.x + 1] = dg;
+  }
+}
+__global__ void __launch_bounds__(64) k_jb_norms_fin(EdgeDev* edges, int parts) {
+  const EdgeDev E = edges[blockIdx.x];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  if (threadIdx.x == 0) {
+    double off = 0.0, dg = 0.0;
+    for (int p = 0; p < parts; ++p) {
+      off += E.jb_cs[2 * p];
+      dg += E.jb_cs[2 * p + 1];
+    }
     E.jb_norm[0] = off;
     E.jb_norm[1] = dg;
   }
 }
 
-// singular values |theta| in descending order, factor rows sqrt(|theta_k|) * v_k with the sign convention
 // ---- two-level (block) Jacobi for the large ranks ---------------------------------------------------------------
 // The Lg columns are cut into blocks of 32; a block round pairs them up round-robin and, for every pair, the 64x64
 // principal sub-matrix is diagonalised COMPLETELY in LDS (k_bj_solve: the LDS Jacobi above on a gathered
@@ -3345,6 +3361,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     int ablocks = (int)((items + 255) / 256);
     if (ablocks > 4096) ablocks = 4096;
     hipLaunchKernelGGL(k_jb_init, dim3(512, B), dim3(256), 0, st, d_edges);
+    const int jbn_parts = JBN_PARTS;  // (partial sums of the norms live at the head of jb_cs, sized for them)
     // gpet_set_option("block_jacobi", 1) / GPET_JB_BLOCK=1: two-level Jacobi, ~5x faster at Lg = 1024 and an equally valid decomposition (reconstruction
     // 4e-12), but it converges to a slightly different point in the 1e-12 ball than the scalar rounds; the sampler is
     // chaotic in such perturbations for full-rank posteriors, so traces stop matching a LAPACK-based run after a
@@ -3358,7 +3375,8 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
         bj_attr = true;
       }
       for (int sweep = 0; sweep < 24; ++sweep) {
-        hipLaunchKernelGGL(k_jb_norms, dim3(1, B), dim3(1024), 0, st, d_edges);
+        hipLaunchKernelGGL(k_jb_norms, dim3(jbn_parts, B), dim3(1024), 0, st, d_edges);
+        hipLaunchKernelGGL(k_jb_norms_fin, dim3(B), dim3(64), 0, st, d_edges, jbn_parts);
         for (int round = 0; round < nblk - 1; ++round) {
           hipLaunchKernelGGL(k_bj_solve, dim3(nblk / 2, B), dim3(1024), (size_t)2 * 64 * 65 * sizeof(double), st, d_edges, round, nblk);
           hipLaunchKernelGGL(k_bj_rows, dim3(t64, nblk / 2, B), dim3(256), 0, st, d_edges, round, nblk);
@@ -3368,7 +3386,8 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     } else {
     // (graded spectra need up to ~20 sweeps from a cold start: linear phase, then quadratic)
     for (int sweep = 0; sweep < 30; ++sweep) {
-      hipLaunchKernelGGL(k_jb_norms, dim3(1, B), dim3(1024), 0, st, d_edges);
+      hipLaunchKernelGGL(k_jb_norms, dim3(jbn_parts, B), dim3(1024), 0, st, d_edges);
+        hipLaunchKernelGGL(k_jb_norms_fin, dim3(B), dim3(64), 0, st, d_edges, jbn_parts);
       for (int round = 0; round < m - 1; ++round) {
         hipLaunchKernelGGL(k_jb_params, dim3(cdiv(half, 256), B), dim3(256), 0, st, d_edges, round);
         hipLaunchKernelGGL(k_jb_apply, dim3(ablocks, B), dim3(256), 0, st, d_edges, round);
