@@ -243,6 +243,16 @@ def main():
     # ---- quality of this rank's traces vs ground truth (sanity band, not the metric)
     mse = float(np.mean([pkg.gpet_utils.trace_MSE(tr, truth) for tr in traces]))
 
+    # ---- one step alone (nothing else on the GPU): device time of the LML kernel launches of its converged fits,
+    #      hipEvents around every launch on the fit stream (gpet_lml_stats)
+    tracer.reset()
+    it_alone = tracer.run_loop()
+    tracer._batch.lml_stats(reset=True)
+    tracer.finish(it_alone)
+    lml = tracer._batch.lml_stats()
+    n_fit = float(np.mean([len(o) for o in tracer._batch.read_obs_all()])) + len(init)  # training points of a converged fit
+    iters_per_trace = float(np.mean(it_alone))
+
     # ---- per-stage and per-kernel device time at a mid-trace state (batch of E edges, 7 iterations in),
     #      measured live with hipEvents on the library's stream (gpet_profile_stage)
     tracer.reset()
@@ -291,9 +301,17 @@ def main():
     kernel_ms["k_mt_normals"] = stage_ms["normals"] * ring
     alg["k_mt_normals"] = dict(flops=40.0 * S * zc * ring, bytes=8.0 * S * zc * ring)
     per_iter = {k: (v / ring if k == "k_mt_normals" else v) for k, v in kernel_ms.items()}
-    # dominant kernel of the timed region: every loop kernel runs once per iteration, so the largest
-    # per-iteration share is the largest total (the LML kernel of the final fits: ~80 launches of ~0.1 ms per step)
-    dom = max(per_iter, key=per_iter.get)
+    # dominant kernel of a step = largest device time per step of 256 traces, kernels timed alone: a loop kernel runs
+    # once per iteration of the trace, the LML kernel of the converged fits ~80 times per step (one launch per
+    # lock-step round of the optimiser).  The LML kernel evaluates `evaluations` problems of n_fit points each:
+    # n^3 flops (sweep of the bordered matrix, n^3 / 2 FMAs) and 3 n + 4 doubles of HBM traffic per evaluation.
+    per_step = {k: v * iters_per_trace for k, v in per_iter.items()}
+    per_step["k_lml"] = lml["kernel_ms"]
+    kernel_ms["k_lml"] = lml["kernel_ms"] / max(1, lml["launches"])
+    per_iter["k_lml"] = lml["kernel_ms"] / iters_per_trace
+    ev_per_launch = lml["evaluations"] / max(1, lml["launches"])
+    alg["k_lml"] = dict(flops=n_fit ** 3 * ev_per_launch / E, bytes=8.0 * (3 * n_fit + 4) * ev_per_launch / E)
+    dom = max(per_step, key=per_step.get)
     d_ms = kernel_ms[dom]
     a_bytes = alg[dom]["bytes"] * E
     a_flops = alg[dom]["flops"] * E
@@ -312,10 +330,16 @@ def main():
                     unit="TFLOP/s" if use_flops else "GB/s",
                     frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
                     launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
+                    launches_per_step=(lml["launches"] if dom == "k_lml" else iters_per_trace),
+                    device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                     note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
-                          "bound is LDS bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_lds" else None),
+                          "bound is LDS bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_lds" else
+                          ("objective of the converged fits: %d evaluations of ~%.0f-point problems in %d launches per step; "
+                           "f64 vector peak; latency-bound (one barrier per pivot), DESIGN.md section 6"
+                           % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None)),
                     state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
-                               loop_path="structured" if structured else "generic"),
+                               loop_path="structured" if structured else "generic", iterations_per_trace=iters_per_trace,
+                               n_train_final_fit=n_fit),
                     all_kernels={k: dict(ms=v, ms_per_iteration=per_iter[k],
                                          GBps=alg[k]["bytes"] * E / (v * 1e-3) / 1e9,
                                          TFLOPps=alg[k]["flops"] * E / (v * 1e-3) / 1e12) for k, v in kernel_ms.items()})

@@ -80,6 +80,7 @@ SYMBOLS = {
     "gpet_select_pixels_only": (C.c_int, [_P]),
     "gpet_final_set_training": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "gpet_lml_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "gpet_lml_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "gpet_final_set_training_all": (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     "gpet_batch_read_obs_all": (C.c_int, [_P, _P, _P, C.c_int]),
     "gpet_batch_read_scalars_all": (C.c_int, [_P, _P]),
@@ -316,6 +317,11 @@ class Batch:
         self.ctx.check(self.lib.gpet_lml_batch(self.h, P, edge_of.ctypes.data, theta.ctypes.data, f.ctypes.data,
                                                g.ctypes.data))
         return f, g
+
+    def lml_stats(self, reset=False):
+        ms, ev, la = C.c_double(), C.c_int64(), C.c_int32()
+        self.ctx.check(self.lib.gpet_lml_stats(self.h, int(bool(reset)), C.byref(ms), C.byref(ev), C.byref(la)))
+        return dict(kernel_ms=ms.value, evaluations=ev.value, launches=la.value)
 
     def select_pixels(self):
         self.ctx.check(self.lib.gpet_select_pixels(self.h))

@@ -54,6 +54,10 @@ struct gpet_batch {
   bool structured = false;  // every edge can take the prior-eigenbasis loop path
   // converged-fit scratch (grown on demand)
   int lml_cap = 0;
+  hipEvent_t ev_l0 = nullptr, ev_l1 = nullptr;  // around every LML kernel launch (gpet_lml_stats)
+  double lml_ms = 0.0;
+  long long lml_evals = 0;
+  int lml_launches = 0;
   int* d_edge_of = nullptr;
   double *d_theta = nullptr, *d_f = nullptr, *d_g = nullptr;
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
@@ -511,6 +515,8 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_edges) (void)hipFree(b->d_edges);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->ev_l0) (void)hipEventDestroy(b->ev_l0);
+  if (b->ev_l1) (void)hipEventDestroy(b->ev_l1);
   if (b->d_fin_stage) (void)hipFree(b->d_fin_stage);
   if (b->d_fin_n) (void)hipFree(b->d_fin_n);
   if (b->fit) {
@@ -983,10 +989,33 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
   }
   HIPCHK(c, hipMemcpyAsync(b->d_edge_of, edge_of, sizeof(int) * P, hipMemcpyHostToDevice, b->fit));
   HIPCHK(c, hipMemcpyAsync(b->d_theta, theta, sizeof(double) * 3 * P, hipMemcpyHostToDevice, b->fit));
+  if (!b->ev_l0) {
+    HIPCHK(c, hipEventCreate(&b->ev_l0));
+    HIPCHK(c, hipEventCreate(&b->ev_l1));
+  }
+  HIPCHK(c, hipEventRecord(b->ev_l0, b->fit));
   HIPCHK(c, launch_lml(b->fit, b->d_edges, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g));
+  HIPCHK(c, hipEventRecord(b->ev_l1, b->fit));
   HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, b->fit));
   HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, b->fit));
   HIPCHK(c, hipStreamSynchronize(b->fit));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, b->ev_l0, b->ev_l1) == hipSuccess) b->lml_ms += (double)ms;
+  b->lml_evals += P;
+  b->lml_launches += 1;
+  return GPET_OK;
+}
+
+int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  if (kernel_ms) *kernel_ms = b->lml_ms;
+  if (evaluations) *evaluations = b->lml_evals;
+  if (launches) *launches = b->lml_launches;
+  if (reset) {
+    b->lml_ms = 0.0;
+    b->lml_evals = 0;
+    b->lml_launches = 0;
+  }
   return GPET_OK;
 }
 

@@ -217,6 +217,10 @@ int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, d
  * kernel matrix gives f = +inf, g = 0 (sklearn_gpr.py:521-522). */
 int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out);
 
+/* Device time of the LML kernel launches of this batch since the last reset (hipEvents around each launch), the
+ * number of objective evaluations and of launches; any of the outputs may be NULL.  (bench.py's roofline leg.) */
+int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Enqueue one stage `reps` times between two hipEvents on the context's stream and return the
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
