@@ -3096,12 +3096,12 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
       }
       T[a][b] = v;
     }
-  int buf = 0;
   bool bad = false, stop = false;
   for (int kb = 0; kb < nb && !stop; ++kb) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int k = 4 * kb + kk;
+      const int buf = kk & 1;  // (= k & 1: a constant once the loop is unrolled -- no double-buffer address arithmetic per step)
       if (k == 0) continue;  // the y border is not a pivot
       if (k > n) {
         stop = true;
@@ -3152,7 +3152,6 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
           if (ti == kb) T[kk][kk] = -inv;
         }
       }
-      buf ^= 1;
     }
   }
   if (bad) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
@@ -3163,12 +3162,13 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
     return;
   }
   // alpha = column 0 of the swept matrix; its corner is -y^T alpha
+  const int fbuf = (n + 1) & 1;  // (the last pivot n used buffer n & 1)
   if (active && tj == 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) s_col[buf][4 * ti + a] = T[a][0];
+    for (int a = 0; a < 4; ++a) s_col[fbuf][4 * ti + a] = T[a][0];
   }
   __syncthreads();
-  const double* al = s_col[buf];
+  const double* al = s_col[fbuf];
   double ld = 0.0;
   for (int k = 1 + tid; k <= n; k += bs) ld += log(sqrt(s_piv[k]));
   const double logdet = block_sum(ld, s_red);
