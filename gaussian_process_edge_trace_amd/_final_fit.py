@@ -96,6 +96,69 @@ def prepare(init_sorted, obs_xy, x_grid, fix_endpoints):
     return dict(xs=xs, yt=(ys - m2) / s2, w=w, y_m=y_m, y_s=y_s, X_m=X_m, X_s=X_s, m2=m2, s2=s2, xg=xg)
 
 
+def prepare_many(inits, obs_list, x_grids, fix_endpoints_list):
+    """``prepare`` for many edges with far fewer NumPy calls: edges with the same numbers of init and observation
+    points (most of a batch) are stacked and reduced along axis 1.  Row-wise ``argsort`` / ``mean`` / ``std`` on a
+    C-contiguous 2-D array run the same per-row kernels as their 1-D forms, so every value is bit-identical to
+    ``prepare`` (tests/test_host_logic.py)."""
+    out = [None] * len(inits)
+    groups = {}
+    for e, (init, obs, xg, fe) in enumerate(zip(inits, obs_list, x_grids, fix_endpoints_list)):
+        init = np.asarray(init).reshape(-1, 2)
+        obs = np.asarray(obs).reshape(-1, 2)
+        groups.setdefault((init.shape[0], obs.shape[0], len(xg), bool(fe), init.dtype.str, obs.dtype.str), []).append(e)
+    for (ni, no, nxg, fe, _, _), members in groups.items():
+        pts = np.stack([np.concatenate([np.asarray(inits[e]).reshape(-1, 2), np.asarray(obs_list[e]).reshape(-1, 2)], axis=0)
+                        for e in members])                                          # (g, n, 2)
+        w1 = np.concatenate([np.full(ni, 1e-7 if fe else 0.5), np.ones(no)])
+        order = np.argsort(np.ascontiguousarray(pts[:, :, 0]), axis=1)
+        pts = np.take_along_axis(pts, order[:, :, None], axis=1)
+        w = w1[order]
+        x = np.ascontiguousarray(pts[:, :, 0].astype(np.float64))
+        y = np.ascontiguousarray(pts[:, :, 1].astype(np.float64))
+        y_m, y_s = np.mean(y, axis=1), np.std(y, axis=1)
+        ys = (y - y_m[:, None]) / y_s[:, None]
+        X_m, X_s = np.mean(x, axis=1), np.std(x, axis=1)
+        xs = (x - X_m[:, None]) / X_s[:, None]
+        if ni + no == nxg:  # sklearn_gpr.py:673-677
+            w = np.zeros_like(w)
+        m2, s2 = np.mean(ys, axis=1), np.std(ys, axis=1)
+        s2 = np.where(s2 == 0.0, 1.0, s2)
+        yt = (ys - m2[:, None]) / s2[:, None]
+        for k, e in enumerate(members):
+            out[e] = dict(xs=xs[k], yt=yt[k], w=w[k], y_m=y_m[k], y_s=y_s[k], X_m=X_m[k], X_s=X_s[k],
+                          m2=float(m2[k]), s2=float(s2[k]), xg=np.asarray(x_grids[e], dtype=np.float64))
+    return out
+
+
+def start_points_many(noise_ys, seeds, n_restarts=12):
+    """``start_points`` for many edges.  ``RandomState(seed)`` costs ~50 us of Python per edge; here MT19937's
+    ``init_genrand`` recurrence (what numpy's legacy seeding runs for an integer seed) is evaluated for all seeds at once
+    and each state is handed to one reused ``RandomState`` -- the draws are the generator's own, bit for bit."""
+    seeds = np.asarray(seeds, dtype=np.uint64)
+    if np.any(seeds > np.uint64(0xFFFFFFFF)):
+        raise ValueError("seeds must fit 32 bits (numpy legacy seeding)")
+    E = seeds.shape[0]
+    key = np.empty((624, E), dtype=np.uint64)
+    key[0] = seeds
+    mask = np.uint64(0xFFFFFFFF)
+    for i in range(1, 624):
+        prev = key[i - 1]
+        key[i] = (np.uint64(1812433253) * (prev ^ (prev >> np.uint64(30))) + np.uint64(i)) & mask
+    key = np.ascontiguousarray(key.T.astype(np.uint32))
+    rs = np.random.RandomState(0)
+    out = []
+    lo, span = BOUNDS[:, 0], BOUNDS[:, 1] - BOUNDS[:, 0]
+    for e in range(E):
+        th = np.empty((1 + max(0, n_restarts), 3))
+        th[0] = np.log(np.array([5.0, 5.0, float(noise_ys[e])]))
+        if n_restarts > 0:
+            rs.set_state(("MT19937", key[e], 624, 0, 0.0))
+            th[1:] = lo + span * rs.uniform(size=(n_restarts, 3))
+        out += list(th)
+    return out
+
+
 def start_points(noise_y, seed, n_restarts=12):
     """theta of the kernel (gpet.py:244-245) + log-uniform restarts (sklearn_gpr.py:283-288)."""
     th = np.empty((1 + max(0, n_restarts), 3))

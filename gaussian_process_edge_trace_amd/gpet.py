@@ -242,15 +242,12 @@ def device_final_fits(batch, ps, obs_list, iters, farm=None):
     from . import _final_fit as ff
     from ._lbfgsb_lockstep import minimize_many
 
-    preps, x0s, edge_of = [], [], []
-    for e, (p, obs) in enumerate(zip(ps, obs_list)):
-        pr = ff.prepare(p["init"], obs, p["x_grid"], p["fix_endpoints"])
-        preps.append(pr)
-        th = ff.start_points(p["noise_y"], p["seed"] + iters[e])
-        x0s += th
-        edge_of += [e] * len(th)
+    preps = ff.prepare_many([p["init"] for p in ps], obs_list, [p["x_grid"] for p in ps],
+                            [p["fix_endpoints"] for p in ps])
+    x0s = ff.start_points_many([p["noise_y"] for p in ps], [p["seed"] + iters[e] for e, p in enumerate(ps)])
+    n_start = len(x0s) // len(ps)  # 1 + 12 restarts for every edge
+    edge_of = np.repeat(np.arange(len(ps), dtype=np.int32), n_start)
     batch.final_set_training_all([pr["xs"] for pr in preps], [pr["yt"] for pr in preps], [pr["w"] for pr in preps])
-    edge_of = np.asarray(edge_of, dtype=np.int32)
 
     def eval_batch(idx, X):
         return batch.lml_batch(edge_of[idx], X)
@@ -259,13 +256,11 @@ def device_final_fits(batch, ps, obs_list, iters, farm=None):
         X, F, rounds = farm.minimize(eval_batch, x0s, ff.BOUNDS)
     else:
         X, F, rounds = minimize_many(eval_batch, x0s, ff.BOUNDS)
-    thetas = []
+    best = np.argmin(F.reshape(len(ps), n_start), axis=1)  # first minimum per edge, like np.argmin in sklearn_gpr.py:292
+    thetas = [X[e * n_start + int(best[e])] for e in range(len(ps))]
     par = np.zeros((len(ps), 12))
+    par[:, :3] = np.exp(np.asarray(thetas))
     for e, pr in enumerate(preps):
-        sel = np.nonzero(edge_of == e)[0]
-        theta = X[sel[int(np.argmin(F[sel]))]]  # first minimum, like np.argmin in sklearn_gpr.py:292
-        thetas.append(theta)
-        par[e, :3] = np.exp(theta)
         par[e, 3:9] = [pr["X_m"], pr["X_s"], pr["y_m"], pr["y_s"], pr["m2"], pr["s2"]]
     mean, std = batch.final_predict_all(par)
     out = [(mean[e, :len(p["x_grid"])].copy(), std[e, :len(p["x_grid"])].copy(), thetas[e]) for e, p in enumerate(ps)]

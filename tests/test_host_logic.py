@@ -166,3 +166,42 @@ def test_committed_bench_line_keeps_the_driver_contract():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 50 * c["value"]  # north_star target: >= 50x the CPU path on one GPU
+
+
+def test_prepare_many_is_bit_identical_to_prepare():
+    """The grouped (stacked, axis=1) standardisation of many training sets equals the per-edge one bit for bit:
+    same argsort permutation, means, stds and standardised values, including a set that fills the whole x-grid
+    (weights zeroed) and sets with repeated x."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    rng = np.random.default_rng(5)
+    inits, obs, grids, fes = [], [], [], []
+    for e in range(40):
+        n_obs = [30, 31, 30, 97, 30][e % 5]
+        xg = np.arange(0, 500) if e % 7 else np.arange(0, n_obs + 2)
+        x = rng.choice(np.arange(1, len(xg) - 1), size=n_obs, replace=(e % 3 == 0)) if len(xg) > n_obs + 2 else np.arange(1, n_obs + 1)
+        inits.append(np.array([[0, rng.integers(0, 400)], [len(xg) - 1, rng.integers(0, 400)]]))
+        obs.append(np.stack([x, rng.integers(0, 400, size=n_obs)], axis=1).astype(np.int64))
+        grids.append(xg)
+        fes.append(bool(e % 2))
+    many = ff.prepare_many(inits, obs, grids, fes)
+    for e in range(40):
+        one = ff.prepare(inits[e], obs[e], grids[e], fes[e])
+        for k in ("xs", "yt", "w"):
+            assert np.array_equal(many[e][k], one[k]), (e, k)
+        for k in ("y_m", "y_s", "X_m", "X_s", "m2", "s2"):
+            assert many[e][k] == one[k], (e, k)
+
+
+def test_start_points_many_equals_randomstate_per_edge():
+    """Vectorised legacy seeding (init_genrand for all seeds at once) + one reused RandomState: the restart points
+    equal ``start_points`` (= ``RandomState(seed).uniform``) bit for bit, including the extreme seeds."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    seeds = [0, 1, 2, 42, 12345, 2**31 - 1, 2**31, 2**32 - 1] + list(range(100, 140))
+    noise = [1.0, 0.5] * (len(seeds) // 2)
+    many = ff.start_points_many(noise, seeds)
+    k = 0
+    for nz, sd in zip(noise, seeds):
+        for th in ff.start_points(nz, sd):
+            assert np.array_equal(many[k], th), (sd, k)
+            k += 1
+    assert k == len(many)
