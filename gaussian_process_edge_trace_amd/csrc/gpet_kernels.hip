@@ -2315,7 +2315,7 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
 // by shuffle inside the group, group reduction by shuffle, and one (arc, integral) partial per
 // (tile, curve); k_score_combine adds the partials in tile order (deterministic) and divides.
 #define SC_PAIRS 16
-#define SC_CURVES 512
+#define SC_CURVES 1024
 #define SC_THREADS 1024
 __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
   y = y < 0.0 ? 0.0 : (y > (double)(M - 1) ? (double)(M - 1) : y);
