@@ -141,7 +141,7 @@ __global__ void k_normalise_f32(const float* __restrict__ in, size_t count, cons
 // FINAL: the converged fit at the optimum found by L-BFGS-B (gpet.py:232-266): training set,
 // amplitude, length scale and noise come from fin_x/fin_y/fin_w/fin_par instead of the loop state.
 template <bool K_IN_LDS, bool FINAL>
-__global__ void __launch_bounds__(256) k_fit(EdgeDev* edges) {
+__global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if (!FINAL && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
@@ -3304,7 +3304,7 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
   fit_predict_attrs();
   if (!(parts & 1u)) {
   } else if (bd.n_cap <= 128)
-    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(512),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else
     launch_fit_blocked(st, d_edges, B, bd);
@@ -3435,7 +3435,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   }
   if (!(parts & 1u)) {
   } else if (bd.n_cap <= 128)
-    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(256),
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(512),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else  // (more possible training points than K fits LDS for: blocked factorisation in HBM)
     launch_fit_blocked(st, d_edges, B, bd);
