@@ -93,8 +93,8 @@ class GaussianProcessRegressor(object):
             if n == white.edge_length:
                 w = np.zeros(n)
         alpha = np.broadcast_to(np.asarray(self.alpha, dtype=np.float64), (n,))
-        if n > 128:
-            raise NotImplementedError("more than 128 training points: use GP_Edge_Tracing (large-n path)")
+        if n > 4096:
+            raise NotImplementedError("more than 4096 training points")
         self._fit = dict(kt=kt, nu=nu, const=const, ell=ell, x=X[:, 0].copy(), yt=yt, noise=nl * w + alpha)
         self.X_train_, self.y_train_ = X, yt
         return self

@@ -252,3 +252,21 @@ def test_gaussian_process_regressor_mirror(amd, ctx, golden):
     gp = GaussianProcessRegressor(kernel=kern, alpha=1e-6, normalize_y=True, _ctx=ctx).fit(x[:, None], y)
     fit = orc.gp_fit(x, y, w, 2.5, 15.0, "RBF", 2.5, 0.4, xq.size, jitter=1e-6)
     np.testing.assert_allclose(gp.predict(xq[:, None]), orc.gp_predict(fit, xq, want_cov=False)["mean"], rtol=1e-8)
+
+
+def test_gaussian_process_regressor_mirror_many_points(amd, ctx):
+    """The GPR mirror beyond the LDS-resident sizes: 300 training points (K and the factor in HBM)."""
+    from gaussian_process_edge_trace_amd.sklearn_gpr import GaussianProcessRegressor, WeightedWhiteKernel
+    rng = np.random.default_rng(1)
+    x = np.sort(rng.choice(np.arange(0, 1000), size=300, replace=False)).astype(float)
+    y = 5 * np.sin(x / 60.0) + rng.normal(0, 0.3, x.size) + 3.0
+    w = np.ones(x.size)
+    xq = np.arange(0, 1000, dtype=float)
+    kern = dict(kernel="RBF", nu=2.5, constant=2.5, length_scale=40.0,
+                white=WeightedWhiteKernel(noise_weight=w, edge_length=xq.size, noise_level=0.4))
+    gp = GaussianProcessRegressor(kernel=kern, alpha=1e-6, normalize_y=False, _ctx=ctx).fit(x[:, None], y)
+    mean, std = gp.predict(xq[:, None], return_std=True)
+    fit = orc.gp_fit(x, y, w, 2.5, 40.0, "RBF", 2.5, 0.4, xq.size, jitter=1e-6, center=True, scale=True)
+    pred = orc.gp_predict(fit, xq, want_cov=False)
+    np.testing.assert_allclose(mean, pred["mean"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(std, pred["std"], rtol=1e-5, atol=1e-7)
