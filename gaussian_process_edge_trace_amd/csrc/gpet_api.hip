@@ -874,7 +874,7 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
   if (n > E.n_cap) return fail(c, GPET_ERR_BAD_ARG, "final fit: n=%d exceeds n_cap=%d", n, E.n_cap);
-  if (n > 128) return fail(c, GPET_ERR_UNSUPPORTED, "final fit on the device needs n <= 128 (got %d)", n);
+  if (n > 250) return fail(c, GPET_ERR_UNSUPPORTED, "final fit on the device needs n <= 250 (got %d)", n);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(E.fin_x, xs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(E.fin_y, ys, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));

@@ -3208,10 +3208,195 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
   }
 }
 
+// The same kernel for 128 < n <= 250 training points (small delta_x): two tiles per thread (t and t + blockDim), up to
+// 63 x 64 / 2 = 2016 tiles on 1024 threads.  Kept separate so that the common sizes keep their lean single-tile code.
+#define LML2_MAXD 260
+__global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+                                               double* g_out) {
+  constexpr int SLOTS = 2;
+  const int pb = blockIdx.x;
+  const EdgeDev E = edges[edge_of[pb]];
+  const int n = E.fin_n;
+  const int nb = (n + 1 + 3) >> 2;
+  const int ntile = nb * (nb + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double s_col[2][LML2_MAXD];
+  __shared__ double s_x[LML2_MAXD], s_y[LML2_MAXD], s_w[LML2_MAXD];  // x / l, y, noise weights at index 1..n
+  __shared__ double s_piv[LML2_MAXD];
+  __shared__ double s_red[16];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  bool active[SLOTS];
+  int ti[SLOTS], tj[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int t = tid + s * bs;
+    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > t) --r;
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    ti[s] = r;
+    tj[s] = t - r * (r + 1) / 2;
+    active[s] = t < ntile;
+  }
+  const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
+  for (int i = tid; i < 4 * nb; i += bs) {
+    const bool in = (i >= 1 && i <= n);
+    s_x[i] = in ? E.fin_x[i - 1] / ell : 0.0;
+    s_y[i] = in ? E.fin_y[i - 1] : 0.0;
+    s_w[i] = in ? E.fin_w[i - 1] : 0.0;
+    s_piv[i] = 1.0;
+  }
+  __syncthreads();
+  double T[SLOTS][4][4];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = 4 * ti[s] + a, j = 4 * tj[s] + b;
+        double v = 0.0;
+        if (active[s] && i <= n && j <= n) {
+          if (i == 0 || j == 0) {
+            v = (i == j) ? 0.0 : s_y[i + j];
+          } else if (i == j) {
+            v = c + nl * s_w[i];
+            v = v + 1e-6;
+          } else {
+            v = c * corr_fn(E.kernel_type, E.nu_code, s_x[i], s_x[j]);
+          }
+        }
+        T[s][a][b] = v;
+      }
+  bool bad = false, stop = false;
+  for (int kb = 0; kb < nb && !stop; ++kb) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kb + kk;
+      const int buf = kk & 1;
+      if (k == 0) continue;  // the y border is not a pivot
+      if (k > n) {
+        stop = true;
+        break;
+      }
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (active[s]) {
+          if (tj[s] == kb) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s_col[buf][4 * ti[s] + a] = T[s][a][kk];
+            if (ti[s] == kb) s_piv[k] = T[s][kk][kk];
+          } else if (ti[s] == kb) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s_col[buf][4 * tj[s] + b] = T[s][kk][b];
+          }
+        }
+      }
+      __syncthreads();
+      const double d = s_col[buf][k];
+      if (!(d > 0.0)) {  // not positive definite (same for every thread)
+        bad = true;
+        stop = true;
+        break;
+      }
+      double inv = __builtin_amdgcn_rcp(d);
+      inv = inv * (2.0 - d * inv);
+      inv = inv * (2.0 - d * inv);
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        if (active[s]) {
+          double ci[4], cj[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            ci[a] = s_col[buf][4 * ti[s] + a];
+            cj[a] = s_col[buf][4 * tj[s] + a];
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const double ma = -(ci[a] * inv);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) T[s][a][b] = fma(ma, cj[b], T[s][a][b]);
+          }
+          if (ti[s] == kb) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) T[s][kk][b] = cj[b] * inv;
+          }
+          if (tj[s] == kb) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) T[s][a][kk] = ci[a] * inv;
+            if (ti[s] == kb) T[s][kk][kk] = -inv;
+          }
+        }
+      }
+    }
+  }
+  if (bad) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
+    if (tid == 0) {
+      f_out[pb] = INFINITY;
+      g_out[3 * pb] = g_out[3 * pb + 1] = g_out[3 * pb + 2] = 0.0;
+    }
+    return;
+  }
+  const int fbuf = (n + 1) & 1;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s)
+    if (active[s] && tj[s] == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s_col[fbuf][4 * ti[s] + a] = T[s][a][0];
+    }
+  __syncthreads();
+  const double* al = s_col[fbuf];
+  double ld = 0.0;
+  for (int k = 1 + tid; k <= n; k += bs) ld += log(sqrt(s_piv[k]));
+  const double logdet = block_sum(ld, s_red);
+  double gc = 0.0, gl = 0.0, gn = 0.0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    if (active[s]) {
+      const double wt = (ti[s] == tj[s]) ? 1.0 : 2.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = 4 * ti[s] + a, j = 4 * tj[s] + b;
+          if (i >= 1 && j >= 1 && i <= n && j <= n) {
+            const double inner = al[i] * al[j] + T[s][a][b];  // T = -Kinv
+            if (i == j) {
+              gc += inner * c;
+              gn += inner * (nl * s_w[i]);
+            } else {
+              double R, dR;
+              corr_and_dlog(E.kernel_type, E.nu_code, s_x[i], s_x[j], R, dR);
+              gc += wt * inner * (c * R);
+              gl += wt * inner * (c * dR);
+            }
+          }
+        }
+    }
+  }
+  gc = block_sum(gc, s_red);
+  gl = block_sum(gl, s_red);
+  gn = block_sum(gn, s_red);
+  if (tid == 0) {
+    const double yta = -al[0];
+    const double lml = -0.5 * yta - logdet - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    f_out[pb] = -lml;
+    g_out[3 * pb] = -0.5 * gc;
+    g_out[3 * pb + 1] = -0.5 * gl;
+    g_out[3 * pb + 2] = -0.5 * gn;
+  }
+}
+
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
                       double* d_f, double* d_g) {
   (void)hipGetLastError();
-  if (n_max > 128) return hipErrorInvalidValue;
+  if (n_max > 250) return hipErrorInvalidValue;
+  if (n_max > 128) {  // two tiles per thread
+    const int nb2 = (n_max + 1 + 3) >> 2;
+    const int tiles = nb2 * (nb2 + 1) / 2;
+    int threads = (((tiles + 1) / 2 + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    hipLaunchKernelGGL(k_lml2, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+    return hipGetLastError();
+  }
   const int nb = (n_max + 1 + 3) >> 2;
   const int threads = ((nb * (nb + 1) / 2 + 63) / 64) * 64;  // one thread per 4x4 tile of the lower triangle
   hipLaunchKernelGGL(k_lml, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g);

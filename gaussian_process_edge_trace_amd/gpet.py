@@ -208,7 +208,7 @@ class GP_Edge_Tracing(object):
         pre_fobs = b.read(_lib.BUF_OBS)
         self.score_thresh = b.scalars().score_thresh
         # final hyper-parameter-optimised fit (gpet.py:874-876), seed = seed + N_iter
-        if pre_fobs.shape[0] + self.N_inits <= 128:
+        if pre_fobs.shape[0] + self.N_inits <= 250:
             fits, _ = device_final_fits(b, [dict(self._p, seed=self.seed)], [pre_fobs], [n_iter])
             y_mean_optim, y_std, self._theta = fits[0]
         else:  # more training points than the LDS-resident LML kernel takes: host objective
@@ -233,7 +233,7 @@ class GP_Edge_Tracing(object):
 def device_final_fits(batch, ps, obs_list, iters, farm=None):
     """Converged fits (gpet.py:874) of every edge of a batch at once.
 
-    Host: standardisation of the <=128-point training sets (numpy, as the reference does it) and
+    Host: standardisation of the <=250-point training sets (numpy, as the reference does it) and
     scipy's own L-BFGS-B routine, driven in lock step for all (edge, restart) problems
     (``_lbfgsb_lockstep``, optionally spread over worker processes).  Device: every round of
     objective evaluations is one batched launch of the LML kernel (gpet_lml_batch), and the
@@ -336,10 +336,10 @@ class GP_Edge_Tracing_Batch(object):
                          p["fix_endpoints"], p["seed"] + iters[e]))
         if self._pool is not None and len(jobs) > 1:
             return self._pool.map(_final_fit_job, jobs)
-        if all(len(j[1]) + len(j[0]) <= 128 for j in jobs):
+        if all(len(j[1]) + len(j[0]) <= 250 for j in jobs):
             fits, self._fit_rounds = device_final_fits(b, self._ps, [j[1] for j in jobs], iters, self._farm)
             return fits
-        return [_final_fit_job(j) for j in jobs]  # > 128 training points: host objective
+        return [_final_fit_job(j) for j in jobs]  # > 250 training points: host objective
 
     def finish(self, iters):
         """Converged fits + rounding of the means to pixel indices (gpet.py:874-886) for every edge."""

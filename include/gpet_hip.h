@@ -198,7 +198,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
 
 /* ---- f2: converged fit (gpet.py:232-248; sklearn_gpr.py:254-295, 475-585) ----------------- */
 /* Upload edge e's standardised training set (x, y standardised as gpet.py:235-238 and
- * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= 128. */
+ * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= 250 (one 4x4 tile per thread up to 128 points, two beyond). */
 int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n);
 /* The same for every edge of the batch in one call: xs/ys/w are [B*stride], n [B]. */
 int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* ys, const double* w, const int32_t* n,

@@ -138,6 +138,75 @@ def test_many_observations_take_the_streamed_factor_path(amd, ctx):
     assert np.array_equal(tr(), et_o) and tr._n_iter == oinfo["n_iter"]
 
 
+@pytest.mark.parametrize("kernel,nu", [("RBF", 2.5), ("Matern", 2.5), ("Matern", 1.5)])
+@pytest.mark.parametrize("n", [129, 200, 250])
+def test_lml_objective_with_two_tiles_per_thread(amd, ctx, kernel, nu, n):
+    """128 < n <= 250 training points (delta_x = 2..3 on wide edges): the sweep kernel with two 4x4 tiles per thread
+    vs the oracle's Cholesky-based objective and gradient (sklearn_gpr.py:512-585)."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    N = 2 * n + 8
+    grad, truth = _image(N, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    ko = {'kernel': kernel, 'sigma_f': 40, 'length_scale': 12}
+    if kernel == "Matern":
+        ko['nu'] = nu
+    tr = amd.GP_Edge_Tracing(init, grad, kernel_options=ko, noise_y=1, N_samples=64, score_thresh=1, delta_x=2,
+                             keep_ratio=0.1, pixel_thresh=20, seed=4, fix_endpoints=True, _ctx=ctx)
+    rng = np.random.default_rng(n)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=n - 2, replace=False))
+    obs = np.stack([cols, truth[cols, 0] + rng.integers(-3, 4, size=n - 2)], axis=1)
+    pr = ff.prepare(tr.init, obs, tr.x_grid, tr.fix_endpoints)
+    assert pr["xs"].shape[0] == n
+    b = tr._batch
+    b.final_set_training(0, pr["xs"], pr["yt"], pr["w"])
+    th = ff.BOUNDS[:, 0] + (ff.BOUNDS[:, 1] - ff.BOUNDS[:, 0]) * rng.uniform(size=(24, 3))
+    th[:, 2] = np.log(rng.uniform(1e-3, 1.0, size=24))
+    th[0] = np.log([5.0, 5.0, 1.0])
+    th[1] = np.log([1.0, 1e-3, 1e-2])     # near-diagonal K
+    th[2] = np.log([10.0, 50.0, 1e-10])   # near-singular K: not positive definite or barely so
+    f, gr = b.lml_batch(np.zeros(24, dtype=np.int32), th)
+    finite = 0
+    for i in range(24):
+        lml, g_o = orc.lml_and_grad(th[i], pr["xs"], pr["yt"], pr["w"], tr.kernel_type, tr.kernel_nu)
+        if not np.isfinite(lml):
+            assert np.isinf(f[i]) and f[i] > 0
+            continue
+        if not np.isfinite(f[i]):
+            # pivots of the sweep and of LAPACK's Cholesky differ in the last bits: a matrix on the edge of
+            # positive definiteness may be rejected by one and not by the other
+            assert th[i, 2] < np.log(1e-6)
+            continue
+        finite += 1
+        np.testing.assert_allclose(f[i], -lml, rtol=1e-8, atol=1e-8)
+        # (ill-conditioned K at these sizes: the gradient is a difference of large traces -- compare to its norm)
+        np.testing.assert_allclose(gr[i], -g_o, rtol=1e-5, atol=1e-5 * (1 + np.abs(g_o).max()))
+    assert finite >= 20
+
+
+def test_converged_fit_on_device_beyond_128_points(amd, ctx):
+    """The converged fit of an edge with 129..250 observations runs in lock step on the device objective and
+    lands on the optimum of the host-side objective (scipy L-BFGS-B on the oracle's function)."""
+    from gaussian_process_edge_trace_amd.gpet import device_final_fits
+    from gaussian_process_edge_trace_amd._final_fit import converged_fit_predict
+    grad, truth = _image(320, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 12}, noise_y=1, N_samples=200,
+              score_thresh=1, delta_x=2, keep_ratio=0.1, pixel_thresh=20, seed=4, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    rng = np.random.default_rng(1)
+    cols = np.arange(1, 319, 2)
+    obs = np.stack([cols, truth[cols, 0] + rng.integers(-2, 3, size=cols.size)], axis=1)
+    assert 128 < obs.shape[0] + 2 <= 250
+    fits, _ = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [7])
+    mean, std, theta = fits[0]
+    m_h, s_h, th_h = converged_fit_predict(tr.init, obs, tr.x_grid, tr.kernel_type, tr.kernel_nu, tr.noise_y,
+                                           tr.fix_endpoints, tr.seed + 7)
+    np.testing.assert_allclose(theta[:2], th_h[:2], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.exp(theta[2]), np.exp(th_h[2]), rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(mean, m_h, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(std, s_h, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("shape,init", [((48, 64), [[7, 20], [55, 30]]),     # edge strictly inside a non-square image
                                         ((80, 50), [[0, 60], [49, 15]]),     # taller than wide, steep edge
                                         ((64, 64), [[3, 10], [40, 50]])])    # x_st > 0 and x_en < N - 1
