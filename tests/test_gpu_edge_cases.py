@@ -183,6 +183,55 @@ def test_lml_objective_with_two_tiles_per_thread(amd, ctx, kernel, nu, n):
     assert finite >= 20
 
 
+def test_lml_objective_every_size_class(amd, ctx):
+    """The objective kernel for training-set sizes across every launch shape: from 3 points, sizes around the multiples
+    of 4 where the tile count and the border move, one problem per edge with DIFFERENT n in one launch (the launch is
+    sized for the largest), single-problem launches.  vs the oracle."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    L = amd._lib
+    N = 520
+    grad, truth = _image(N, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    sizes = [3, 4, 5, 15, 16, 17, 28, 29, 44, 45, 60, 61, 63, 64, 76, 77, 92, 93, 99, 100, 108, 109, 124, 125, 128]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 12}, noise_y=1, N_samples=64, score_thresh=1,
+              delta_x=4, keep_ratio=0.1, pixel_thresh=20, fix_endpoints=True)
+    batch = amd.GP_Edge_Tracing_Batch([init] * len(sizes), grad.astype(np.float32), list(range(len(sizes))), **kw, _ctx=ctx)
+    b = batch._batch
+    rng = np.random.default_rng(7)
+    prs = []
+    for e, n in enumerate(sizes):
+        cols = np.sort(rng.choice(np.arange(1, N - 1), size=n - 2, replace=False))
+        obs = np.stack([cols, truth[cols, 0] + rng.integers(-3, 4, size=n - 2)], axis=1).reshape(-1, 2)
+        pr = ff.prepare(np.asarray(init)[np.argsort(np.asarray(init)[:, 0])], obs, np.arange(N), True)
+        assert pr["xs"].shape[0] == n
+        b.final_set_training(e, pr["xs"], pr["yt"], pr["w"])
+        prs.append(pr)
+    wrong = []
+    if True:
+        for group in (list(range(len(sizes))), [0, 1], [5, 6], [len(sizes) - 1]):  # mixed sizes / small launches
+            reps = 3
+            edge_of = np.repeat(np.array(group, dtype=np.int32), reps)
+            th = ff.BOUNDS[:, 0] + (ff.BOUNDS[:, 1] - ff.BOUNDS[:, 0]) * rng.uniform(size=(edge_of.size, 3))
+            th[:, 2] = np.log(rng.uniform(1e-2, 1.0, size=edge_of.size))
+            th[0] = np.log([5.0, 5.0, 1.0])
+            f, gr = b.lml_batch(edge_of, th)
+            for i, e in enumerate(edge_of):
+                pr = prs[e]
+                lml, g_o = orc.lml_and_grad(th[i], pr["xs"], pr["yt"], pr["w"], "RBF", 2.5)
+                assert np.isfinite(lml)
+                if not (np.allclose(f[i], -lml, rtol=1e-9, atol=1e-9) and
+                        np.allclose(gr[i], -g_o, rtol=1e-6, atol=1e-6 * (1 + np.abs(g_o).max()))):
+                    wrong.append((sizes[e], len(group), float(f[i]), float(-lml)))
+        assert not wrong, wrong
+        # not positive definite -> (+inf, 0) on both paths (sklearn_gpr.py:521-522): a negative noise level cannot be
+        # expressed in log space, so provoke it with duplicated inputs and no noise
+        th_bad = np.log(np.array([[1e3, 1e5, 1e-300]]))
+        f, gr = b.lml_batch(np.array([len(sizes) - 1], dtype=np.int32), th_bad)
+        lml, _ = orc.lml_and_grad(th_bad[0], prs[-1]["xs"], prs[-1]["yt"], prs[-1]["w"], "RBF", 2.5)
+        if not np.isfinite(lml):
+            assert np.isinf(f[0]) and f[0] > 0 and np.all(gr[0] == 0)
+
+
 def test_converged_fit_on_device_beyond_128_points(amd, ctx):
     """The converged fit of an edge with 129..250 observations runs in lock step on the device objective and
     lands on the optimum of the host-side objective (scipy L-BFGS-B on the oracle's function)."""
