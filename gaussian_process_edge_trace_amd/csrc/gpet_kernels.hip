@@ -3474,14 +3474,26 @@ __global__ void __launch_bounds__(256) k_pred_std_big(EdgeDev* edges) {
   E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
 }
 
+// hipFuncSetAttribute applies to the CURRENT device: remember per device what has been raised, so that one process
+// may hold contexts on several GPUs (the launchers run with the context's device current).
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 static void fit_predict_attrs() {
-  static bool attr_set = false;
-  if (attr_set) return;
+  static PerDeviceOnce once;
+  if (!once.first()) return;
   (void)hipFuncSetAttribute((const void*)k_fit<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void)hipFuncSetAttribute((const void*)k_fit<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void)hipFuncSetAttribute((const void*)k_predict<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void)hipFuncSetAttribute((const void*)k_predict<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  attr_set = true;
 }
 
 hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov, unsigned parts) {
@@ -3554,11 +3566,9 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     if (gpet_opt_block_jacobi()) {
       // two-level Jacobi: 32-column blocks, 64x64 sub-problems solved in LDS, rotations applied as MFMA GEMMs
       const int nblk = 2 * cdiv(r, 2 * BJ), t64 = cdiv(r, 64);
-      static bool bj_attr = false;
-      if (!bj_attr) {
+      static PerDeviceOnce bj_once;
+      if (bj_once.first())
         (void)hipFuncSetAttribute((const void*)k_bj_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        bj_attr = true;
-      }
       for (int sweep = 0; sweep < 24; ++sweep) {
         hipLaunchKernelGGL(k_jb_norms, dim3(jbn_parts, B), dim3(1024), 0, st, d_edges);
         hipLaunchKernelGGL(k_jb_norms_fin, dim3(B), dim3(64), 0, st, d_edges, jbn_parts);
@@ -3595,11 +3605,9 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;
     const size_t lds = (size_t)2 * mm * (mm | 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first())
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
-    }
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges, 0);
   }
   if (parts & 8u)
@@ -3611,12 +3619,11 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
   (void)hipGetLastError();
   fit_predict_attrs();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce once;
+  if (once.first()) {
     (void)hipFuncSetAttribute((const void*)k_struct_H, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     (void)hipFuncSetAttribute((const void*)k_struct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
   }
   if (!(parts & 1u)) {
   } else if (bd.n_cap <= 128)
@@ -3778,11 +3785,9 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
   if (parts & 1u) {
     const size_t lds = (size_t)(2 * SC_PAIRS + 1) * (bd.M | 1) * sizeof(float);
     if (lds <= 150 * 1024 && B * 1 > 0 && bd.S >= 64) {
-      static bool attr_set = false;
-      if (!attr_set) {
+      static PerDeviceOnce once;
+      if (once.first())
         (void)hipFuncSetAttribute((const void*)k_score_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-      }
       const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
       hipLaunchKernelGGL(k_score_tile, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
       hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
