@@ -358,7 +358,7 @@ def main():
                                "delta_x=5, pixel_thresh=5) x %d independent edges per GPU (config 4's batch of 256), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
                    "edges_per_gpu": E, "image": [N, N], "iterations_per_trace": iters[:4],
-                   "final_fit": ("scipy L-BFGS-B routine x13 starts in lock step (%d worker processes), objective = batched LML kernel on the GPU" % args.lbfgs_workers
+                   "final_fit": ("scipy L-BFGS-B routine x13 starts in lock step (%d worker processes), objective = batched LML kernel on the GPU" % n_lbfgs
                                  if args.fit_workers <= 1 else "host objective, %d worker processes" % args.fit_workers)},
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},

@@ -941,11 +941,12 @@ __global__ void __launch_bounds__(256) k_gram(EdgeDev* edges) {
 }
 
 // step 3 (fast path, r_cap <= 96): the same cyclic Jacobi with the Gram matrix and the
-// accumulated rotations resident in LDS (2 * m * (m|1) doubles <= 146 KB of the CU's 160 KB).
+// accumulated rotations resident in LDS (m * (m|1) + m * (m+2) doubles <= 146 KB of the CU's 160 KB).
 // A round applies its m/2 disjoint rotations as independent 2x2 blocks: block (a, b) holds the
 // four entries touched by the row rotation of pair a and the column rotation of pair b, so one
 // thread updates it in place (column rotation, then row rotation -- the arithmetic of the
-// sequential algorithm) and the whole round needs two barriers.  Odd ranks are padded with a
+// sequential algorithm) and the whole round needs two barriers: blocks | barrier | accumulated rotations on 15
+// waves while the 16th computes the rotation parameters of the next round | barrier.  Odd ranks are padded with a
 // decoupled zero row/column.  Row stride ld is odd: conflict-free row and column walks.
 __device__ __forceinline__ void rr_pair(int m1, int round, int k, int& p, int& q) {  // m1 = m - 1
   if (k == 0) {
@@ -964,26 +965,31 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
-  extern __shared__ double s_mem[];
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
   __shared__ double s_red[16];
-  __shared__ __attribute__((aligned(16))) double2 s_cs[64];  // (c, s) of the round: one 16-byte read per pair
+  __shared__ __attribute__((aligned(16))) double2 s_cs[2][64];  // (c, s) of a round, double-buffered: one 16-byte read per pair
   __shared__ int s_pos[96];
   const int r = sc->rank, ldg = E.r_cap;
   const int m = (r + 1) & ~1;
   const int ld = m | 1;
+  // The accumulated rotations are kept TRANSPOSED with an even stride: a column of the eigenvector matrix is a
+  // contiguous, 16-byte aligned run, so a thread rotates two rows per 16-byte LDS access (the LDS pipe -- ~8 cycles
+  // per wave access whatever its width -- is what bounds this kernel).
+  const int ldw = m + 2;
   double* A = s_mem;
-  double* W = s_mem + (size_t)m * ld;
+  double* W = s_mem + (size_t)m * ld;  // m * ld is even: 16-byte aligned
   const int tid = threadIdx.x, bs = blockDim.x;
   for (int e = tid; e < m * m; e += bs) {
     const int i = e / m, j = e - i * m;
     A[i * ld + j] = (i < r && j < r) ? E.C[(size_t)i * ldg + j] : 0.0;
-    W[i * ld + j] = (i == j) ? 1.0 : 0.0;
+    W[j * ldw + i] = (i == j) ? 1.0 : 0.0;
   }
   __syncthreads();
   const int half = m >> 1, m1 = m - 1;
   // fixed roles for the whole factorisation.  A: 2x2 blocks (pair a rows) x (pair b columns) of the UPPER
   // triangle of pairs, a <= b (the mirrored block is written, not recomputed): half (half + 1) / 2 blocks,
-  // one per thread for m <= 88.  W: (pair b, row segment) items, rows seg, seg + nseg, ...
+  // one per thread for m <= 88.  W: (pair b, segment of row PAIRS) items on the first 15 waves; the last wave
+  // computes the rotation parameters of the NEXT round meanwhile.
   const int nblk = half * (half + 1) / 2;
   int ba[2], bb[2];
 #pragma unroll
@@ -996,9 +1002,40 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
     ba[u] = e - b_ * (b_ + 1) / 2;
     if (e >= nblk) ba[u] = -1;
   }
-  const int nseg = half > 0 ? min(r, bs / half) : 1;
+  const int wthreads = bs - 64;  // W workers; threads wthreads .. bs-1 (one wave) own the rotation parameters
+  const int nseg = half > 0 ? min(half, wthreads / half) : 1;
   const int wb = tid / nseg, wseg = tid - wb * nseg;
-  const bool w_on = half > 0 && wb < half;
+  const bool w_on = half > 0 && tid < wthreads && wb < half;
+  const int pk = tid - wthreads;  // pair index of a parameter thread
+  // rotation parameters of pair pk for `round`, from the current A, into s_cs[round & 1]
+  auto params = [&](int round) {
+    if (pk >= 0 && pk < half) {
+      int p, q;
+      rr_pair(m1, round, pk, p, q);
+      double c = 1.0, s = 0.0;
+      const double apq = A[p * ld + q];
+      const double app = A[p * ld + p], aqq = A[q * ld + q];
+      if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
+        // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
+        // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
+        // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
+        const double d = aqq - app, hh = 2.0 * apq;
+        const double rho2 = d * d + hh * hh;
+        double y = __builtin_amdgcn_rsq(rho2);
+        y = y * (1.5 - 0.5 * rho2 * y * y);
+        const double den = fabs(d) + rho2 * y;
+        double iv = __builtin_amdgcn_rcp(den);
+        iv = iv * (2.0 - den * iv);
+        const double t = (d >= 0.0 ? hh : -hh) * iv;
+        const double u = 1.0 + t * t;
+        c = __builtin_amdgcn_rsq(u);
+        c = c * (1.5 - 0.5 * u * c * c);
+        c = c * (1.5 - 0.5 * u * c * c);
+        s = t * c;
+      }
+      s_cs[round & 1][pk] = make_double2(c, s);
+    }
+  };
   int sweeps = 0;
   if (r >= 2) {
     for (int sweep = 0; sweep < 40; ++sweep) {
@@ -1013,39 +1050,16 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
       // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
       if (off <= 1e-24 * dg || off == 0.0) break;
       ++sweeps;
+      params(0);
+      __syncthreads();
       for (int round = 0; round < m1; ++round) {
-        if (tid < half) {
-          int p, q;
-          rr_pair(m1, round, tid, p, q);
-          double c = 1.0, s = 0.0;
-          const double apq = A[p * ld + q];
-          const double app = A[p * ld + p], aqq = A[q * ld + q];
-          if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
-            // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
-            // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
-            // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
-            const double d = aqq - app, hh = 2.0 * apq;
-            const double rho2 = d * d + hh * hh;
-            double y = __builtin_amdgcn_rsq(rho2);
-            y = y * (1.5 - 0.5 * rho2 * y * y);
-            const double den = fabs(d) + rho2 * y;
-            double iv = __builtin_amdgcn_rcp(den);
-            iv = iv * (2.0 - den * iv);
-            const double t = (d >= 0.0 ? hh : -hh) * iv;
-            const double u = 1.0 + t * t;
-            c = __builtin_amdgcn_rsq(u);
-            c = c * (1.5 - 0.5 * u * c * c);
-            c = c * (1.5 - 0.5 * u * c * c);
-            s = t * c;
-          }
-          s_cs[tid] = make_double2(c, s);
-        }
-        __syncthreads();
+        const double2* cs = s_cs[round & 1];
+        // phase 1: the 2x2 blocks of A
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int a_ = ba[u], b_ = bb[u];
           if (a_ < 0) continue;
-          const double2 ra = s_cs[a_], rb = s_cs[b_];
+          const double2 ra = cs[a_], rb = cs[b_];
           const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
           if (sa == 0.0 && sb == 0.0) continue;
           int pa, qa, pb, qb;
@@ -1068,20 +1082,25 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
             A[qb * ld + qa] = n11;
           }
         }
-        // W: column rotations only
+        __syncthreads();
+        // phase 2: W (column rotations only, two rows per access) on the first 15 waves, while the last wave
+        // reads the updated A for the parameters of the next round
         if (w_on) {
-          const double2 rb = s_cs[wb];
+          const double2 rb = cs[wb];
           const double cb = rb.x, sb = rb.y;
           if (sb != 0.0) {
             int pb, qb;
             rr_pair(m1, round, wb, pb, qb);
-            for (int i = wseg; i < r; i += nseg) {
-              const double wp = W[i * ld + pb], wq = W[i * ld + qb];
-              W[i * ld + pb] = cb * wp - sb * wq;
-              W[i * ld + qb] = sb * wp + cb * wq;
+            double2* wp_ = reinterpret_cast<double2*>(W + pb * ldw);
+            double2* wq_ = reinterpret_cast<double2*>(W + qb * ldw);
+            for (int ip = wseg; ip < half; ip += nseg) {
+              const double2 wp = wp_[ip], wq = wq_[ip];
+              wp_[ip] = make_double2(cb * wp.x - sb * wq.x, cb * wp.y - sb * wq.y);
+              wq_[ip] = make_double2(sb * wp.x + cb * wq.x, sb * wp.y + cb * wq.y);
             }
           }
         }
+        if (round + 1 < m1) params(round + 1);
         __syncthreads();
       }
     }
@@ -1089,7 +1108,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
   for (int k = tid; k < r; k += bs) E.theta[k] = A[k * ld + k];
   for (int e = tid; e < r * r; e += bs) {
     const int i = e / r, j = e - i * r;
-    E.W[(size_t)i * ldg + j] = W[i * ld + j];
+    E.W[(size_t)i * ldg + j] = W[j * ldw + i];
   }
   __syncthreads();
   for (int k = tid; k < r; k += bs) {
@@ -1110,7 +1129,7 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
     for (int e = tid; e < r * r; e += bs) {
       const int i = e / r, j = e - i * r;
       const double th = A[j * ld + j];
-      E.G[(size_t)i * ldg + s_pos[j]] = W[i * ld + j] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+      E.G[(size_t)i * ldg + s_pos[j]] = W[j * ldw + i] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
     }
   }
   if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
@@ -3604,7 +3623,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   if (parts & 2u) hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
   if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;
-    const size_t lds = (size_t)2 * mm * (mm | 1) * sizeof(double);
+    const size_t lds = ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double);
     static PerDeviceOnce once;
     if (once.first())
       (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -3649,7 +3668,8 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   }
   if (parts & 4u) {
     const int mm = (bd.r_cap + 1) & ~1;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), (size_t)2 * mm * (mm | 1) * sizeof(double), st, d_edges, 1);
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double), st,
+                       d_edges, 1);
   }
   if (parts & 8u) {
     // the variant k_struct_rows picks for r0_max: [4 KS][16 MT + 1] eigenvector tile, reused as [r][64] products
