@@ -86,8 +86,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--edges", type=int, default=256,
-                    help="independent edges per GPU (BASELINE config 4 is a batch of 256 independent 500x500 edges)")
+    ap.add_argument("--edges", type=int, default=1024,
+                    help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges; "
+                         "measured on one MI355X: 256 edges 3.6 k traces/s, 512 4.0 k, 1024 4.2 k, 2048 4.2 k -- the loop's "
+                         "kernels are latency-bound below ~4 workgroups per CU)")
     ap.add_argument("--size", type=int, default=500)
     ap.add_argument("--fit-workers", type=int, default=int(os.environ.get("GPET_FIT_WORKERS", "0")),
                     help="0: final fits on the GPU (batched LML kernel); >1: host worker processes instead")
@@ -95,6 +97,9 @@ def main():
                     help="worker processes advancing scipy's L-BFGS-B routine in lock step (final fits)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1)")
+    ap.add_argument("--concurrent-steps", action="store_true",
+                    help="experiment: one driver thread per batch object (device loop + fits of a step back to back), "
+                         "so that device loops of different batch objects overlap too (measured: slower, DESIGN.md)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace the steps strictly one after the other (default: the converged fits of step k overlap "
                          "the device loop of step k+1 on a second batch object / HIP stream)")
@@ -119,7 +124,7 @@ def main():
     depth = max(1, args.pipeline_depth) if pipeline else 0
     n_farms = depth + 1 if pipeline else 1
     # one farm, one job slot per batch object: a fit running alone (the last of a run) gets every worker
-    big_farm = LockstepFarm(n_lbfgs, slots=n_farms) if (n_lbfgs > 1 and pool is None) else None
+    big_farm = LockstepFarm(n_lbfgs, slots=n_farms, pmax=max(16384, 13 * args.edges)) if (n_lbfgs > 1 and pool is None) else None
     farms = [big_farm.slot(i) if big_farm is not None else None for i in range(n_farms)]
     farm = farms[0]
     import torch
@@ -178,6 +183,7 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
     executor = ThreadPoolExecutor(max_workers=max(1, depth))
+    drivers = [ThreadPoolExecutor(max_workers=1) for _ in tracers] if args.concurrent_steps else []
 
     fit_walls = []  # wall time of every step's converged fits (they run concurrently with later device loops)
 
@@ -187,6 +193,20 @@ def main():
         loop_s = fit_s = 0.0
         iters_, traces_, pending = [], None, []
         fit_walls.clear()
+        if pipeline and args.concurrent_steps:
+            def one_step(tr__):
+                t_a = time.time()
+                tr__.reset()
+                it__ = tr__.run_loop()
+                t_m = time.time()
+                out_ = tr__.finish(it__)
+                return it__, out_, t_m - t_a, time.time() - t_m
+            futs = [drivers[k % len(tracers)].submit(one_step, tracers[k % len(tracers)]) for k in range(n_steps)]
+            for f_ in futs:
+                iters_, traces_, lw, fw = f_.result()
+                loop_s += lw
+                fit_walls.append(fw)
+            return loop_s, 0.0, iters_, traces_
         for k in range(n_steps):
             tr_ = tracers[k % len(tracers)]
             # a batch object is reused only after its previous fits (depth+1 steps ago) were collected
@@ -301,7 +321,7 @@ def main():
     kernel_ms["k_mt_normals"] = stage_ms["normals"] * ring
     alg["k_mt_normals"] = dict(flops=40.0 * S * zc * ring, bytes=8.0 * S * zc * ring)
     per_iter = {k: (v / ring if k == "k_mt_normals" else v) for k, v in kernel_ms.items()}
-    # dominant kernel of a step = largest device time per step of 256 traces, kernels timed alone: a loop kernel runs
+    # dominant kernel of a step = largest device time per step of E traces, kernels timed alone: a loop kernel runs
     # once per iteration of the trace, the LML kernel of the converged fits ~80 times per step (one launch per
     # lock-step round of the optimiser).  The LML kernel evaluates `evaluations` problems of n_fit points each:
     # n^3 flops (sweep of the bordered matrix, n^3 / 2 FMAs) and 3 n + 4 doubles of HBM traffic per evaluation.
@@ -355,7 +375,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE config 2 edge (500x500 sinusoidal image, RBF sigma_f=75 l=20, N_samples=1000, "
-                               "delta_x=5, pixel_thresh=5) x %d independent edges per GPU (config 4's batch of 256), "
+                               "delta_x=5, pixel_thresh=5) x %d independent edges per GPU and step (config 4's batch of independent edges, sized to fill the GPU), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
                    "edges_per_gpu": E, "image": [N, N], "iterations_per_trace": iters[:4],
                    "final_fit": ("scipy L-BFGS-B routine x13 starts in lock step (%d worker processes), objective = batched LML kernel on the GPU" % n_lbfgs

@@ -273,6 +273,13 @@ class LockstepFarm:
         saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
         for k in saved:
             os.environ[k] = "1"
+        # the workers are CPU-only (numpy + scipy's L-BFGS-B routine): start the fork server without a tool library a
+        # profiler may have preloaded into this process (rocprofv3's installs signal handlers the fork server cannot
+        # hand on to its children)
+        tool_env = [k for k in os.environ if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") or
+                    k.startswith("ROCPROF")]
+        for k in tool_env:
+            saved[k] = os.environ.pop(k)
         try:
             ctx = mp.get_context("forkserver")
             ctx.set_forkserver_preload(["numpy", "scipy.optimize"])

@@ -1,8 +1,9 @@
 """profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes of tools/prof_stages.py:
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_stages.py 256 2
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stages.py 256 2
-    python tools/make_traffic_profile.py 256 500
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_stages.py 1024 2
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stages.py 1024 2
+    (the same two passes over tools/prof_final.py 1024 0 into gpurun_out/pmc_lml_f, pmc_lml_w)
+    python tools/make_traffic_profile.py 1024 500        -- all of it: tools/refresh_profiles.sh
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half the
 bytes of a streaming read (MI355X_MICROARCH.md, HBM section); calibrated here on two kernels with a
@@ -20,7 +21,13 @@ def last(path, name):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name:
             acc[r["Kernel_Name"].split("(")[0].replace("gpet::", "").replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
-    return {k: v[-1] for k, v in acc.items()}  # last launch = the 256-edge profile launch
+    return {k: v[-1] for k, v in acc.items()}  # last launch = the full-batch profile launch
+
+
+def mean_of(path, name, kernel):
+    f = glob.glob(os.path.join(ROOT, path, "*", "*_counter_collection.csv"))[0]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
+    return sum(v) / len(v), len(v)
 
 
 def main():
@@ -33,12 +40,17 @@ def main():
             out["kernels"][k] = dict(fetch_size_kb=fe[k], write_size_kb=wr[k],
                                      hbm_bytes_per_launch=(2.0 * fe[k] + wr[k]) * 1024.0)
     # the LML kernel of the converged fits is not part of tools/prof_stages.py: its entry comes from two more PMC passes
-    # over `tools/prof_final.py 256 0` (gpurun_out/pmc_lml_f, pmc_lml_w), averaged over the launches; keep it if present
+    # over `tools/prof_final.py E 0` (gpurun_out/pmc_lml_f, pmc_lml_w), averaged over all its launches
     old_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(old_path):
-        old = json.load(open(old_path)).get("kernels", {})
-        if "k_lml" in old and "k_lml" not in out["kernels"]:
-            out["kernels"]["k_lml"] = old["k_lml"]
+    if glob.glob(os.path.join(ROOT, "gpurun_out/pmc_lml_f", "*", "*_counter_collection.csv")):
+        lf, lw = mean_of("gpurun_out/pmc_lml_f", "FETCH_SIZE", "k_lml"), mean_of("gpurun_out/pmc_lml_w", "WRITE_SIZE", "k_lml")
+        out["kernels"]["k_lml"] = dict(fetch_size_kb=lf[0], write_size_kb=lw[0], launches=lf[1],
+                                       hbm_bytes_per_launch=(2.0 * lf[0] + lw[0]) * 1024.0,
+                                       source="tools/prof_final.py %d 0: mean over the LML launches of one batch's converged fits" % E)
+    elif os.path.exists(old_path):
+        old = json.load(open(old_path))
+        if old.get("edges") == E and "k_lml" in old.get("kernels", {}):
+            out["kernels"]["k_lml"] = old["kernels"]["k_lml"]
     json.dump(out, open(old_path, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1)[:1500])
 
