@@ -47,6 +47,7 @@ struct gpet_batch {
                                        // latency-bound, and run while OTHER batches' loops keep the GPU busy
   hipEvent_t ev_norm[16] = {};
   hipEvent_t ev_gemm[16] = {};         // sample GEMM of iteration k done: ring slot k % ring may be refilled
+  hipEvent_t ev_pix[16] = {};          // pixel selection of iteration k done: the `done` flags of iteration k + 1 are final
   int norm_issued = 0;                 // iterations whose normals have been enqueued on `side`
   hipEvent_t ev_main = nullptr;
   unsigned int* d_minmax = nullptr;
@@ -164,6 +165,12 @@ extern "C" {
 int gpet_abi_version(void) { return GPET_ABI_VERSION; }
 
 int gpet_set_option(const char* name, int value) {
+  if (name && strcmp(name, "rng_lookahead") == 0) {
+    int& v = gpet_opt_rng_lookahead();
+    const int old = v;
+    v = value < 0 ? 0 : (value > 15 ? 15 : value);
+    return old;
+  }
   if (name && strcmp(name, "block_jacobi") == 0) {
     int& v = gpet_opt_block_jacobi();
     const int old = v;
@@ -433,6 +440,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   }
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_norm[i], hipEventDisableTiming));
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_gemm[i], hipEventDisableTiming));
+  for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_pix[i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
   float* d_raw = nullptr;
@@ -531,6 +539,8 @@ void gpet_batch_destroy(gpet_batch* b) {
     if (b->ev_norm[i]) (void)hipEventDestroy(b->ev_norm[i]);
   for (int i = 0; i < 16; ++i)
     if (b->ev_gemm[i]) (void)hipEventDestroy(b->ev_gemm[i]);
+  for (int i = 0; i < 16; ++i)
+    if (b->ev_pix[i]) (void)hipEventDestroy(b->ev_pix[i]);
   if (b->ev_main) (void)hipEventDestroy(b->ev_main);
   if (b->d_edge_of) (void)hipFree(b->d_edge_of);
   if (b->d_theta) (void)hipFree(b->d_theta);
@@ -1036,12 +1046,18 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
-  // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs ahead of
-  // the loop on its own HIP stream -- one launch per iteration, at most `look` iterations ahead (an edge
-  // that finishes wastes at most that many), never past this call's horizon; a ring slot is refilled
-  // only after the sample GEMM that read it (16 iterations earlier) has completed.
+  // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs ahead of the loop on
+  // its own HIP stream, one launch per iteration, `look` iterations ahead (gpet_set_option("rng_lookahead", n), default
+  // 1: the draws of iteration k+1 are enqueued when iteration k starts and run next to it), never past this call's
+  // horizon.  An edge that finishes still gets the draws already enqueued for it, so a deeper look-ahead only wastes
+  // generator work (n = 4: 19 % of it; measured loop time of a batch alone: n = 1, 2, 4 within 1 %).  n = 0 orders the
+  // draws of iteration k after the pixel selection of iteration k-1 -- nothing is drawn for finished edges, but the
+  // generator then competes with the eigen-solver for the start of every iteration: 187 instead of 179 ms per loop of
+  // 1024 edges, 70 instead of 56 ms at 256.  A ring slot is refilled only after the sample GEMM that read it (one ring
+  // earlier) has completed.
   const int ring = b->bd.z_ring;
-  const int look = ring > 4 ? 4 : ring - 1;
+  int look = gpet_opt_rng_lookahead();
+  if (look > ring - 1) look = ring - 1;
   const int first = b->iters_issued, horizon = first + max_iters;
   if (b->norm_issued < first) b->norm_issued = first;
   HIPCHK(c, hipEventRecord(b->ev_main, c->stream));  // the seeds are on the device
@@ -1051,7 +1067,11 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     const int cur = first + it;
     while (b->norm_issued <= cur + look && b->norm_issued < horizon) {
       const int j = b->norm_issued;
-      if (j - ring >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
+      if (look == 0) {
+        if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));
+      } else if (j - ring >= first) {
+        HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
+      }
       HIPCHK(c, launch_normals(b->side, b->d_edges, b->B, b->d_seeds, 1, j, 1));
       HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
       b->norm_issued = j + 1;
@@ -1069,6 +1089,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
     HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1));
     HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd, 1));
+    HIPCHK(c, hipEventRecord(b->ev_pix[cur % 16], c->stream));
     b->iters_issued += 1;
   }
   b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = (max_iters > 0) || b->have_fit;

@@ -28,6 +28,9 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
 // process-wide switch (gpet_set_option "block_jacobi"; initial value from the environment GPET_JB_BLOCK)
 int& gpet_opt_block_jacobi();
+// gpet_set_option "rng_lookahead" (default 1; environment GPET_RNG_LOOKAHEAD): how many iterations the RNG stream of
+// the device loop may run ahead of it (gpet_api.hip, gpet_trace_iterate)
+int& gpet_opt_rng_lookahead();
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);

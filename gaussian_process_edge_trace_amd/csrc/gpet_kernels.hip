@@ -3562,6 +3562,11 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
   return hipGetLastError();
 }
 
+int& gpet_opt_rng_lookahead() {
+  static int v = getenv("GPET_RNG_LOOKAHEAD") != nullptr ? atoi(getenv("GPET_RNG_LOOKAHEAD")) : 1;
+  return v;
+}
+
 int& gpet_opt_block_jacobi() {
   static int v = getenv("GPET_JB_BLOCK") != nullptr ? 1 : 0;
   return v;

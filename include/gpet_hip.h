@@ -120,7 +120,10 @@ int gpet_abi_version(void);
  * for full-rank posterior covariances (Matern: ~5x faster per iteration at 1024 columns, an equally valid eigen-
  * decomposition, but traces stop matching a LAPACK-based run after a few iterations -- the sampler is chaotic in
  * 1e-12 perturbations there); 0 (default, or environment GPET_JB_BLOCK unset) keeps the scalar rounds the parity
- * tests are passed with.  Returns the previous value, or -1 for an unknown name. */
+ * tests are passed with.  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
+ * run ahead of it (default 1; 0: it starts when the previous iteration's pixel selection is done, so nothing is drawn for
+ * finished edges, but it then delays the start of every iteration; larger n only adds draws for edges that finish
+ * meanwhile; results are identical).  Returns the previous value, or -1 for an unknown name. */
 int gpet_set_option(const char* name, int value);
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
  * to let the library create its own. */

@@ -14,7 +14,7 @@ N = 500
 img, truth = bench.synth_image(N, 3)
 init = truth[[0, -1], :][:, [1, 0]]
 grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
-E = 256
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 seeds = [1 + e for e in range(E)]
 tr = pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **bench.README_KW, _ctx=ctx)
 tr.reset(); it = tr.run_loop()
@@ -37,3 +37,11 @@ for k in range(1, 15):
     tr._batch.iterate(seeds, k)
     sc = tr._batch.all_scalars()
     print("  k=%2d n_obs=%3d sweeps" % (k, sc[0].n), [int(s.lml) for s in sc[:8]], "max over batch", max(int(s.lml) for s in sc), flush=True)
+for look in (0, 1, 2, 4):
+    pkg._lib.set_option("rng_lookahead", look)
+    ts = []
+    for _ in range(5):
+        tr.reset(); ctx.sync()
+        t0 = time.time(); tr.run_loop(); ts.append(time.time() - t0)
+    print("rng_lookahead=%d: run_loop %.1f ms" % (look, 1e3 * min(ts)), flush=True)
+pkg._lib.set_option("rng_lookahead", 0)
