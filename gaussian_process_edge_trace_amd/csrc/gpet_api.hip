@@ -30,6 +30,10 @@ struct gpet_batch {
   std::vector<EdgeDev> h_edges;
   std::vector<gpet_params> params;
   EdgeDev* d_edges = nullptr;
+  EdgeDev* d_edges_act = nullptr;      // the edges still running, compacted (gpet_trace_iterate)
+  unsigned int* d_seeds_act = nullptr;
+  std::vector<EdgeDev> h_edges_act;
+  std::vector<unsigned int> h_seeds_act;
   char* arena = nullptr;
   size_t arena_bytes = 0;
   unsigned int* d_seeds = nullptr;
@@ -521,6 +525,8 @@ void gpet_batch_destroy(gpet_batch* b) {
   (void)hipStreamSynchronize(b->ctx->stream);
   if (b->arena) (void)hipFree(b->arena);
   if (b->d_edges) (void)hipFree(b->d_edges);
+  if (b->d_edges_act) (void)hipFree(b->d_edges_act);
+  if (b->d_seeds_act) (void)hipFree(b->d_seeds_act);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
   if (b->ev_l0) (void)hipEventDestroy(b->ev_l0);
@@ -1048,56 +1054,102 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, base_seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
   // Normals: the seeds of upcoming iterations are known (gpet.py:839), so the RNG stream runs ahead of the loop on
   // its own HIP stream, one launch per iteration, `look` iterations ahead (gpet_set_option("rng_lookahead", n), default
-  // 1: the draws of iteration k+1 are enqueued when iteration k starts and run next to it), never past this call's
-  // horizon.  An edge that finishes still gets the draws already enqueued for it, so a deeper look-ahead only wastes
-  // generator work (n = 4: 19 % of it; measured loop time of a batch alone: n = 1, 2, 4 within 1 %).  n = 0 orders the
-  // draws of iteration k after the pixel selection of iteration k-1 -- nothing is drawn for finished edges, but the
-  // generator then competes with the eigen-solver for the start of every iteration: 187 instead of 179 ms per loop of
-  // 1024 edges, 70 instead of 56 ms at 256.  A ring slot is refilled only after the sample GEMM that read it (one ring
-  // earlier) has completed.
+  // 1: the draws of iteration k+1 are enqueued when iteration k starts and run next to it), never past the horizon of
+  // the iterations enqueued together.  An edge that finishes still gets the draws already enqueued for it, so a deeper
+  // look-ahead only wastes generator work (n = 4: 19 % of it; measured loop time of a batch alone: n = 1, 2, 4 within
+  // 1 %).  n = 0 orders the draws of iteration k after the pixel selection of iteration k-1 -- nothing is drawn for
+  // finished edges, but the generator then competes with the eigen-solver for the start of every iteration: 187 instead
+  // of 179 ms per loop of 1024 edges, 70 instead of 56 ms at 256.  A ring slot is refilled only after the sample GEMM
+  // that read it (one ring earlier) has completed.
   const int ring = b->bd.z_ring;
   int look = gpet_opt_rng_lookahead();
   if (look > ring - 1) look = ring - 1;
-  const int first = b->iters_issued, horizon = first + max_iters;
-  if (b->norm_issued < first) b->norm_issued = first;
-  HIPCHK(c, hipEventRecord(b->ev_main, c->stream));  // the seeds are on the device
-  HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_main, 0));
-  for (int it = 0; it < max_iters; ++it) {
-    // every kernel skips edges whose `done` flag is set, so finished edges cost nothing.
-    const int cur = first + it;
-    while (b->norm_issued <= cur + look && b->norm_issued < horizon) {
-      const int j = b->norm_issued;
-      if (look == 0) {
-        if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));
-      } else if (j - ring >= first) {
-        HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
-      }
-      HIPCHK(c, launch_normals(b->side, b->d_edges, b->B, b->d_seeds, 1, j, 1));
-      HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
-      b->norm_issued = j + 1;
-    }
-    if (b->structured) {
-      HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd));
-    } else {
-      HIPCHK(c, launch_fit_predict(c->stream, b->d_edges, b->B, b->bd, 1));
-      HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
-    }
-    HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
-    HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0));
-    HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
-    HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd));
-    // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
-    HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1));
-    HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd, 1));
-    HIPCHK(c, hipEventRecord(b->ev_pix[cur % 16], c->stream));
-    b->iters_issued += 1;
+  // The iterations are enqueued in groups of 8, then 4 and -- once the first edges have finished -- 2: after every
+  // group the host reads the `done` flags, stops if no edge is left and otherwise launches the next group on a
+  // COMPACTED copy of the edge table (only the edges still running).  Every kernel skips finished edges by itself, but
+  // it still starts one workgroup per edge and tile to find that out: 2.2 ms per iteration for 1024 finished edges, and
+  // the last iterations of a batch run with a handful of edges left.
+  int remaining = max_iters, group = 8, active = b->B;
+  bool flags_known = false;
+  *n_active = b->B;
+  if (max_iters == 0) {
+    int rc0 = check_device_status(b);
+    if (rc0) return rc0;
+    active = 0;
+    for (int e = 0; e < b->B; ++e) active += b->h_scalars[e].done ? 0 : 1;
+    *n_active = active;
+    return GPET_OK;
   }
-  b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = (max_iters > 0) || b->have_fit;
-  int rc = check_device_status(b);
-  if (rc) return rc;
-  int active = 0;
-  for (int e = 0; e < b->B; ++e) active += b->h_scalars[e].done ? 0 : 1;
-  *n_active = active;
+  while (remaining > 0) {
+    const int n_it = group < remaining ? group : remaining;
+    EdgeDev* edges_l = b->d_edges;
+    unsigned int* seeds_l = b->d_seeds;
+    int B_l = b->B;
+    if (flags_known && active < b->B) {
+      b->h_edges_act.clear();
+      b->h_seeds_act.clear();
+      for (int e = 0; e < b->B; ++e)
+        if (!b->h_scalars[e].done) {
+          b->h_edges_act.push_back(b->h_edges[e]);
+          b->h_seeds_act.push_back(base_seeds[e]);
+        }
+      B_l = (int)b->h_edges_act.size();
+      if (!b->d_edges_act) {
+        HIPCHK(c, hipMalloc(&b->d_edges_act, sizeof(EdgeDev) * b->B));
+        HIPCHK(c, hipMalloc(&b->d_seeds_act, sizeof(unsigned int) * b->B));
+      }
+      // (the previous group has completed -- check_device_status synchronised -- so the tables may be overwritten)
+      HIPCHK(c, hipMemcpyAsync(b->d_edges_act, b->h_edges_act.data(), sizeof(EdgeDev) * B_l, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(b->d_seeds_act, b->h_seeds_act.data(), sizeof(unsigned int) * B_l, hipMemcpyHostToDevice, c->stream));
+      edges_l = b->d_edges_act;
+      seeds_l = b->d_seeds_act;
+    }
+    const int first = b->iters_issued, horizon = first + n_it;
+    if (b->norm_issued < first) b->norm_issued = first;
+    HIPCHK(c, hipEventRecord(b->ev_main, c->stream));  // the seeds and the edge table are on the device
+    HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_main, 0));
+    for (int it = 0; it < n_it; ++it) {
+      // every kernel skips edges whose `done` flag is set, so edges that finish inside a group cost little.
+      const int cur = first + it;
+      while (b->norm_issued <= cur + look && b->norm_issued < horizon) {
+        const int j = b->norm_issued;
+        if (look == 0) {
+          if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));
+        } else if (j - ring >= first) {
+          HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
+        }
+        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, 1));
+        HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
+        b->norm_issued = j + 1;
+      }
+      if (b->structured) {
+        HIPCHK(c, launch_struct_iteration(c->stream, edges_l, B_l, b->bd));
+      } else {
+        HIPCHK(c, launch_fit_predict(c->stream, edges_l, B_l, b->bd, 1));
+        HIPCHK(c, launch_factor(c->stream, edges_l, B_l, b->bd));
+      }
+      HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
+      HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, b->structured ? b->bd.r0_max : 0));
+      HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
+      HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
+      // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
+      HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
+      HIPCHK(c, launch_pixels(c->stream, edges_l, B_l, b->bd, 1));
+      HIPCHK(c, hipEventRecord(b->ev_pix[cur % 16], c->stream));
+      b->iters_issued += 1;
+    }
+    b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = true;
+    HIPCHK(c, hipStreamSynchronize(b->side));  // (its launches read the compacted tables too)
+    int rc = check_device_status(b);
+    if (rc) return rc;
+    active = 0;
+    for (int e = 0; e < b->B; ++e) active += b->h_scalars[e].done ? 0 : 1;
+    flags_known = true;
+    *n_active = active;
+    remaining -= n_it;
+    if (active == 0) break;
+    group = active == b->B ? (group < 4 ? group : 4) : 2;
+  }
   return GPET_OK;
 }
 

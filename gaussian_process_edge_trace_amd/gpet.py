@@ -311,23 +311,19 @@ class GP_Edge_Tracing_Batch(object):
     def reset(self):
         self._batch.reset()
 
-    def run_loop(self, max_iter=1000, chunk=8):
+    def run_loop(self, max_iter=1000, chunk=64):
         """The device-resident while-loops of all edges (gpet.py:829-870); returns iterations per edge.
 
-        The loop is advanced `chunk` iterations per library call while every edge is still running, then 4 and, once
-        the first edges have finished, 2 at a time: the host only learns how many edges are left when a call returns,
-        and an iteration enqueued for a batch that has finished is not free (every kernel still launches one
-        workgroup per edge and tile to find its edge done: 2.2 ms per iteration at 1024 edges)."""
+        One library call advances the loop by up to `chunk` iterations and returns as soon as every edge has finished
+        (gpet_trace_iterate enqueues the iterations in shrinking groups and checks the `done` flags in between)."""
         b = self._batch
         n_active = self.B
         done_iters = 0
-        step = max(1, int(chunk))
         while n_active > 0:
-            n_active = b.iterate(self.seeds, step)
-            done_iters += step
+            n_active = b.iterate(self.seeds, chunk)
+            done_iters += chunk
             if done_iters >= max_iter and n_active > 0:
                 raise _lib.GpetError(_lib.ERR_ITER_CAP, f"{n_active} edges did not converge in {max_iter} iterations")
-            step = min(step, 4) if n_active == self.B else min(step, 2)
         return self._iters()
 
     def _iters(self):

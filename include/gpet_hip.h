@@ -196,7 +196,9 @@ int gpet_select_pixels_only(gpet_batch* b);
 /* ---- a8: the outer loop (gpet.py:829-870) ---------------------------------------------- */
 /* Runs up to max_iters iterations of fit->factor->normals->sample->score->pixels for every
  * edge that is not done; seed of iteration k (0-based) of edge e is base_seed[e] + k + 1
- * (gpet.py:839).  Returns the number of edges still not done in *n_active. */
+ * (gpet.py:839).  The iterations are enqueued in groups (8, 4, then 2 once edges start to finish); after
+ * each group the `done` flags are read, the call returns early when no edge is left, and the next group is
+ * launched over the edges still running only.  Returns the number of edges still not done in *n_active. */
 int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active);
 
 /* ---- f2: converged fit (gpet.py:232-248; sklearn_gpr.py:254-295, 475-585) ----------------- */
