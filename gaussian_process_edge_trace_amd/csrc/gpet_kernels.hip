@@ -1922,6 +1922,7 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
 // blockIdx.x = how many iterations ahead of the edge's current one this stream belongs to: the
 // seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
 // generated by one launch, one workgroup per (iteration, edge).
+#define MTQ_CAP 512  // ring of pending (r2, x1, x2, destinations) records: < 64 left over + 156 per block + slack
 __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
                                                     int iter_abs) {
 #pragma clang fp contract(off)
@@ -1934,8 +1935,12 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   double* __restrict__ Zs = E.Z + (size_t)(iter_idx % E.z_ring) * ((size_t)E.S * E.z_cols);
   __shared__ unsigned int s_mt[2][624];
   __shared__ int s_cnt[2][4];
+  __shared__ int s_qtail;  // records queued so far (monotonic; slots are taken with one LDS atomic per wave)
+  __shared__ double q_r2[MTQ_CAP], q_x1[MTQ_CAP], q_x2[MTQ_CAP];
+  __shared__ int q_d0[MTQ_CAP], q_d1[MTQ_CAP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
+    s_qtail = 0;
     // seed of iteration k (0-based) = base + k + 1 (gpet.py:839)
     unsigned int p = seeds[blockIdx.y] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);
     s_mt[0][0] = p;
@@ -1945,10 +1950,24 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     }
   }
   __syncthreads();
-  const long long total = (long long)E.S * E.Lg;
+  const int Lg = E.Lg, zc = E.z_cols;
+  const long long total = (long long)E.S * Lg;
   const long long need_pairs = (total + 1) / 2;
+  // Only the first z_cols normals of every sample row are stored, but every attempt's accept/reject decision is
+  // needed (it positions the rest of the stream).  When few are stored (z_cols << Lg: the structured loop path keeps
+  // ~1 in 7) the log/sqrt of the stored ones would still run in every wave of every block, so those pairs are queued
+  // in LDS and the fourth wave -- idle during the attempts -- evaluates them 64 at a time; when most are stored
+  // they are evaluated in place.
+  const bool queued = 2 * zc <= Lg;
   long long done_pairs = 0;
+  int row0 = 0, col0 = 0;  // (row, column) of the normal at stream position 2 * done_pairs
+  int q_popped = 0;  // records evaluated so far (same value in every thread)
   int cur = 0, it = 0;
+  auto emit = [&](double r2, double x1, double x2, int d0, int d1) {
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    if (d0 >= 0) Zs[d0] = f * x2;
+    if (d1 >= 0) Zs[d1] = f * x1;
+  };
   while (done_pairs < need_pairs) {
     unsigned int* o = s_mt[cur];
     unsigned int* nw = s_mt[cur ^ 1];
@@ -1959,9 +1978,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
     if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
     __syncthreads();
-    // 156 polar attempts.  Every attempt's accept/reject decision is needed (it positions the
-    // rest of the stream), but the log/sqrt only for the normals that are actually stored
-    // (columns < z_cols of each sample row).
+    // 156 polar attempts on waves 0-2; wave 3 drains the queue of the previous blocks meanwhile
     bool ok = false;
     double x1 = 0.0, x2 = 0.0, r2 = 1.0;
     if (tid < 156) {
@@ -1974,6 +1991,18 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
       r2 = x1 * x1 + x2 * x2;
       ok = !(r2 >= 1.0 || r2 == 0.0);
     }
+    if (queued) {
+      // (s_qtail is only written after the barrier below, so every thread reads the same value here)
+      const int pops = (s_qtail - q_popped) >> 6;  // whole groups of 64 pending records
+      if (w == 3) {
+        for (int g = 0; g < pops; ++g) {
+          const int i = (q_popped + 64 * g + lane) & (MTQ_CAP - 1);
+          emit(q_r2[i], q_x1[i], q_x2[i], q_d0[i], q_d1[i]);
+        }
+      }
+      q_popped += 64 * pops;
+    }
+    // position of this attempt's pair in the stream and whether any of its two normals is stored
     const unsigned long long bal = __ballot(ok);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) s_cnt[it & 1][w] = __popcll(bal);
@@ -1984,28 +2013,66 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
       if (q < w) base += cq;
       tot += cq;
     }
+    bool need = false;
+    int d0 = -1, d1 = -1;
+    // (pairs still wanted, as a 32-bit number: the 64-bit stream position stays in wave-uniform registers)
+    const long long rem64 = need_pairs - done_pairs;
+    const int rem = rem64 > 1024 ? 1024 : (int)rem64;
+    const bool odd_total = (total & 1LL) != 0;
     if (ok) {
-      const long long q0 = 2 * (done_pairs + base + before);
-      if (q0 < total) {
-        const int srow = (int)(q0 / E.Lg);
-        const int col0 = (int)(q0 - (long long)srow * E.Lg);
-        int srow1 = srow, col1 = col0 + 1;
-        if (col1 == E.Lg) {
-          col1 = 0;
-          srow1 = srow + 1;
+      const int k = base + before;  // k-th accepted pair of this block
+      if (k < rem) {
+        int col = col0 + 2 * k, row = row0;
+        while (col >= Lg) {
+          col -= Lg;
+          ++row;
         }
-        const bool w0 = col0 < E.z_cols;
-        const bool w1 = (q0 + 1 < total) && (col1 < E.z_cols);
-        if (w0 || w1) {
-          const double f = sqrt(-2.0 * log(r2) / r2);
-          if (w0) Zs[(size_t)srow * E.z_cols + col0] = f * x2;
-          if (w1) Zs[(size_t)srow1 * E.z_cols + col1] = f * x1;
+        int row1 = row, col1 = col + 1;
+        if (col1 == Lg) {
+          col1 = 0;
+          row1 = row + 1;
+        }
+        const bool last_odd = odd_total && (k == rem - 1) && rem64 <= 1024;  // the stream ends on the first normal of the pair
+        if (col < zc) d0 = row * zc + col;
+        if (!last_odd && col1 < zc) d1 = row1 * zc + col1;
+        need = (d0 >= 0) || (d1 >= 0);
+      }
+    }
+    if (!queued) {
+      if (need) emit(r2, x1, x2, d0, d1);
+    } else {
+      const unsigned long long nb = __ballot(need);
+      if (nb != 0ull) {  // (wave-uniform)
+        const int nbefore = __popcll(nb & ((1ull << lane) - 1ull));
+        int wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&s_qtail, __popcll(nb));
+        wbase = __shfl(wbase, 0);
+        if (need) {
+          const int i = (wbase + nbefore) & (MTQ_CAP - 1);
+          q_r2[i] = r2;
+          q_x1[i] = x1;
+          q_x2[i] = x2;
+          q_d0[i] = d0;
+          q_d1[i] = d1;
         }
       }
     }
     done_pairs += tot;
+    col0 += 2 * tot;
+    while (col0 >= Lg) {
+      col0 -= Lg;
+      ++row0;
+    }
     cur ^= 1;
     ++it;
+  }
+  if (queued) {  // what is left in the queue (fewer than 64 + 156 records)
+    __syncthreads();
+    const int left = s_qtail - q_popped;
+    for (int i = tid; i < left; i += blockDim.x) {
+      const int j = (q_popped + i) & (MTQ_CAP - 1);
+      emit(q_r2[j], q_x1[j], q_x2[j], q_d0[j], q_d1[j]);
+    }
   }
 }
 

@@ -100,6 +100,42 @@ def test_normals_stream(amd, ctx, golden, name):
     np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
 
 
+@pytest.mark.parametrize("name,z_cols", [("stage_rbf500", 96), ("stage_rbf500", 250), ("stage_rbf500", 251),
+                                         ("stage_rbf65", 16), ("stage_rbf64", 1)])
+def test_normals_stream_sparse_columns(amd, ctx, golden, name, z_cols):
+    """Only the first z_cols normals of every sample row are kept (the structured loop path needs the factor's rank
+    many): the kept ones must be the reference stream's -- the queued evaluation (z_cols <= N/2) and the in-place one
+    (above), odd widths where a pair straddles two rows, a single kept column."""
+    g = golden(name)
+    L = amd._lib
+    tr = _tracer(amd, ctx, g, name, z_cols=z_cols)
+    b = tr._batch
+    seed = int(g["in_gp_seed"])
+    b.normals([seed])
+    Z = b.read(L.BUF_NORMALS)
+    S = Z.shape[0]
+    N = int(g["ref_scalars"][8])
+    assert Z.shape[1] == z_cols
+    ref = orc.legacy_standard_normal(seed, S * N).reshape(S, N)[:, :z_cols]
+    np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
+
+
+@pytest.mark.parametrize("z_cols", [65, 20])
+def test_normals_stream_odd_count(amd, ctx, golden, z_cols):
+    """151 samples x 65 columns: an odd number of normals, so the last polar pair contributes only its first value."""
+    g = golden("stage_rbf65")
+    L = amd._lib
+    kw = dict(CTOR["stage_rbf65"], N_samples=151)
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **kw, _ctx=ctx, z_cols=z_cols)
+    b = tr._batch
+    seed = 12345
+    b.normals([seed])
+    Z = b.read(L.BUF_NORMALS)
+    assert Z.shape == (151, z_cols)
+    ref = orc.legacy_standard_normal(seed, 151 * 65).reshape(151, 65)[:, :z_cols]
+    np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
+
+
 @pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96"])
 def test_sample_T2_injected_factor(amd, ctx, golden, name):
     """T2: with the reference's factor sqrt(s)*v injected, samples match the reference."""
