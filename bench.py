@@ -55,7 +55,7 @@ def cpu_baseline(N, img_seed, n_traces, per_curve=True):
     grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
     init = edge[[0, -1], :][:, [1, 0]]
     best = None
-    for threads in (1, min(16, os.cpu_count() or 1)):
+    for threads in (1, min(16, usable_cpus())):
         with threadpool_limits(limits=threads):
             t0 = time.time()
             iters = []
@@ -81,6 +81,23 @@ def log(msg):
 T_START = time.time()
 
 
+def usable_cpus():
+    """CPUs this job may actually use: the smallest of the machine's count, the affinity mask and the cgroup quota
+    (a container with `cpu.max = 1600000 100000` on a 256-thread host has 16)."""
+    n = os.cpu_count() or 2
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(2, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +110,7 @@ def main():
     ap.add_argument("--size", type=int, default=500)
     ap.add_argument("--fit-workers", type=int, default=int(os.environ.get("GPET_FIT_WORKERS", "0")),
                     help="0: final fits on the GPU (batched LML kernel); >1: host worker processes instead")
-    ap.add_argument("--lbfgs-workers", type=int, default=max(1, min(12, (os.cpu_count() or 2) - 2)),
+    ap.add_argument("--lbfgs-workers", type=int, default=max(1, min(12, usable_cpus() - 2)),
                     help="worker processes advancing scipy's L-BFGS-B routine in lock step (final fits)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
                     help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1)")
@@ -119,7 +136,7 @@ def main():
     pool = make_fit_pool(args.fit_workers) if args.fit_workers > 1 else None
     # L-BFGS-B state machines of the final fits advance in worker processes (the objective runs on
     # the GPU); also created before HIP is initialised
-    n_lbfgs = max(2, min(args.lbfgs_workers, ((os.cpu_count() or 2) - 2) // max(1, world))) if args.lbfgs_workers > 1 else 0
+    n_lbfgs = max(2, min(args.lbfgs_workers, (usable_cpus() - 2) // max(1, world))) if args.lbfgs_workers > 1 else 0
     pipeline = (not args.no_pipeline) and pool is None
     depth = max(1, args.pipeline_depth) if pipeline else 0
     n_farms = depth + 1 if pipeline else 1
