@@ -169,6 +169,12 @@ extern "C" {
 int gpet_abi_version(void) { return GPET_ABI_VERSION; }
 
 int gpet_set_option(const char* name, int value) {
+  if (name && strcmp(name, "lml_two_tiles_from") == 0) {
+    int& v = gpet_opt_lml_two_tiles_from();
+    const int old = v;
+    v = value < 1 ? 1 : value;
+    return old > 0x3fffffff ? 0x3fffffff : old;
+  }
   if (name && strcmp(name, "rng_lookahead") == 0) {
     int& v = gpet_opt_rng_lookahead();
     const int old = v;

@@ -31,6 +31,9 @@ int& gpet_opt_block_jacobi();
 // gpet_set_option "rng_lookahead" (default 1; environment GPET_RNG_LOOKAHEAD): how many iterations the RNG stream of
 // the device loop may run ahead of it (gpet_api.hip, gpet_trace_iterate)
 int& gpet_opt_rng_lookahead();
+// gpet_set_option "lml_two_tiles_from" (default 600; environment GPET_LML_TWO_TILES_FROM): launches of the converged fits' objective with at least this many problems use
+// the two-tiles-per-thread kernel also below 129 training points (fewer instructions per problem, longer latency)
+int& gpet_opt_lml_two_tiles_from();
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);

@@ -3299,7 +3299,7 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
 #define LML2_MAXD 260
 __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                                double* g_out) {
-  constexpr int SLOTS = 2;
+  constexpr int SLOTS = 2;  // (three and four tiles per thread were measured: 163 / 203 VGPRs, 6-40 % slower)
   const int pb = blockIdx.x;
   const EdgeDev E = edges[edge_of[pb]];
   const int n = E.fin_n;
@@ -3475,7 +3475,10 @@ hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const 
                       double* d_f, double* d_g) {
   (void)hipGetLastError();
   if (n_max > 250) return hipErrorInvalidValue;
-  if (n_max > 128) {  // two tiles per thread
+  // two tiles per thread: the only form above 128 training points, and the faster one for big launches (fewer
+  // instructions per problem: 109 instead of 134 us at 900 problems of 98 points, 1.07 instead of 1.41 ms at 13312) --
+  // small launches are latency-bound and keep one tile per thread (64 instead of 80 us at 256 problems)
+  if (n_max > 128 || gpet_opt_lml_two_tiles_from() <= P) {
     const int nb2 = (n_max + 1 + 3) >> 2;
     const int tiles = nb2 * (nb2 + 1) / 2;
     int threads = (((tiles + 1) / 2 + 63) / 64) * 64;
@@ -3627,6 +3630,11 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
   else
     hipLaunchKernelGGL((k_predict<false, true>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, bd.Lg);
   return hipGetLastError();
+}
+
+int& gpet_opt_lml_two_tiles_from() {
+  static int v = getenv("GPET_LML_TWO_TILES_FROM") != nullptr ? atoi(getenv("GPET_LML_TWO_TILES_FROM")) : 600;
+  return v;
 }
 
 int& gpet_opt_rng_lookahead() {

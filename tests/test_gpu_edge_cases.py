@@ -183,10 +183,12 @@ def test_lml_objective_with_two_tiles_per_thread(amd, ctx, kernel, nu, n):
     assert finite >= 20
 
 
-def test_lml_objective_every_size_class(amd, ctx):
+@pytest.mark.parametrize("two_tiles_from", [1 << 29, 1])
+def test_lml_objective_every_size_class(amd, ctx, two_tiles_from):
     """The objective kernel for training-set sizes across every launch shape: from 3 points, sizes around the multiples
     of 4 where the tile count and the border move, one problem per edge with DIFFERENT n in one launch (the launch is
-    sized for the largest), single-problem launches.  vs the oracle."""
+    sized for the largest), single-problem launches; with one 4x4 tile per thread (small launches) and with two (the
+    form big launches take, option lml_two_tiles_from).  vs the oracle."""
     from gaussian_process_edge_trace_amd import _final_fit as ff
     L = amd._lib
     N = 520
@@ -207,7 +209,8 @@ def test_lml_objective_every_size_class(amd, ctx):
         b.final_set_training(e, pr["xs"], pr["yt"], pr["w"])
         prs.append(pr)
     wrong = []
-    if True:
+    old_opt = L.set_option("lml_two_tiles_from", two_tiles_from)
+    try:
         for group in (list(range(len(sizes))), [0, 1], [5, 6], [len(sizes) - 1]):  # mixed sizes / small launches
             reps = 3
             edge_of = np.repeat(np.array(group, dtype=np.int32), reps)
@@ -230,6 +233,8 @@ def test_lml_objective_every_size_class(amd, ctx):
         lml, _ = orc.lml_and_grad(th_bad[0], prs[-1]["xs"], prs[-1]["yt"], prs[-1]["w"], "RBF", 2.5)
         if not np.isfinite(lml):
             assert np.isinf(f[0]) and f[0] > 0 and np.all(gr[0] == 0)
+    finally:
+        L.set_option("lml_two_tiles_from", old_opt)
 
 
 def test_converged_fit_on_device_beyond_128_points(amd, ctx):

@@ -27,7 +27,13 @@ cp profiles/r01_pmc_traffic.json gpurun_out/profiles_new/
 grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('gpurun_out/profiles_new/r01_bench_n1.json','w'), indent=1)"
 cp $(ls $O/bench_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r01_bench_kernel_stats.csv
 cp $(ls $O/stage_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r01_stage_kernel_stats.csv
-NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//4)")
-python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r01_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
+DOM=$(grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel'])")
+echo "dominant kernel: $DOM"
+if [ "$DOM" = "k_lml" ]; then
+  NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//4)")
+  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r01_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
+else
+  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/r01_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
+fi
 rm -rf $O/bench_trace $O/stage_trace $O/lml_trace gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 ls -la gpurun_out/profiles_new

@@ -26,9 +26,10 @@ obs = np.stack([cols, truth[cols, 0] + rng.integers(-3, 4, size=n - 2)], axis=1)
 pr = ff.prepare(np.asarray(init)[np.argsort(np.asarray(init)[:, 0])], obs, np.arange(N), True)
 for e in range(B):
     b.final_set_training(e, pr["xs"], pr["yt"], pr["w"])
-for mfma in (0,):
+for two_from in (1 << 29, 1):  # one tile per thread / two tiles per thread
+    L.set_option("lml_two_tiles_from", two_from)
 
-    for P in (1, 64, 256, 900, 3328):
+    for P in (1, 256, 900, 3328, 6656, 13312):
         edge_of = (np.arange(P) % B).astype(np.int32)
         th = np.tile(np.log([5.0, 5.0, 0.5]), (P, 1)) + 0.1 * rng.standard_normal((P, 3))
         f, g = b.lml_batch(edge_of, th)
@@ -37,5 +38,5 @@ for mfma in (0,):
             f, g = b.lml_batch(edge_of, th)
         st = b.lml_stats()
         ms = st["kernel_ms"] / st["launches"]
-        print("mfma=%d n=%d P=%5d  %8.1f us/launch  %7.2f TFLOP/s (n^3 per problem)  f[0]=%.9g" %
-              (mfma, n, P, 1e3 * ms, P * n ** 3 / (ms * 1e-3) / 1e12, f[0]), flush=True)
+        print("two_tiles_from=%d n=%d P=%5d  %8.1f us/launch  %7.2f TFLOP/s (n^3 per problem)  f[0]=%.9g" %
+              (two_from, n, P, 1e3 * ms, P * n ** 3 / (ms * 1e-3) / 1e12, f[0]), flush=True)
