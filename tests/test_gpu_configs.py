@@ -153,3 +153,32 @@ def test_block_jacobi_option_gives_a_valid_factor(amd, ctx):
     assert np.abs(A.T @ A - cov).max() < 1e-10 * np.abs(cov).max()
     assert np.abs(ev[:len(w)] - w).max() < 1e-10 * w[0]
     assert np.abs(G - np.diag(np.diag(G))).max() < 1e-11 * w[0]
+
+
+def test_config4_batch_equals_single_edge_runs_at_bench_shape(amd, ctx):
+    """BASELINE config 4's shape (a batch of independent 500x500 edges, here 48 with different seeds): the edges
+    finish after different numbers of iterations, so the loop is advanced in groups over a compacted edge table, and
+    the batch's 624 converged-fit problems per launch take the two-tiles-per-thread objective kernel while a single
+    edge's 13 take the one-tile one.  Every edge must get what its own single-edge run gets: the same number of
+    iterations, the same observations, the same trace; the credible interval to 1e-6 (the two objective kernels add
+    their final sums in a different order)."""
+    img, truth = orc.synth_sinusoid_image(500, 3)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, N_samples=1000,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True, return_std=True)
+    B = 48
+    seeds = [101 + e for e in range(B)]
+    batch = amd.GP_Edge_Tracing_Batch([init] * B, grad, seeds, **kw, _ctx=ctx)
+    out = batch()
+    iters_b = batch._iters()
+    obs_b = batch._batch.read_obs_all()
+    assert len(set(iters_b)) > 1  # staggered finishing: the compaction is exercised
+    for e in range(0, B, 5):
+        single = amd.GP_Edge_Tracing(init, grad, seed=seeds[e], **kw, _ctx=ctx)
+        et, ci = single()
+        assert single._n_iter == iters_b[e], "edge %d" % e
+        assert np.array_equal(single._batch.read(amd._lib.BUF_OBS), obs_b[e]), "edge %d" % e
+        assert np.array_equal(out[e][0], et), "edge %d" % e
+        np.testing.assert_allclose(out[e][1][0], ci[0], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(out[e][1][1], ci[1], rtol=1e-6, atol=1e-6)
