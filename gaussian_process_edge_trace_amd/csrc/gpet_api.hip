@@ -446,7 +446,12 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   {
     int pr_least = 0, pr_greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-    HIPCHK(c, hipStreamCreateWithPriority(&b->fit, hipStreamNonBlocking, pr_greatest));
+    // GPET_FIT_PRIORITY = high (default) | normal | low: priority of the stream the converged fits' objective runs on
+    const char* fp = getenv("GPET_FIT_PRIORITY");
+    int prio = pr_greatest;
+    if (fp && strcmp(fp, "low") == 0) prio = pr_least;
+    else if (fp && strcmp(fp, "normal") == 0) prio = (pr_least + pr_greatest) / 2;
+    HIPCHK(c, hipStreamCreateWithPriority(&b->fit, hipStreamNonBlocking, prio));
   }
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_norm[i], hipEventDisableTiming));
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_gemm[i], hipEventDisableTiming));
