@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="trace the steps strictly one after the other (default: the converged fits of step k overlap "
                          "the device loop of step k+1 on a second batch object / HIP stream)")
-    ap.add_argument("--cpu-traces", type=int, default=1)
+    ap.add_argument("--cpu-traces", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
