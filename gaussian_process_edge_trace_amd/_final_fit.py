@@ -132,31 +132,44 @@ def prepare_many(inits, obs_list, x_grids, fix_endpoints_list):
 
 
 def start_points_many(noise_ys, seeds, n_restarts=12):
-    """``start_points`` for many edges.  ``RandomState(seed)`` costs ~50 us of Python per edge; here MT19937's
-    ``init_genrand`` recurrence (what numpy's legacy seeding runs for an integer seed) is evaluated for all seeds at once
-    and each state is handed to one reused ``RandomState`` -- the draws are the generator's own, bit for bit."""
+    """``start_points`` for many edges.  ``RandomState(seed)`` costs ~50 us of Python per edge; here the generator is
+    evaluated for all seeds at once: MT19937's ``init_genrand`` recurrence (what numpy's legacy seeding runs for an integer
+    seed), the first twist of the state, the tempering and ``random_sample``'s 53-bit doubles
+    ``((a >> 5) * 2**26 + (b >> 6)) / 2**53`` -- ``uniform(0, 1)`` is ``0.0 + 1.0 * random_sample()``, the same value.
+    Bit-identical to ``start_points`` (tests/test_host_logic.py)."""
     seeds = np.asarray(seeds, dtype=np.uint64)
     if np.any(seeds > np.uint64(0xFFFFFFFF)):
         raise ValueError("seeds must fit 32 bits (numpy legacy seeding)")
     E = seeds.shape[0]
-    key = np.empty((624, E), dtype=np.uint64)
-    key[0] = seeds
-    mask = np.uint64(0xFFFFFFFF)
-    for i in range(1, 624):
-        prev = key[i - 1]
-        key[i] = (np.uint64(1812433253) * (prev ^ (prev >> np.uint64(30))) + np.uint64(i)) & mask
-    key = np.ascontiguousarray(key.T.astype(np.uint32))
-    rs = np.random.RandomState(0)
-    out = []
-    lo, span = BOUNDS[:, 0], BOUNDS[:, 1] - BOUNDS[:, 0]
-    for e in range(E):
-        th = np.empty((1 + max(0, n_restarts), 3))
-        th[0] = np.log(np.array([5.0, 5.0, float(noise_ys[e])]))
-        if n_restarts > 0:
-            rs.set_state(("MT19937", key[e], 624, 0, 0.0))
-            th[1:] = lo + span * rs.uniform(size=(n_restarts, 3))
-        out += list(th)
-    return out
+    n_u = 3 * max(0, n_restarts)          # doubles needed per edge
+    n_w = 2 * n_u                         # 32-bit outputs needed per edge
+    th0 = np.empty((E, 1 + max(0, n_restarts), 3))
+    th0[:, 0, 0] = th0[:, 0, 1] = np.log(5.0)
+    th0[:, 0, 2] = np.log(np.asarray(noise_ys, dtype=np.float64))
+    if n_restarts > 0:
+        if n_w > 227:
+            raise ValueError("start_points_many: more than 37 restarts need a second twist phase")
+        n_key = n_w + 397 + 1             # state words the first n_w outputs depend on
+        key = np.empty((n_key, E), dtype=np.uint64)
+        key[0] = seeds
+        mask = np.uint64(0xFFFFFFFF)
+        for i in range(1, n_key):
+            prev = key[i - 1]
+            key[i] = (np.uint64(1812433253) * (prev ^ (prev >> np.uint64(30))) + np.uint64(i)) & mask
+        # genrand: word k of the next state = key[k + 397] ^ twist(key[k], key[k + 1]) for k < 227
+        y = (key[:n_w] & np.uint64(0x80000000)) | (key[1:n_w + 1] & np.uint64(0x7FFFFFFF))
+        w = key[397:397 + n_w] ^ (y >> np.uint64(1)) ^ np.where((y & np.uint64(1)) != 0, np.uint64(0x9908B0DF), np.uint64(0))
+        w ^= w >> np.uint64(11)
+        w ^= (w << np.uint64(7)) & np.uint64(0x9D2C5680)
+        w ^= (w << np.uint64(15)) & np.uint64(0xEFC60000)
+        w &= mask
+        w ^= w >> np.uint64(18)
+        a = (w[0::2] >> np.uint64(5)).astype(np.float64)
+        b_ = (w[1::2] >> np.uint64(6)).astype(np.float64)
+        u = ((a * 67108864.0 + b_) / 9007199254740992.0).T.reshape(E, n_restarts, 3)  # row-major fill of uniform(size=(R, 3))
+        lo, span = BOUNDS[:, 0], BOUNDS[:, 1] - BOUNDS[:, 0]
+        th0[:, 1:, :] = lo + span * u
+    return list(th0.reshape(-1, 3))
 
 
 def start_points(noise_y, seed, n_restarts=12):
