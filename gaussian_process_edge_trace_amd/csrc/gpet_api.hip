@@ -131,7 +131,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.lam0 = cv.take<double>(rc);
   E.beta = cv.take<double>(rc);
   E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
-  E.bj_R = cv.take<double>((size_t)(E.bj_pairs > 0 ? E.bj_pairs : 0) * 4096 + 1);
+  E.eig = cv.take<EigState>(1);
+  E.pcx_d = cv.take<double>(Lg);
+  E.pcx_cand = cv.take<double>(4 * (Lg / 32 + 2));
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
@@ -181,10 +183,16 @@ int gpet_set_option(const char* name, int value) {
     v = value < 0 ? 0 : (value > 15 ? 15 : value);
     return old;
   }
-  if (name && strcmp(name, "block_jacobi") == 0) {
-    int& v = gpet_opt_block_jacobi();
+  if (name && strcmp(name, "scalar_jacobi") == 0) {
+    int& v = gpet_opt_scalar_jacobi();
     const int old = v;
     v = value ? 1 : 0;
+    return old;
+  }
+  if (name && strcmp(name, "oj_max_sweeps") == 0) {
+    int& v = gpet_opt_oj_max_sweeps();
+    const int old = v;
+    v = value < 1 ? 1 : (value > 64 ? 64 : value);
     return old;
   }
   return -1;
@@ -391,7 +399,6 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
   }
   b->bd = bd;
-  for (int e = 0; e < B; ++e) b->h_edges[e].bj_pairs = any_big ? (bd.Lg + 63) / 64 : 0;
   // measure, allocate, carve
   const size_t px = (size_t)M * N;
   Carver meas;

@@ -7,6 +7,14 @@
 
 namespace gpet {
 
+// Device-side state of the any-rank factorisation (gpet_eig.hip): pivoted Cholesky + one-sided block Jacobi.
+struct EigState {
+  double tol;                      // 1e-14 * first pivot: where the pivoted Cholesky stops
+  unsigned long long maxrel_bits;  // bits of the largest squared relative row coupling met in the current sweep
+  int stopped, rank;               // pivoted Cholesky finished; rows of G
+  int converged, sweeps;           // Jacobi: every pair orthogonal to 1e-11; sweeps done
+};
+
 // One entry per edge, stored in a device array; kernels index it with blockIdx.y.
 struct EdgeDev {
   // geometry / clamped ctor parameters (gpet.py:95-158)
@@ -39,10 +47,11 @@ struct EdgeDev {
   double* beta;          // [r_cap] c * lam0 * Q0[:, obs] alpha
   double* row_part;      // [r_cap][Lg/64 + 1] per-column-tile partial sums of the sign convention
   int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
-  double* bj_R;          // [bj_pairs][64*64] rotations of the block pairs of a block-Jacobi round (large ranks)
-  int bj_pairs;          // pairs per block round of the BATCH (largest edge): ceil(Lg_max / 64); 0 for small ranks
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
+  EigState* eig;         // state of the any-rank factorisation
+  double* pcx_d;         // [Lg] remaining diagonal of the multi-workgroup pivoted Cholesky (-1: pivoted)
+  double* pcx_cand;      // [2][Lg/32 + 1][2] per-workgroup pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
   double* Y;             // [S*Lg]

@@ -26,8 +26,13 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u,
                       int raw_band = 0);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
-// process-wide switch (gpet_set_option "block_jacobi"; initial value from the environment GPET_JB_BLOCK)
-int& gpet_opt_block_jacobi();
+// any-rank factor (gpet_eig.hip): pivoted Cholesky over the whole GPU + one-sided block Jacobi on its rows
+hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+// gpet_set_option "oj_max_sweeps" (default 16; environment GPET_OJ_MAX_SWEEPS): sweep budget of that Jacobi
+int& gpet_opt_oj_max_sweeps();
+// process-wide switch (gpet_set_option "scalar_jacobi"; initial value from the environment GPET_SCALAR_JACOBI):
+// 1 = factor covariances of rank > 96 with the round-1 whole-GPU scalar Jacobi instead of gpet_eig.hip
+int& gpet_opt_scalar_jacobi();
 // gpet_set_option "rng_lookahead" (default 1; environment GPET_RNG_LOOKAHEAD): how many iterations the RNG stream of
 // the device loop may run ahead of it (gpet_api.hip, gpet_trace_iterate)
 int& gpet_opt_rng_lookahead();

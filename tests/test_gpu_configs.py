@@ -127,32 +127,83 @@ def test_large_n_structured_path_equals_generic(amd, ctx):
     np.testing.assert_allclose(b.read(L.BUF_MEAN), pred["mean"], rtol=1e-7)
 
 
-def test_block_jacobi_option_gives_a_valid_factor(amd, ctx):
-    """gpet_set_option("block_jacobi", 1) (two-level Jacobi for full-rank posteriors, opt-in): the factor of a
-    1024-wide Matern-5/2 posterior covariance must reconstruct it and have orthogonal rows and LAPACK's eigenvalues."""
+def _matern_frame(amd, ctx, N=1024, S=300):
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    warm = truth[16:-16:16][:, [1, 0]].astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=S, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True)
+    return init, grad, warm, kw
+
+
+def test_any_rank_factor_full_rank_matern_vs_lapack(amd, ctx):
+    """The default factor of a full-rank posterior (pivoted Cholesky over the GPU + one-sided block Jacobi on its
+    rows, gpet_eig.hip) on a 1024-wide Matern-5/2 covariance: reconstruction, LAPACK's eigenvalues, orthogonal rows,
+    and -- what the tracer sees -- the samples Z A against Z F with F = LAPACK's sqrt(s) v rows (same sign convention)
+    and against the round-1 scalar Jacobi (gpet_set_option("scalar_jacobi", 1)), in pixels."""
+    L = amd._lib
+    init, grad, warm, kw = _matern_frame(amd, ctx)
+    tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, warm)
+    b.fit_predict(want_cov=True)
+    b.factor()
+    s = b.scalars()
+    A, cov, ev = b.read(L.BUF_FACTOR), b.read(L.BUF_COV), b.read(L.BUF_EIGVALS)
+    assert s.rank == 1024 and 4 <= int(s.lml) <= 14, (s.rank, s.lml)  # (lml field: Jacobi sweeps)
+    w = np.linalg.eigvalsh(cov)[::-1]
+    assert np.abs(A.T @ A - cov).max() < 2e-12 * np.abs(cov).max()
+    assert np.abs(ev - w).max() < 1e-12 * w[0]
+    assert (np.abs(ev - w) / w).max() < 1e-6  # Jacobi on the Cholesky factor: small eigenvalues to high RELATIVE accuracy
+    Gm = A @ A.T
+    d = np.sqrt(np.diag(Gm))
+    assert np.abs(Gm / d[:, None] / d[None, :] - np.eye(len(d))).max() < 1e-10
+    F, _, _ = orc.mvn_factor_svd(cov, "harmonic")
+    Z = orc.legacy_standard_normal(11, 64 * 1024).reshape(64, 1024)
+    y_s = s.y_s
+    d_lapack = np.abs(Z @ A - Z @ F).max() * y_s
+    old = L.set_option("scalar_jacobi", 1)
+    try:
+        b.factor()
+    finally:
+        L.set_option("scalar_jacobi", old)
+    A1 = b.read(L.BUF_FACTOR)
+    d_scalar = np.abs(Z @ A - Z @ A1).max() * y_s
+    d_scalar_lapack = np.abs(Z @ A1 - Z @ F).max() * y_s
+    print("max sample difference (pixels): new vs LAPACK %.3g, new vs scalar Jacobi %.3g, scalar Jacobi vs LAPACK %.3g"
+          % (d_lapack, d_scalar, d_scalar_lapack))
+    assert d_lapack < 1e-5 and d_scalar < 0.05  # (measured: 2.7e-7 px; the scalar rounds are 4e-3 px from LAPACK)
+
+
+def test_any_rank_factor_rank_deficient_rbf(amd, ctx):
+    """RBF with a short length scale on 1024 columns: numerical rank ~270 -- above the LDS solver's 96, far below Lg.
+    The pivoted Cholesky stops at its tolerance and the Jacobi runs on the rows it produced."""
     L = amd._lib
     N = 1024
     img, truth = orc.synth_sinusoid_image(N, 5)
     grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
     init = truth[[0, -1], :][:, [1, 0]]
     warm = truth[16:-16:16][:, [1, 0]].astype(np.int64)
-    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41}, noise_y=1,
-              N_samples=300, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 150, 'length_scale': 10}, noise_y=1, N_samples=300,
+              score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True)
     tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx)
     b = tr._batch
+    assert b.info()["factor_cap"] > 96
     b.set_obs(0, warm)
     b.fit_predict(want_cov=True)
-    old = L.set_option("block_jacobi", 1)
-    try:
-        b.factor()
-    finally:
-        L.set_option("block_jacobi", old)
+    b.factor()
+    s = b.scalars()
     A, cov, ev = b.read(L.BUF_FACTOR), b.read(L.BUF_COV), b.read(L.BUF_EIGVALS)
+    assert 96 < s.rank < 400, s.rank
     w = np.linalg.eigvalsh(cov)[::-1]
-    G = A @ A.T
-    assert np.abs(A.T @ A - cov).max() < 1e-10 * np.abs(cov).max()
-    assert np.abs(ev[:len(w)] - w).max() < 1e-10 * w[0]
-    assert np.abs(G - np.diag(np.diag(G))).max() < 1e-11 * w[0]
+    assert np.abs(A.T @ A - cov).max() < 1e-11 * np.abs(cov).max()
+    assert np.abs(ev - w[:s.rank]).max() < 1e-11 * w[0]
+    F, _, _ = orc.mvn_factor_svd(cov, "harmonic")
+    Z = orc.legacy_standard_normal(11, 64 * 1024).reshape(64, 1024)
+    d = np.abs(Z[:, :s.rank] @ A - Z @ F).max() * s.y_s
+    print("rank %d, %d sweeps, max sample difference vs LAPACK %.3g px" % (s.rank, int(s.lml), d))
+    assert d < 1e-4
 
 
 def test_config4_batch_equals_single_edge_runs_at_bench_shape(amd, ctx):
