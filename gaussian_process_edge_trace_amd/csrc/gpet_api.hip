@@ -132,8 +132,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.beta = cv.take<double>(rc);
   E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
   E.eig = cv.take<EigState>(1);
+  E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);
   E.pcx_d = cv.take<double>(Lg);
-  E.pcx_cand = cv.take<double>(4 * (Lg / 32 + 2));
+  E.pcx_cand = cv.take<double>(16 * ((size_t)E.N / 32 + 2));  // (indexed with the widest edge of the batch)
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
   E.jb_norm = cv.take<double>(2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
@@ -187,6 +188,12 @@ int gpet_set_option(const char* name, int value) {
     int& v = gpet_opt_scalar_jacobi();
     const int old = v;
     v = value ? 1 : 0;
+    return old;
+  }
+  if (name && strcmp(name, "oj_tol_exp") == 0) {
+    int& v = gpet_opt_oj_tol_exp();
+    const int old = v;
+    v = value < 4 ? 4 : (value > 15 ? 15 : value);
     return old;
   }
   if (name && strcmp(name, "oj_max_sweeps") == 0) {

@@ -50,8 +50,9 @@ struct EdgeDev {
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
   EigState* eig;         // state of the any-rank factorisation
+  double* Gt;            // [Lg][r_cap] transposed copy of G kept by the multi-workgroup pivoted Cholesky (ranks > 96 only)
   double* pcx_d;         // [Lg] remaining diagonal of the multi-workgroup pivoted Cholesky (-1: pivoted)
-  double* pcx_cand;      // [2][Lg/32 + 1][2] per-workgroup pivot candidates (value, index) of the current / next step
+  double* pcx_cand;      // [2][4 (Lg/32 + 1)][2] per-wave pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
   double* Y;             // [S*Lg]

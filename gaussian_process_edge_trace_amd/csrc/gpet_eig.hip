@@ -26,6 +26,8 @@ namespace gpet {
 #define PCX_COLS 32
 #define OJ_B 8
 #define OJ_M 16
+#define OJ_STAGE_MAX 1024  // widest edge whose 16-row panel (16 x Lg doubles) is staged in LDS
+#define OJ_PF 16  // 16-column tiles per wave whose operands are prefetched into registers (4 waves x 16 x 16 = 1024 columns)
 
 static inline int cdiv_h(int a, int b) { return (a + b - 1) / b; }
 
@@ -63,6 +65,8 @@ __device__ __forceinline__ void pcx_argmax_wave(double& bv, int& bi) {
   }
 }
 
+// Pivot candidates: one (value, index) pair per WAVE (8 columns), two halves of pcx_cand used alternately: the
+// candidates of step t live in half (t & 1), a step writes those of step t + 1 into the other half.
 __global__ void __launch_bounds__(256) k_pcx_init(EdgeDev* edges, int nw_max) {
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E)) return;
@@ -76,59 +80,61 @@ __global__ void __launch_bounds__(256) k_pcx_init(EdgeDev* edges, int nw_max) {
     st->converged = 0;
     st->sweeps = 0;
   }
-  if (j0 >= Lg || tid >= WAVE) return;
-  const int j = j0 + tid;
+  if (j0 >= Lg) return;
+  const int lane = tid & 63, w = tid >> 6;
+  const int j = j0 + w * 8 + lane;
   double bv = -1.0;
   int bi = 0x7FFFFFFF;
-  if (tid < PCX_COLS && j < Lg) {
+  if (lane < 8 && j < Lg) {
     const double d = E.cov[(size_t)j * Lg + j];
     E.pcx_d[j] = d;
     bv = d;
     bi = j;
   }
   pcx_argmax_wave(bv, bi);
-  if (tid == 0) {
-    E.pcx_cand[2 * blockIdx.x] = bv;
-    E.pcx_cand[2 * blockIdx.x + 1] = (double)bi;
+  if (lane == 0) {
+    E.pcx_cand[2 * (blockIdx.x * 4 + w)] = bv;
+    E.pcx_cand[2 * (blockIdx.x * 4 + w) + 1] = (double)bi;
   }
   (void)nw_max;
 }
 
-// pivot step t: candidates of step t live in half (t & 1) of pcx_cand, those of step t + 1 go to the other half
+// Pivot step t.  A kernel starts with cold caches (data written by the previous launch comes from the Infinity Cache),
+// so what bounds a step is its chain of DEPENDENT global round trips, not its arithmetic.  There are three: the edge
+// table; {state, candidates, this wave's remaining diagonals}; {the pivot's previous entries, the pivot's covariance
+// row, the previous entries of this wave's 8 columns}.  No LDS and no workgroup barrier: every wave finds the pivot
+// itself and reads the pivot's entries itself, a wave owns 8 columns, lane = previous row index s (mod 64).
 __global__ void __launch_bounds__(256) k_pcx_step(EdgeDev* edges, int t, int nw_max) {
   const EdgeDev E = edges[blockIdx.y];
-  if (eig_skip(E)) return;
-  EigState* st = E.eig;
-  if (st->stopped || t >= E.r_cap) return;
   const int Lg = E.Lg, j0 = blockIdx.x * PCX_COLS, tid = threadIdx.x;
-  if (j0 >= Lg) return;
-  extern __shared__ double s_gp[];  // [t] the pivot's entries of the previous rows
-  __shared__ double s_part[8][PCX_COLS + 1];
-  __shared__ double s_piv;
-  __shared__ int s_pidx;
-  const int nwe = (Lg + PCX_COLS - 1) / PCX_COLS;
-  const double* cand = E.pcx_cand + (size_t)(t & 1) * 2 * nw_max;
-  if (tid < WAVE) {
-    double bv = -1.0;
-    int bi = 0x7FFFFFFF;
-    for (int i = tid; i < nwe; i += WAVE) {
-      const double v = cand[2 * i];
-      const int ix = (int)cand[2 * i + 1];
-      if (v > bv || (v == bv && ix < bi)) {
-        bv = v;
-        bi = ix;
-      }
-    }
-    pcx_argmax_wave(bv, bi);
-    if (tid == 0) {
-      s_piv = bv;
-      s_pidx = bi;
+  if (j0 >= Lg || t >= E.r_cap) return;
+  const int lane = tid & 63, w = tid >> 6;
+  EigState* st = E.eig;
+  const gpet_scalars* sc = E.sc;
+  // -- round trip 2: everything that does not depend on the pivot
+  const int s_done = sc->done, s_force = sc->force, s_status = sc->status, s_stopped = st->stopped;
+  const double tol_prev = st->tol;
+  const int ncand = 4 * ((Lg + PCX_COLS - 1) / PCX_COLS);
+  const double* cand = E.pcx_cand + (size_t)(t & 1) * 8 * nw_max;
+  double bv = -1.0;
+  int bi = 0x7FFFFFFF;
+  for (int i = lane; i < ncand; i += WAVE) {
+    const double v = cand[2 * i];
+    const int ix = (int)cand[2 * i + 1];
+    if (v > bv || (v == bv && ix < bi)) {
+      bv = v;
+      bi = ix;
     }
   }
-  __syncthreads();
-  const double dp = s_piv;
-  const int p = s_pidx;
-  const double tol = (t == 0) ? dp * 1e-14 : st->tol;
+  const int jw = j0 + w * 8;  // this wave's 8 columns
+  double dcol[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) dcol[cc] = (jw + cc < Lg) ? E.pcx_d[jw + cc] : -1.0;  // (< 0: pivoted / no such column)
+  if ((s_done && !s_force) || s_status != GPET_OK || E.factor_injected || s_stopped) return;
+  pcx_argmax_wave(bv, bi);
+  const double dp = bv;
+  const int p = bi;
+  const double tol = (t == 0) ? dp * 1e-14 : tol_prev;
   if (!(dp > tol) || !(dp > 0.0)) {
     if (blockIdx.x == 0 && tid == 0) {
       st->stopped = 1;
@@ -137,28 +143,55 @@ __global__ void __launch_bounds__(256) k_pcx_step(EdgeDev* edges, int t, int nw_
     return;
   }
   if (t == 0 && blockIdx.x == 0 && tid == 0) st->tol = tol;
-  for (int s = tid; s < t; s += 256) s_gp[s] = E.G[(size_t)s * Lg + p];
-  __syncthreads();
-  const int c = tid & (PCX_COLS - 1), g = tid >> 5;
-  const int j = j0 + c;
-  double acc = 0.0;
-  if (j < Lg) {
-    const double* __restrict__ gc = E.G + j;
-    for (int s = g; s < t; s += 8) acc += gc[(size_t)s * Lg] * s_gp[s];
-  }
-  s_part[g][c] = acc;
-  __syncthreads();
-  if (tid < WAVE) {
-    double bv = -1.0;
-    int bi = 0x7FFFFFFF;
-    if (tid < PCX_COLS && j < Lg) {
-      double sum = 0.0;
+  // -- round trip 3: the transposed copy Gt[j][s] = G[s][j] makes the pivot's previous entries and every column's
+  //    dot product contiguous
+  const int ld = E.r_cap;
+  const double* __restrict__ gp = E.Gt + (size_t)p * ld;
+  double cvv = 0.0;
+  if (lane < 8 && jw + lane < Lg) cvv = E.cov[(size_t)p * Lg + jw + lane];  // (cov is exactly symmetric: row p == column p)
+  double acc[8];
+  const double* __restrict__ gj[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) sum += s_part[q][c];
-      double dj = E.pcx_d[j];
-      double gv = 0.0;
-      if (dj >= 0.0) gv = (E.cov[(size_t)p * Lg + j] - sum) / sqrt(dp);  // (cov is exactly symmetric: row p == column p)
+  for (int cc = 0; cc < 8; ++cc) {
+    gj[cc] = E.Gt + (size_t)(jw + cc < Lg ? jw + cc : 0) * ld;
+    acc[cc] = 0.0;
+  }
+  for (int s0 = 0; s0 < t; s0 += 4 * WAVE) {
+    double gpv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = s0 + i * WAVE + lane;
+      gpv[i] = s < t ? gp[s] : 0.0;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+      if (dcol[cc] >= 0.0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int s = s0 + i * WAVE + lane;
+          if (s < t) acc[cc] += gj[cc][s] * gpv[i];
+        }
+      }
+  }
+  double nb = -1.0;
+  int ni = 0x7FFFFFFF;
+  const double isq = sqrt(dp);
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc) {
+    const int j = jw + cc;
+    if (j >= Lg) continue;
+    double sum = 0.0;
+    if (dcol[cc] >= 0.0) {
+      sum = acc[cc];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
+    }
+    const double cj = __shfl(cvv, cc, WAVE);
+    if (lane == 0) {
+      double dj = dcol[cc], gv = 0.0;
+      if (dj >= 0.0) gv = (cj - sum) / isq;
       E.G[(size_t)t * Lg + j] = gv;
+      E.Gt[(size_t)j * ld + t] = gv;
       if (j == p) {
         dj = -1.0;  // used
         E.perm[t] = p;
@@ -167,15 +200,16 @@ __global__ void __launch_bounds__(256) k_pcx_step(EdgeDev* edges, int t, int nw_
         dj = nd > 0.0 ? nd : 0.0;
       }
       E.pcx_d[j] = dj;
-      bv = dj;
-      bi = j;
+      if (dj > nb || (dj == nb && j < ni)) {
+        nb = dj;
+        ni = j;
+      }
     }
-    pcx_argmax_wave(bv, bi);
-    if (tid == 0) {
-      double* nxt = E.pcx_cand + (size_t)((t + 1) & 1) * 2 * nw_max;
-      nxt[2 * blockIdx.x] = bv;
-      nxt[2 * blockIdx.x + 1] = (double)bi;
-    }
+  }
+  if (lane == 0) {
+    double* nxt = E.pcx_cand + (size_t)((t + 1) & 1) * 8 * nw_max;
+    nxt[2 * (blockIdx.x * 4 + w)] = nb;
+    nxt[2 * (blockIdx.x * 4 + w) + 1] = (double)ni;
   }
 }
 
@@ -190,10 +224,10 @@ __global__ void __launch_bounds__(64) k_pcx_fin(EdgeDev* edges, int steps, int n
     st->rank = cap;
     st->stopped = 1;
     if (cap < E.Lg) {  // capacity reached before the tolerance: what is left must be negligible
-      const int nwe = (E.Lg + PCX_COLS - 1) / PCX_COLS;
-      const double* cand = E.pcx_cand + (size_t)(cap & 1) * 2 * nw_max;
+      const int ncand = 4 * ((E.Lg + PCX_COLS - 1) / PCX_COLS);
+      const double* cand = E.pcx_cand + (size_t)(cap & 1) * 8 * nw_max;
       double rem = 0.0;
-      for (int i = 0; i < nwe; ++i) rem = cand[2 * i] > rem ? cand[2 * i] : rem;
+      for (int i = 0; i < ncand; ++i) rem = cand[2 * i] > rem ? cand[2 * i] : rem;
       if (rem > st->tol * 1e4) sc->status = GPET_ERR_RANK_CAP;
     }
   }
@@ -203,6 +237,100 @@ __global__ void __launch_bounds__(64) k_pcx_fin(EdgeDev* edges, int steps, int n
 // ---- 2. one-sided block Jacobi on the rows of G --------------------------------------------------------------------
 __device__ __forceinline__ int oj_row(int bI, int bJ, int t) { return t < OJ_B ? bI * OJ_B + t : bJ * OJ_B + (t - OJ_B); }
 
+// rotation (c, s) that annihilates the coupling apq of a symmetric 2x2 block [app apq; apq aqq]: the smaller angle
+// (c >= 1/sqrt 2).  With rho = sqrt(d^2 + 4 apq^2), d = aqq - app:  c^2 = (rho + |d|) / (2 rho),
+// s = +-apq / (rho c)  -- two reciprocal square roots (hardware seed + two Newton steps each), no division.
+__device__ __forceinline__ void oj_rotation(double app, double apq, double aqq, double& c, double& s, double& rel2) {
+  c = 1.0;
+  s = 0.0;
+  const double den = fabs(app * aqq), num = apq * apq;
+  rel2 = den > 0.0 ? num * __builtin_amdgcn_rcp(den) : 0.0;  // (hardware reciprocal: a convergence measure, not arithmetic)
+  if (num > 1e-34 * den && fabs(apq) > 1e-300) {
+    const double d = aqq - app, hh = 2.0 * apq;
+    const double rho2 = d * d + hh * hh;
+    double y = __builtin_amdgcn_rsq(rho2);  // 1 / rho
+    y = y * (1.5 - 0.5 * rho2 * y * y);
+    y = y * (1.5 - 0.5 * rho2 * y * y);
+    const double x = 0.5 + 0.5 * fabs(d) * y;  // c^2 in [1/2, 1]
+    double z = __builtin_amdgcn_rsq(x);        // 1 / c
+    z = z * (1.5 - 0.5 * x * z * z);
+    z = z * (1.5 - 0.5 * x * z * z);
+    c = x * z;
+    s = (d >= 0.0 ? hh : -hh) * (0.5 * y) * z;
+  }
+}
+
+// One cyclic sweep (15 rounds of 8 disjoint rotations) on the symmetric 16x16 matrix s_C, executed by ONE wave:
+// lane = 2x2 block (a_, b_) of the current pairing, upper triangle of blocks active, mirrored writes; the accumulated
+// rotation goes to s_R (s_R <- s_R J).  Wave-synchronous LDS traffic only -- no workgroup barrier inside.
+__device__ __forceinline__ double oj_inner_sweep(double (*s_C)[OJ_M + 1], double (*s_R)[OJ_M + 1], int lane) {
+  double mr = 0.0;  // largest squared relative coupling rotated away (this lane's pairs)
+  const int a_ = lane >> 3, b_ = lane & 7;
+  const bool act = a_ <= b_;
+  const int i0 = lane >> 3;
+  for (int rnd = 0; rnd < OJ_M - 1; ++rnd) {
+    int pa, qa, pb, qb;
+    oj_rr_pair(OJ_M - 1, rnd, a_, pa, qa);
+    oj_rr_pair(OJ_M - 1, rnd, b_, pb, qb);
+    // both rotations of this lane's block are computed here (two independent dependency chains that interleave: the
+    // same latency as one, and no cross-lane traffic); lanes that share a pair compute identical values
+    double ca, sa, cb, sb, ra2, rb2;
+    oj_rotation(s_C[pa][pa], s_C[pa][qa], s_C[qa][qa], ca, sa, ra2);
+    oj_rotation(s_C[pb][pb], s_C[pb][qb], s_C[qb][qb], cb, sb, rb2);
+    mr = rb2 > mr ? rb2 : mr;  // (every pair is some lane's b_)
+    (void)ra2;
+    double n00 = 0.0, n01 = 0.0, n10 = 0.0, n11 = 0.0;
+    if (act) {
+      const double b00 = s_C[pa][pb], b01 = s_C[pa][qb], b10 = s_C[qa][pb], b11 = s_C[qa][qb];
+      const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+      const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+      n00 = ca * t00 - sa * t10;
+      n10 = sa * t00 + ca * t10;
+      n01 = ca * t01 - sa * t11;
+      n11 = sa * t01 + ca * t11;
+    }
+    const double r0p = s_R[i0][pb], r0q = s_R[i0][qb], r1p = s_R[i0 + 8][pb], r1q = s_R[i0 + 8][qb];
+    __builtin_amdgcn_wave_barrier();  // every read of this round precedes its writes
+    if (act) {
+      s_C[pa][pb] = n00;
+      s_C[qa][pb] = n10;
+      s_C[pa][qb] = n01;
+      s_C[qa][qb] = n11;
+      if (a_ != b_) {
+        s_C[pb][pa] = n00;
+        s_C[pb][qa] = n10;
+        s_C[qb][pa] = n01;
+        s_C[qb][qa] = n11;
+      }
+    }
+    s_R[i0][pb] = cb * r0p - sb * r0q;
+    s_R[i0][qb] = sb * r0p + cb * r0q;
+    s_R[i0 + 8][pb] = cb * r1p - sb * r1q;
+    s_R[i0 + 8][qb] = sb * r1p + cb * r1q;
+    __builtin_amdgcn_wave_barrier();
+  }
+  return mr;
+}
+
+// the sweep's convergence measure: largest squared relative coupling any rotation of this visit met
+__device__ __forceinline__ void oj_report(double mr, int lane, EigState* st) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(mr, o, WAVE);
+    mr = ov > mr ? ov : mr;
+  }
+  if (lane == 0 && mr > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr));
+}
+
+// K index of matrix instruction jj, lane group lg -> row of the 16-row panel.  Lane groups 0/1 (and 2/3) share an
+// LDS cycle: their rows are 8 apart, which with a row stride of 2 (mod 32) doubles puts them on disjoint banks.
+__device__ __forceinline__ int oj_krow(int jj, int lg) { return 8 * (lg & 1) + 4 * (lg >> 1) + jj; }
+
+// One round of the block Jacobi for one pair of 8-row blocks.  STAGED: the 16 rows (16 x Lg doubles, <= 131 KB) are
+// read from HBM/L2 ONCE into LDS with fully coalesced loads; the Gram matrix and the row update both take their
+// matrix-core operands from there.  Not STAGED (Lg > OJ_STAGE_MAX): operands straight from global memory, the update's
+// operands requested before the sweep so that they arrive while wave 0 rotates.
+template <bool STAGED>
 __global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int nblk) {
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E)) return;
@@ -212,29 +340,102 @@ __global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int
   int bI, bJ;
   oj_rr_pair(nblk - 1, round, blockIdx.x, bI, bJ);
   if (bI * OJ_B >= rank) return;  // (bI < bJ: both blocks are empty)
+  extern __shared__ double s_X[];  // STAGED: [16][ldx]
   __shared__ double s_part[4][OJ_M][OJ_M + 1];
   __shared__ double s_C[OJ_M][OJ_M + 1];
   __shared__ double s_R[OJ_M][OJ_M + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  // -- Gram matrix of the 16 rows: every wave takes every fourth 16-column chunk, A operand == B operand
-  {
+  const int nch = (Lg + 15) >> 4;  // 16-column chunks = 16-column tiles of the update below
+  const int ldx = ((Lg + 31) & ~31) + 2;
+  if (STAGED) {
+    // -- stage: thread t takes columns t, t + 256, ... of every row: 512 contiguous bytes per wave instruction
+    const int kmax = nch * 16;
+    for (int r0 = 0; r0 < OJ_M; r0 += 16) {
+      double v[16][4];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = oj_row(bI, bJ, r0 + r);
+        const double* __restrict__ xrow = E.G + (size_t)gi * Lg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = tid + 256 * i;
+          v[r][i] = (gi < rank && k < Lg) ? xrow[k] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = tid + 256 * i;
+          if (k < kmax) s_X[(r0 + r) * ldx + k] = v[r][i];
+        }
+    }
+    for (int k = 1024 + tid; k < kmax; k += 256)  // (STAGED is only launched for Lg <= 1024; kept for safety)
+      for (int r = 0; r < OJ_M; ++r) {
+        const int gi = oj_row(bI, bJ, r);
+        s_X[r * ldx + k] = (gi < rank && k < Lg) ? E.G[(size_t)gi * Lg + k] : 0.0;
+      }
+    __syncthreads();
+    // -- Gram matrix: A operand == B operand == X[row lr][k]; four independent accumulators per wave
+    v4f64e acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[jj] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+    const double* xr = s_X + lr * ldx + lg;
+    for (int ch0 = w; ch0 < nch; ch0 += 16) {  // 4 chunks per batch: 16 LDS reads in flight, then 16 matrix instructions
+      double x[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < nch) ? xr[(ch0 + 4 * u) * 16 + 4 * jj] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][jj], x[u][jj], acc[jj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_part[w][lg + 4 * i][lr] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+  } else {
     const int gi = oj_row(bI, bJ, lr);
     const bool valid = gi < rank;
     const double* __restrict__ xrow = E.G + (size_t)gi * Lg;
     v4f64e acc = (v4f64e){0.0, 0.0, 0.0, 0.0};
-    const int nch = (Lg + 15) >> 4;
-    for (int ch = w; ch < nch; ch += 4) {
-      const int k0 = ch * 16 + lg;
+    for (int ch0 = w; ch0 < nch; ch0 += 4 * OJ_PF) {
+      double xv[OJ_PF][4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int k = k0 + 4 * jj;
-        const double v = (valid && k < Lg) ? xrow[k] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+      for (int u = 0; u < OJ_PF; ++u) {
+        const int k0 = (ch0 + 4 * u) * 16 + lg;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int k = k0 + 4 * jj;
+          xv[u][jj] = (valid && k < Lg) ? xrow[k] : 0.0;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < OJ_PF; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][jj], xv[u][jj], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_part[w][lg + 4 * i][lr] = acc[i];
+  }
+  // not STAGED: operands of the row update requested now (they do not depend on the rotation)
+  const double* xb[4];
+  bool vb[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int gb = oj_row(bI, bJ, oj_krow(jj, lg));
+    vb[jj] = gb < rank;
+    xb[jj] = E.G + (size_t)gb * Lg;
+  }
+  double xp[STAGED ? 1 : OJ_PF][4];
+  if (!STAGED) {
+#pragma unroll
+    for (int u = 0; u < OJ_PF; ++u) {
+      const int c = (w + 4 * u) * 16 + lr;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) xp[u][jj] = (vb[jj] && c < Lg) ? xb[jj][c] : 0.0;  // B[K][N = c]
+    }
   }
   {
     const int i = tid >> 4, j = tid & 15;
@@ -246,105 +447,13 @@ __global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int
     s_C[i][j] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);
   }
   __syncthreads();
-  // -- one cyclic sweep on the 16x16 Gram matrix, inside wave 0 (wave-synchronous LDS: no workgroup barrier)
-  if (w == 0) {
-    // largest relative coupling before this visit: the sweep's convergence measure
-    {
-      double mr = 0.0;
-      for (int e = lane; e < OJ_M * OJ_M; e += WAVE) {
-        const int i = e >> 4, j = e & 15;
-        if (i < j) {
-          const double cij = s_C[i][j], den = s_C[i][i] * s_C[j][j];
-          const double r2 = den > 0.0 ? (cij * cij) / den : 0.0;
-          mr = r2 > mr ? r2 : mr;
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(mr, o, WAVE);
-        mr = ov > mr ? ov : mr;
-      }
-      if (lane == 0 && mr > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr));
-    }
-    const int a_ = lane >> 3, b_ = lane & 7;
-    for (int rnd = 0; rnd < OJ_M - 1; ++rnd) {
-      // rotation of pair b_ (every lane; lanes with the same b_ compute identical values)
-      int pb, qb;
-      oj_rr_pair(OJ_M - 1, rnd, b_, pb, qb);
-      double cb = 1.0, sb = 0.0;
-      {
-        const double apq = s_C[pb][qb], app = s_C[pb][pb], aqq = s_C[qb][qb];
-        if (apq * apq > 1e-34 * fabs(app * aqq) && fabs(apq) > 1e-300) {
-          const double d = aqq - app, hh = 2.0 * apq;
-          const double rho2 = d * d + hh * hh;
-          double y = __builtin_amdgcn_rsq(rho2);
-          y = y * (1.5 - 0.5 * rho2 * y * y);
-          y = y * (1.5 - 0.5 * rho2 * y * y);
-          const double den = fabs(d) + rho2 * y;
-          double iv = __builtin_amdgcn_rcp(den);
-          iv = iv * (2.0 - den * iv);
-          iv = iv * (2.0 - den * iv);
-          const double tt = (d >= 0.0 ? hh : -hh) * iv;
-          const double u = 1.0 + tt * tt;
-          double cc = __builtin_amdgcn_rsq(u);
-          cc = cc * (1.5 - 0.5 * u * cc * cc);
-          cc = cc * (1.5 - 0.5 * u * cc * cc);
-          cb = cc;
-          sb = tt * cc;
-        }
-      }
-      // rotation of pair a_ = what lane a_ (whose b_ equals this lane's a_) just computed
-      const double ca = __shfl(cb, a_, WAVE), sa = __shfl(sb, a_, WAVE);
-      int pa, qa;
-      oj_rr_pair(OJ_M - 1, rnd, a_, pa, qa);
-      double n00 = 0.0, n01 = 0.0, n10 = 0.0, n11 = 0.0;
-      const bool act = a_ <= b_;
-      if (act) {
-        const double b00 = s_C[pa][pb], b01 = s_C[pa][qb], b10 = s_C[qa][pb], b11 = s_C[qa][qb];
-        const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
-        const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-        n00 = ca * t00 - sa * t10;
-        n10 = sa * t00 + ca * t10;
-        n01 = ca * t01 - sa * t11;
-        n11 = sa * t01 + ca * t11;
-      }
-      // accumulated rotation R <- R J: columns pb, qb of rows i0, i0 + 8
-      const int i0 = lane >> 3;
-      const double r0p = s_R[i0][pb], r0q = s_R[i0][qb], r1p = s_R[i0 + 8][pb], r1q = s_R[i0 + 8][qb];
-      __builtin_amdgcn_wave_barrier();  // every read of this round precedes its writes
-      if (act) {
-        s_C[pa][pb] = n00;
-        s_C[qa][pb] = n10;
-        s_C[pa][qb] = n01;
-        s_C[qa][qb] = n11;
-        if (a_ != b_) {
-          s_C[pb][pa] = n00;
-          s_C[pb][qa] = n10;
-          s_C[qb][pa] = n01;
-          s_C[qb][qa] = n11;
-        }
-      }
-      s_R[i0][pb] = cb * r0p - sb * r0q;
-      s_R[i0][qb] = sb * r0p + cb * r0q;
-      s_R[i0 + 8][pb] = cb * r1p - sb * r1q;
-      s_R[i0 + 8][qb] = sb * r1p + cb * r1q;
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  if (w == 0) oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
   __syncthreads();
   // -- rows <- R^T rows on the matrix cores: out[a][c] = sum_b R[b][a] X[b][c]; a wave owns whole 16-column tiles
   {
     double ra[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[4 * jj + lg][lr];  // A[M = a = lr][K = b = 4 jj + lg]
-    const double* xb[4];
-    bool vb[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int gb = oj_row(bI, bJ, 4 * jj + lg);
-      vb[jj] = gb < rank;
-      xb[jj] = E.G + (size_t)gb * Lg;
-    }
+    for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_krow(jj, lg)][lr];  // A[M = a = lr][K -> row b]
     double* xo[4];
     bool vo[4];
 #pragma unroll
@@ -353,33 +462,69 @@ __global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int
       vo[i] = ga < rank;
       xo[i] = E.G + (size_t)ga * Lg;
     }
-    const int nct = (Lg + 15) >> 4;
-    for (int ct = w; ct < nct; ct += 4) {
-      const int c = ct * 16 + lr;
-      const bool cv = c < Lg;
-      v4f64e acc = (v4f64e){0.0, 0.0, 0.0, 0.0};
+    if (STAGED) {
+      const double* xs[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const double xv = (vb[jj] && cv) ? xb[jj][c] : 0.0;  // B[K = b = 4 jj + lg][N = c]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv, acc, 0, 0, 0);
+      for (int jj = 0; jj < 4; ++jj) xs[jj] = s_X + oj_krow(jj, lg) * ldx + lr;
+      for (int ct0 = w; ct0 < nch; ct0 += 16) {  // 4 tiles per batch: 16 LDS reads, 4 independent accumulator chains
+        double xv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) xv[u][jj] = (ct0 + 4 * u < nch) ? xs[jj][(ct0 + 4 * u) * 16] : 0.0;
+        v4f64e acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv[u][jj], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = (ct0 + 4 * u) * 16 + lr;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (vo[i] && ct0 + 4 * u < nch && c < Lg) xo[i][c] = acc[u][i];
+        }
       }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (vo[i] && cv) xo[i][c] = acc[i];
+      for (int u = 0; u < OJ_PF; ++u) {
+        const int c = (w + 4 * u) * 16 + lr;
+        v4f64e acc = (v4f64e){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xp[u][jj], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (vo[i] && c < Lg) xo[i][c] = acc[i];
+      }
+      for (int ct = w + 4 * OJ_PF; ct < nch; ct += 4) {  // (more than 64 OJ_PF columns: Lg > 1024)
+        const int c = ct * 16 + lr;
+        const bool cv = c < Lg;
+        v4f64e acc = (v4f64e){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const double xv = (vb[jj] && cv) ? xb[jj][c] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (vo[i] && cv) xo[i][c] = acc[i];
+      }
     }
   }
 }
 
 // after every sweep: converged when the largest relative coupling met during it was below the tolerance (the
 // rotations of that sweep then took it to ~its square)
-__global__ void __launch_bounds__(64) k_oj_check(EdgeDev* edges) {
+__global__ void __launch_bounds__(64) k_oj_check(EdgeDev* edges, double tol2) {
   const EdgeDev E = edges[blockIdx.x];
   if (eig_skip(E)) return;
   EigState* st = E.eig;
   if (threadIdx.x != 0 || st->converged) return;
   const double mr2 = __longlong_as_double((long long)st->maxrel_bits);
   st->sweeps += 1;
-  if (mr2 <= 1e-22) st->converged = 1;  // |g_p.g_q| <= 1e-11 |g_p||g_q| for every pair
+  if (mr2 <= tol2) st->converged = 1;  // default 1e-16: |g_p.g_q| <= 1e-8 |g_p||g_q| for every pair met in this sweep
   st->maxrel_bits = 0ull;
   E.sc->lml = (double)st->sweeps;  // diagnostics (gpet_scalars.lml: sweeps of the last factorisation)
 }
@@ -442,19 +587,40 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   hipLaunchKernelGGL(k_pcx_init, dim3(nw, B), dim3(256), 0, st, d_edges, nw);
   const int steps = bd.r_cap < bd.Lg ? bd.r_cap : bd.Lg;
   for (int t = 0; t < steps; ++t)
-    hipLaunchKernelGGL(k_pcx_step, dim3(nw, B), dim3(256), (size_t)(t + 1) * sizeof(double), st, d_edges, t, nw);
+    hipLaunchKernelGGL(k_pcx_step, dim3(nw, B), dim3(256), 0, st, d_edges, t, nw);
   hipLaunchKernelGGL(k_pcx_fin, dim3(B), dim3(64), 0, st, d_edges, steps, nw);
   const int nblk = 2 * cdiv_h(steps, 2 * OJ_B);
   const int max_sweeps = gpet_opt_oj_max_sweeps();
+  const bool staged = bd.Lg <= OJ_STAGE_MAX && !getenv("GPET_OJ_NO_STAGE");
+  const size_t stage_lds = (size_t)OJ_M * (((bd.Lg + 31) & ~31) + 2) * sizeof(double);
+  if (staged) {
+    static int attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+      (void)hipFuncSetAttribute((const void*)k_oj_round<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      attr_done[dev] = 1;
+    }
+  }
+  const double tol2 = pow(10.0, -2.0 * (double)gpet_opt_oj_tol_exp());
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    for (int round = 0; round < nblk - 1; ++round)
-      hipLaunchKernelGGL(k_oj_round, dim3(nblk / 2, B), dim3(256), 0, st, d_edges, round, nblk);
-    hipLaunchKernelGGL(k_oj_check, dim3(B), dim3(64), 0, st, d_edges);
+    for (int round = 0; round < nblk - 1; ++round) {
+      if (staged)
+        hipLaunchKernelGGL((k_oj_round<true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, d_edges, round, nblk);
+      else
+        hipLaunchKernelGGL((k_oj_round<false>), dim3(nblk / 2, B), dim3(256), 0, st, d_edges, round, nblk);
+    }
+    hipLaunchKernelGGL(k_oj_check, dim3(B), dim3(64), 0, st, d_edges, tol2);
   }
   hipLaunchKernelGGL(k_oj_norms, dim3(cdiv_h(steps, 4), B), dim3(256), 0, st, d_edges);
   hipLaunchKernelGGL(k_oj_order, dim3(1, B), dim3(1024), 0, st, d_edges);
   hipLaunchKernelGGL(k_oj_rows, dim3(steps, B), dim3(256), 0, st, d_edges);
   return hipGetLastError();
+}
+
+int& gpet_opt_oj_tol_exp() {
+  static int v = getenv("GPET_OJ_TOL_EXP") != nullptr ? atoi(getenv("GPET_OJ_TOL_EXP")) : 8;
+  return v;
 }
 
 int& gpet_opt_oj_max_sweeps() {

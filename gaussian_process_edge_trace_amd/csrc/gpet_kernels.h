@@ -30,6 +30,9 @@ hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 // gpet_set_option "oj_max_sweeps" (default 16; environment GPET_OJ_MAX_SWEEPS): sweep budget of that Jacobi
 int& gpet_opt_oj_max_sweeps();
+// gpet_set_option "oj_tol_exp" (default 8; environment GPET_OJ_TOL_EXP): the Jacobi stops after a sweep in which every
+// pair of rows it met was orthogonal to 10^-x relative (that sweep's rotations then take the couplings to ~their square)
+int& gpet_opt_oj_tol_exp();
 // process-wide switch (gpet_set_option "scalar_jacobi"; initial value from the environment GPET_SCALAR_JACOBI):
 // 1 = factor covariances of rank > 96 with the round-1 whole-GPU scalar Jacobi instead of gpet_eig.hip
 int& gpet_opt_scalar_jacobi();
