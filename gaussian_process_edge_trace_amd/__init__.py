@@ -6,5 +6,7 @@ from .gpet import GP_Edge_Tracing, GP_Edge_Tracing_Batch
 from .sklearn_gpr import GaussianProcessRegressor
 from . import gpet_utils
 from . import _lib
+from .sequence import SequenceTracer, trace_sequence
 
-__all__ = ["GP_Edge_Tracing", "GaussianProcessRegressor", "gpet_utils", "GP_Edge_Tracing_Batch"]
+__all__ = ["GP_Edge_Tracing", "GaussianProcessRegressor", "gpet_utils", "GP_Edge_Tracing_Batch", "SequenceTracer",
+           "trace_sequence"]

@@ -22,6 +22,7 @@ OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_ITER_CAP, ERR_RANK_CAP, ERR_UNSUPPORTE
  BUF_NOISE_W) = range(20)
 
 KERNEL_RBF, KERNEL_MATERN = 0, 1
+GRAD_ON_DEVICE = 1  # gpet_batch_create2 / gpet_batch_set_images flag: the gradient image pointers are device pointers
 
 
 class GpetParams(C.Structure):
@@ -62,6 +63,9 @@ SYMBOLS = {
     "gpet_normalise_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gpet_batch_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int,
                                     C.POINTER(GpetParams), C.POINTER(_P), C.POINTER(_P)]),
+    "gpet_batch_create2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.c_int,
+                                     C.POINTER(GpetParams), C.POINTER(_P), C.c_uint, C.POINTER(_P)]),
+    "gpet_batch_set_images": (C.c_int, [_P, C.POINTER(_P), C.c_uint]),
     "gpet_batch_destroy": (None, [_P]),
     "gpet_batch_size": (C.c_int, [_P]),
     "gpet_batch_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_int]),
@@ -77,6 +81,8 @@ SYMBOLS = {
     "gpet_gp_sample": (C.c_int, [_P]),
     "gpet_score_curves": (C.c_int, [_P]),
     "gpet_select_pixels": (C.c_int, [_P]),
+    "gpet_curve_kde": (C.c_int, [_P]),
+    "gpet_final_cov": (C.c_int, [_P]),
     "gpet_select_pixels_only": (C.c_int, [_P]),
     "gpet_final_set_training": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "gpet_lml_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
@@ -184,22 +190,48 @@ _DT = {BUF_X_TRAIN: np.float64, BUF_Y_TRAIN: np.float64, BUF_CHOL: np.float64, B
 class Batch:
     """gpet_batch: B independent edges processed together."""
 
-    def __init__(self, ctx: Context, grads, params, inits, share_image=False):
+    def __init__(self, ctx: Context, grads, params, inits, share_image=False, device_ptrs=None, shape=None):
+        """``grads``: float32 (M, N) arrays on the host -- or, with ``device_ptrs`` (a list of integer device
+        addresses of f32 [M*N] images on the context's device, e.g. ``tensor.data_ptr()`` after an RCCL broadcast) and
+        ``shape`` = (M, N), nothing on the host at all: the library consumes the device images in place."""
         self.ctx = ctx
         self.lib = ctx.lib
         B = len(params)
-        grads = [np.ascontiguousarray(g, dtype=np.float32) for g in grads]
-        self.M, self.N = grads[0].shape
         inits = [np.ascontiguousarray(i, dtype=np.int64) for i in inits]
-        gp = (_P * len(grads))(*[g.ctypes.data for g in grads])
+        if device_ptrs is not None:
+            self.M, self.N = int(shape[0]), int(shape[1])
+            gp = (_P * len(device_ptrs))(*[int(p) for p in device_ptrs])
+            flags = GRAD_ON_DEVICE
+            grads = None
+        else:
+            grads = [np.ascontiguousarray(g, dtype=np.float32) for g in grads]
+            self.M, self.N = grads[0].shape
+            gp = (_P * len(grads))(*[g.ctypes.data for g in grads])
+            flags = 0
         ip = (_P * B)(*[i.ctypes.data for i in inits])
         pa = (GpetParams * B)(*params)
         h = _P()
-        ctx.check(self.lib.gpet_batch_create(ctx.h, B, self.M, self.N, gp, 1 if share_image else 0, pa, ip,
-                                             C.byref(h)))
+        ctx.check(self.lib.gpet_batch_create2(ctx.h, B, self.M, self.N, gp, 1 if share_image else 0, pa, ip, flags,
+                                              C.byref(h)))
         self.h = h
         self.B = B
+        self._scored = False
+        self.share_image = bool(share_image)
         self._keep = (grads, inits)
+
+    def set_images(self, grads=None, device_ptrs=None):
+        """Next frame(s) of an image sequence for the same edges: new gradient image(s), gradient KDE recomputed,
+        loop state reset (gpet_batch_set_images)."""
+        n_img = 1 if self.share_image else self.B
+        if device_ptrs is not None:
+            assert len(device_ptrs) == n_img
+            gp = (_P * n_img)(*[int(p) for p in device_ptrs])
+            self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, GRAD_ON_DEVICE))
+            return
+        grads = [np.ascontiguousarray(g, dtype=np.float32) for g in grads]
+        assert len(grads) == n_img and all(g.shape == (self.M, self.N) for g in grads)
+        gp = (_P * n_img)(*[g.ctypes.data for g in grads])
+        self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, 0))
 
     def _max_info(self, key):
         """max over the edges of a creation-time constant of gpet_batch_info (cached)."""
@@ -219,6 +251,14 @@ class Batch:
         s = GpetScalars()
         self.ctx.check(self.lib.gpet_batch_read(self.h, e, BUF_SCALARS, C.byref(s), C.sizeof(s)))
         return s
+
+    def write_scalars(self, s, e=0):
+        self.ctx.check(self.lib.gpet_batch_write(self.h, e, BUF_SCALARS, C.byref(s), C.sizeof(s), 0))
+
+    @property
+    def have_scores(self):
+        """True once a scoring pass has left costs / best indices on the device (gpet_score_curves or the loop)."""
+        return bool(self._scored)
 
     def all_scalars(self):
         arr = (GpetScalars * self.B)()
@@ -266,6 +306,7 @@ class Batch:
 
     def score(self):
         self.ctx.check(self.lib.gpet_score_curves(self.h))
+        self._scored = True
 
     def reset(self):
         self.ctx.check(self.lib.gpet_batch_reset(self.h))
@@ -326,10 +367,20 @@ class Batch:
     def select_pixels(self):
         self.ctx.check(self.lib.gpet_select_pixels(self.h))
 
+    def select_pixels_only(self):
+        self.ctx.check(self.lib.gpet_select_pixels_only(self.h))
+
+    def curve_kde(self):
+        self.ctx.check(self.lib.gpet_curve_kde(self.h))
+
+    def final_cov(self):
+        self.ctx.check(self.lib.gpet_final_cov(self.h))
+
     def iterate(self, base_seeds, max_iters):
         s = (C.c_uint32 * self.B)(*[int(v) & 0xFFFFFFFF for v in base_seeds])
         n = C.c_int()
         self.ctx.check(self.lib.gpet_trace_iterate(self.h, s, int(max_iters), C.byref(n)))
+        self._scored = self._scored or int(max_iters) > 0
         return n.value
 
     def close(self):

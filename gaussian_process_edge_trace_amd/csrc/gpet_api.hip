@@ -20,6 +20,8 @@ struct gpet_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char* scratch = nullptr;  // device scratch of the a1 entry points (gpet_grad_image / gpet_normalise_f32), grown on demand
+  size_t scratch_bytes = 0;
   std::string err;
 };
 
@@ -55,6 +57,7 @@ struct gpet_batch {
   int norm_issued = 0;                 // iterations whose normals have been enqueued on `side`
   hipEvent_t ev_main = nullptr;
   unsigned int* d_minmax = nullptr;
+  float* d_raw = nullptr;  // [M*N] staging of a user gradient image before its re-normalisation (gpet.py:97)
   int share_image = 0;
   bool structured = false;  // every edge can take the prior-eigenbasis loop path
   // converged-fit scratch (grown on demand)
@@ -238,6 +241,7 @@ void gpet_ctx_destroy(gpet_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->scratch) (void)hipFree(c->scratch);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -267,6 +271,19 @@ int gpet_timer_stop_ms(gpet_ctx* c, float* ms) {
 }
 
 // ---- a1 -------------------------------------------------------------------------------
+// The a1 entry points keep their device scratch in the context: one allocation, grown on demand, freed with the
+// context -- nothing to leak on an error path and no hipMalloc/hipFree per call.
+static int ctx_scratch(gpet_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return GPET_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->scratch) (void)hipFree(c->scratch);
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return GPET_OK;
+}
+
 int gpet_grad_image(gpet_ctx* c, const double* img, int M, int N, const double* kern, int kh, int kw, float* out) {
   if (!c || !img || !kern || !out || M <= 0 || N <= 0 || kh <= 0 || kw <= 0) return fail(c, GPET_ERR_BAD_ARG, "gpet_grad_image: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
@@ -276,14 +293,21 @@ int gpet_grad_image(gpet_ctx* c, const double* img, int M, int N, const double* 
   for (int a = 0; a < kh; ++a)
     for (int b = 0; b < kw; ++b) wf[(size_t)a * kw + b] = kern[(size_t)(kh - 1 - a) * kw + (kw - 1 - b)];
   const int oy = kh / 2 - ((kh % 2 == 0) ? 1 : 0), ox = kw / 2 - ((kw % 2 == 0) ? 1 : 0);
-  double *d_img = nullptr, *d_wf = nullptr;
-  float *d_tmp = nullptr, *d_out = nullptr;
-  unsigned int* d_mm = nullptr;
-  HIPCHK(c, hipMalloc(&d_img, px * sizeof(double)));
-  HIPCHK(c, hipMalloc(&d_wf, wf.size() * sizeof(double)));
-  HIPCHK(c, hipMalloc(&d_tmp, px * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_out, px * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_mm, 2 * sizeof(unsigned int)));
+  Carver meas;
+  (void)meas.take<double>(px);
+  (void)meas.take<double>(wf.size());
+  (void)meas.take<float>(px);
+  (void)meas.take<float>(px);
+  (void)meas.take<unsigned int>(2);
+  int rc = ctx_scratch(c, meas.off + 256);
+  if (rc) return rc;
+  Carver cv;
+  cv.base = c->scratch;
+  double* d_img = cv.take<double>(px);
+  double* d_wf = cv.take<double>(wf.size());
+  float* d_tmp = cv.take<float>(px);
+  float* d_out = cv.take<float>(px);
+  unsigned int* d_mm = cv.take<unsigned int>(2);
   const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
   HIPCHK(c, hipMemcpyAsync(d_img, img, px * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_wf, wf.data(), wf.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -292,22 +316,23 @@ int gpet_grad_image(gpet_ctx* c, const double* img, int M, int N, const double* 
   HIPCHK(c, launch_normalise(c->stream, d_tmp, px, d_mm, d_out));
   HIPCHK(c, hipMemcpyAsync(out, d_out, px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_img);
-  (void)hipFree(d_wf);
-  (void)hipFree(d_tmp);
-  (void)hipFree(d_out);
-  (void)hipFree(d_mm);
   return GPET_OK;
 }
 
 int gpet_normalise_f32(gpet_ctx* c, const float* img, size_t count, float* out) {
   if (!c || !img || !out || count == 0) return fail(c, GPET_ERR_BAD_ARG, "gpet_normalise_f32: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  float *d_in = nullptr, *d_out = nullptr;
-  unsigned int* d_mm = nullptr;
-  HIPCHK(c, hipMalloc(&d_in, count * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_out, count * sizeof(float)));
-  HIPCHK(c, hipMalloc(&d_mm, 2 * sizeof(unsigned int)));
+  Carver meas;
+  (void)meas.take<float>(count);
+  (void)meas.take<float>(count);
+  (void)meas.take<unsigned int>(2);
+  int rc = ctx_scratch(c, meas.off + 256);
+  if (rc) return rc;
+  Carver cv;
+  cv.base = c->scratch;
+  float* d_in = cv.take<float>(count);
+  float* d_out = cv.take<float>(count);
+  unsigned int* d_mm = cv.take<unsigned int>(2);
   const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
   HIPCHK(c, hipMemcpyAsync(d_in, img, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_mm, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
@@ -315,22 +340,56 @@ int gpet_normalise_f32(gpet_ctx* c, const float* img, size_t count, float* out) 
   HIPCHK(c, launch_normalise(c->stream, d_in, count, d_mm, d_out));
   HIPCHK(c, hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  (void)hipFree(d_mm);
   return GPET_OK;
 }
 
 // ---- batch ----------------------------------------------------------------------------
 
+namespace {
+// frees a half-built batch (arena, streams, events, tables, staging buffer) on every early return
+struct BatchGuard {
+  gpet_batch* b = nullptr;
+  ~BatchGuard() {
+    if (b) gpet_batch_destroy(b);
+  }
+};
+}  // namespace
+
+// gradient image(s) as the user passes them -> re-normalised f32 on the device (gpet.py:97).
+// GPET_GRAD_ON_DEVICE: grad[] are device pointers (e.g. the tensor an RCCL broadcast has just filled): consumed in
+// place, no trip through host memory.
+static int upload_images(gpet_batch* b, const float* const* grad, unsigned int flags) {
+  gpet_ctx* c = b->ctx;
+  const size_t px = (size_t)b->bd.M * b->bd.N;
+  const int n_img = b->share_image ? 1 : b->B;
+  const hipMemcpyKind up = (flags & GPET_GRAD_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  for (int g = 0; g < n_img; ++g) {
+    if (!grad[g]) return fail(c, GPET_ERR_BAD_ARG, "gradient image %d is a null pointer", g);
+    const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
+    HIPCHK(c, hipMemcpyAsync(b->d_raw, grad[g], px * sizeof(float), up, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d_minmax, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_minmax(c->stream, b->d_raw, px, b->d_minmax));
+    HIPCHK(c, launch_normalise(c->stream, b->d_raw, px, b->d_minmax, (float*)b->h_edges[g].grad));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host copy of mm0 / a pageable source must stay valid)
+  }
+  return GPET_OK;
+}
+
 int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad, int share_image,
                       const gpet_params* params, const int64_t* const* init_xy, gpet_batch** out) {
+  return gpet_batch_create2(c, B, M, N, grad, share_image, params, init_xy, 0u, out);
+}
+
+int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* grad, int share_image,
+                       const gpet_params* params, const int64_t* const* init_xy, unsigned int flags, gpet_batch** out) {
   if (!c || !out || B <= 0 || M < 2 || N < 2 || !grad || !params || !init_xy)
     return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_create: bad argument");
   *out = nullptr;
   HIPCHK(c, hipSetDevice(c->device));
   gpet_batch* b = new (std::nothrow) gpet_batch();
   if (!b) return fail(c, GPET_ERR_HIP, "out of host memory");
+  BatchGuard guard;
+  guard.b = b;
   b->ctx = c;
   b->B = B;
   b->share_image = share_image ? 1 : 0;
@@ -351,14 +410,10 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
     memset(&E, 0, sizeof E);
     const int Lg = p.x_en - p.x_st + 1;
     if (p.x_st < 0 || p.x_en >= N || Lg < 4 || p.n_init < 1 || p.n_samples < 1 || p.n_keep < 0 ||
-        p.n_keep > p.n_samples || p.delta_x < 1 || p.length_scale <= 0) {
-      delete b;
+        p.n_keep > p.n_samples || p.delta_x < 1 || p.length_scale <= 0)
       return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_create: edge %d has inconsistent parameters", e);
-    }
-    if (p.kernel_type == GPET_KERNEL_MATERN && nu_to_code(p.nu) < 0) {
-      delete b;
+    if (p.kernel_type == GPET_KERNEL_MATERN && nu_to_code(p.nu) < 0)
       return fail(c, GPET_ERR_UNSUPPORTED, "Matern nu=%g not supported (0.5, 1.5, 2.5 only)", p.nu);
-    }
     E.M = M;
     E.N = N;
     E.x_st = p.x_st;
@@ -426,7 +481,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   b->arena_bytes = meas.off + 256;
   hipError_t he = hipMalloc(&b->arena, b->arena_bytes);
   if (he != hipSuccess) {
-    delete b;
+    b->arena = nullptr;
     return fail(c, GPET_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", b->arena_bytes, hipGetErrorString(he));
   }
   HIPCHK(c, hipMemsetAsync(b->arena, 0, b->arena_bytes, c->stream));
@@ -472,18 +527,11 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_pix[i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
-  float* d_raw = nullptr;
-  HIPCHK(c, hipMalloc(&d_raw, px * sizeof(float)));
-  const int n_img = b->share_image ? 1 : B;
-  for (int g = 0; g < n_img; ++g) {
-    const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
-    HIPCHK(c, hipMemcpyAsync(d_raw, grad[g], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(b->d_minmax, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_minmax(c->stream, d_raw, px, b->d_minmax));
-    HIPCHK(c, launch_normalise(c->stream, d_raw, px, b->d_minmax, (float*)b->h_edges[g].grad));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMalloc(&b->d_raw, px * sizeof(float)));
+  {
+    int rcu = upload_images(b, grad, flags);
+    if (rcu) return rcu;
   }
-  (void)hipFree(d_raw);
   for (int e = 0; e < B; ++e) {
     EdgeDev& E = b->h_edges[e];
     HIPCHK(c, hipMemcpyAsync((void*)E.init_xy, init_xy[e], sizeof(long long) * 2 * E.n_init, hipMemcpyHostToDevice,
@@ -503,6 +551,11 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
   b->structured = false;
   if (!any_big && !getenv("GPET_NO_STRUCT")) {
     bool ok = true;
+    // without fix_endpoints the pixel selection admits every image column (gpet.py:655-657 only filters when it is
+    // set), so the loop can accept observations outside [x_st, x_en] unless the edge spans the whole image: those are
+    // not on the grid the prior eigenbasis indexes
+    for (int e = 0; e < B && ok; ++e)
+      if (!b->h_edges[e].fix_endpoints && !(b->h_edges[e].x_st == 0 && b->h_edges[e].x_en == N - 1)) ok = false;
     for (int e = 0; e < B && ok; ++e)
       for (int i = 0; i < b->h_edges[e].n_init; ++i) {
         const int64_t x = init_xy[e][2 * i];
@@ -540,6 +593,7 @@ int gpet_batch_create(gpet_ctx* c, int B, int M, int N, const float* const* grad
       b->structured = ok;
     }
   }
+  guard.b = nullptr;  // success: the caller owns the batch
   *out = b;
   return GPET_OK;
 }
@@ -554,6 +608,7 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_seeds_act) (void)hipFree(b->d_seeds_act);
   if (b->d_seeds) (void)hipFree(b->d_seeds);
   if (b->d_minmax) (void)hipFree(b->d_minmax);
+  if (b->d_raw) (void)hipFree(b->d_raw);
   if (b->ev_l0) (void)hipEventDestroy(b->ev_l0);
   if (b->ev_l1) (void)hipEventDestroy(b->ev_l1);
   if (b->d_fin_stage) (void)hipFree(b->d_fin_stage);
@@ -628,6 +683,12 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
   if (n_obs > E.obs_cap) return fail(c, GPET_ERR_BAD_ARG, "n_obs=%d exceeds obs_cap=%d", n_obs, E.obs_cap);
+  // the pixel kernels index the density images with the observations (gpet.py:568: kde_arr[pre_fobs[:,0], pre_fobs[:,1]]
+  // raises IndexError in the reference for pixels outside the image)
+  for (int i = 0; i < n_obs; ++i)
+    if (obs_xy[2 * i] < 0 || obs_xy[2 * i] >= E.N || obs_xy[2 * i + 1] < 0 || obs_xy[2 * i + 1] >= E.M)
+      return fail(c, GPET_ERR_BAD_ARG, "observation %d = (%lld, %lld) lies outside the %d x %d image", i,
+                  (long long)obs_xy[2 * i], (long long)obs_xy[2 * i + 1], E.M, E.N);
   HIPCHK(c, hipSetDevice(c->device));
   gpet_scalars s;
   int rc = read_scalars(b, e, &s);
@@ -756,6 +817,10 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
     case GPET_BUF_GRAD_KDE: dst = (void*)E.grad_kde; cap = px * 4; break;
     case GPET_BUF_KDE: dst = E.kde; cap = px * 4; break;
     case GPET_BUF_COSTS: dst = E.costs; cap = (size_t)E.S * 8; break;
+    case GPET_BUF_BEST_IDX: dst = E.best_idx; cap = (size_t)E.n_keep * 4; b->have_scores = true; break;
+    case GPET_BUF_BEST_COSTS: dst = E.best_costs; cap = (size_t)E.n_keep * 8; break;
+    case GPET_BUF_MEAN: dst = E.mean; cap = Lg * 8; break;
+    case GPET_BUF_COV: dst = E.cov; cap = Lg * Lg * 8; b->have_fit = true; break;
     case GPET_BUF_SCALARS: dst = E.sc; cap = sizeof(gpet_scalars); break;
     default:
       return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: buffer %d is not writable", which);
@@ -838,6 +903,29 @@ int gpet_score_curves(gpet_batch* b) {
   return GPET_OK;
 }
 
+int gpet_curve_kde(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  if (!b->have_scores) return fail(c, GPET_ERR_STATE, "gpet_curve_kde before gpet_score_curves");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
+  HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0));
+  HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
+  return check_device_status(b);
+}
+
+int gpet_final_cov(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int e = 0; e < b->B; ++e)
+    if (b->h_edges[e].fin_n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_cov before gpet_final_predict_all");
+  HIPCHK(c, launch_final_cov(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->have_fit = true;  // (mean in the caller's hands, covariance in GPET_BUF_COV: gpet_gp_factor may follow)
+  return GPET_OK;
+}
+
 int gpet_select_pixels(gpet_batch* b) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -866,6 +954,19 @@ int gpet_batch_reset(gpet_batch* b) {
   HIPCHK(c, hipMemcpyAsync(b->d_scalars, b->h_scalars.data(), sizeof(gpet_scalars) * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GPET_OK;
+}
+
+int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int flags) {
+  if (!b || !grad) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = upload_images(b, grad, flags);
+  if (rc) return rc;
+  // gradient KDE of every distinct image (gpet.py:127), then the state of a fresh constructor
+  HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : b->B, b->bd, 1));
+  b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = false;
+  return gpet_batch_reset(b);
 }
 
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
@@ -1021,6 +1122,9 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
     if (b->d_theta) (void)hipFree(b->d_theta);
     if (b->d_f) (void)hipFree(b->d_f);
     if (b->d_g) (void)hipFree(b->d_g);
+    b->d_edge_of = nullptr;
+    b->d_theta = b->d_f = b->d_g = nullptr;
+    b->lml_cap = 0;
     const int cap = P * 2;
     HIPCHK(c, hipMalloc(&b->d_edge_of, sizeof(int) * cap));
     HIPCHK(c, hipMalloc(&b->d_theta, sizeof(double) * 3 * cap));

@@ -16,6 +16,7 @@ hipError_t launch_normalise(hipStream_t st, const float* d_in, size_t count, con
 hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int want_cov,
                               unsigned parts = ~0u);
 hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_final_cov(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
 // dynamic LDS available to k_struct_H (the structured path needs at least U + one row of L + beta in it)
 #define STRUCT_H_LDS_MAX (150 * 1024)

@@ -2029,10 +2029,12 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
 // both operands are 32-row chunks of V; only tiles on or above the diagonal are computed and mirrored.
-__global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges) {
+// final_mode: covariance of the converged fit (GaussianProcessRegressor.predict(return_cov=True) on the standardised
+// grid, sklearn_gpr.py:398-403) from the V that k_predict<.., FINAL> left behind.
+__global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges, int final_mode) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  if (!final_mode && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
   const int bx = blockIdx.x, by = blockIdx.y;
   if (bx < by) return;
   const int Lg = E.Lg;
@@ -2070,13 +2072,15 @@ __global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges) {
   for (int t = 0; t < 4; ++t) {
     const int c = c0 + 16 * t + li;
     if (c >= Lg) continue;
-    const double xc = (double)(E.x_st + c) / E.length_scale;
+    const double xoff = final_mode ? E.fin_par[3] : 0.0, xsc = final_mode ? E.fin_par[4] : 1.0;
+    const double length = final_mode ? E.fin_par[1] : E.length_scale;
+    const double xc = (((double)(E.x_st + c) - xoff) / xsc) / length;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = r0 + 16 * w + lq + 4 * g;
       if (r >= Lg) continue;
       if (bx == by && c < r) continue;  // diagonal tile: the mirror write below covers it
-      const double k = (r == c) ? amp : amp * corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + r) / E.length_scale, xc);
+      const double k = (r == c) ? amp : amp * corr_fn(E.kernel_type, E.nu_code, (((double)(E.x_st + r) - xoff) / xsc) / length, xc);
       const double val = (k - acc[t][g]) * s2;
       E.cov[(size_t)r * Lg + c] = val;
       E.cov[(size_t)c * Lg + r] = val;
@@ -3407,8 +3411,15 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
     hipLaunchKernelGGL((k_predict<false, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), 0, st, d_edges, 0);
   if (want_cov && (parts & 4u)) {
     const int t = cdiv(bd.Lg, 64);
-    hipLaunchKernelGGL(k_cov_mfma, dim3(t, t, B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_cov_mfma, dim3(t, t, B), dim3(256), 0, st, d_edges, 0);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_final_cov(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();
+  const int t = cdiv(bd.Lg, 64);
+  hipLaunchKernelGGL(k_cov_mfma, dim3(t, t, B), dim3(256), 0, st, d_edges, 1);
   return hipGetLastError();
 }
 

@@ -126,9 +126,14 @@ class GP_Edge_Tracing(object):
     def fit_predict_GP(self, obs, converged=False, seed=0):
         """Not-converged branch: returns ``N_samples`` posterior curves, shape (N, N_samples),
         exactly like the reference (a transposed view of the row-per-sample device buffer)."""
-        if converged:
-            raise NotImplementedError("converged fit runs through GP_Edge_Tracing.__call__")
         b = self._batch
+        if converged:
+            # gpet.py:232-248,262-266: hyper-parameters optimised (1 + 12 L-BFGS-B starts), returns (mean in pixels,
+            # std in standardised units -- the reference does not rescale it)
+            obs = np.asarray(obs).reshape(-1, 2).astype(np.int64)
+            fits, _ = device_final_fits(b, [dict(self._p, seed=int(seed))], [obs], [0])
+            y_mean_optim, y_std, self._theta = fits[0]
+            return y_mean_optim, y_std
         b.set_obs(0, obs)
         b.fit_predict(want_cov=True)
         b.factor()
@@ -152,22 +157,94 @@ class GP_Edge_Tracing(object):
         return curves, costs, (curves[:, 0, :], costs[0])
 
     def cost_funct(self, edge):
-        """Cost of one curve given as (N, 2) xy (gpet.py:371-410)."""
+        """Cost of one curve given as (N, 2) xy (gpet.py:371-410).  The device scores whole sample sets, so the curve
+        takes the place of sample 0 for one scoring pass; the samples and the scores of the set are restored after it."""
         edge = np.asarray(edge, dtype=np.float64)
         edge = edge[edge[:, 0].argsort(), :]
         b = self._batch
+        have = b.have_scores
         Y = b.read(_lib.BUF_SAMPLES)
+        saved = (Y[0].copy(), b.read(_lib.BUF_COSTS), b.read(_lib.BUF_BEST_IDX), b.read(_lib.BUF_BEST_COSTS))
         Y[0] = edge[:, 1]
         b.write(_lib.BUF_SAMPLES, Y)
         b.score()
-        return float(b.read(_lib.BUF_COSTS)[0])
+        cost = float(b.read(_lib.BUF_COSTS)[0])
+        Y[0] = saved[0]
+        b.write(_lib.BUF_SAMPLES, Y)
+        if have:
+            b.write(_lib.BUF_COSTS, saved[1])
+            b.write(_lib.BUF_BEST_IDX, saved[2])
+            b.write(_lib.BUF_BEST_COSTS, saved[3])
+        return cost
 
-    # ---- gpet.py:622-662 ---------------------------------------------------------------
-    def get_best_pixels(self, best_curves=None, costs=None, pre_fobs=None):
-        """KDE of the best curves + pixel scoring / binning / non-max suppression on the device,
-        for the curves scored last.  Returns the new observation set (xy int64)."""
+    # ---- gpet.py:455-662 ---------------------------------------------------------------
+    def _upload_best(self, best_curves, costs):
+        """A caller's own best curves (N, n_keep, 2) xy + costs (n_keep,) become samples 0..n_keep-1 of the device's
+        sample set, selected in that order."""
+        bc = np.asarray(best_curves, dtype=np.float64)
+        costs = np.asarray(costs, dtype=np.float64).reshape(-1)
         b = self._batch
+        inf = b.info()
+        if bc.ndim != 3 or bc.shape[0] != inf["Lg"] or bc.shape[1] != inf["n_keep"] or costs.shape[0] != inf["n_keep"]:
+            raise ValueError("best_curves must be (edge_length, N_keep, 2) = (%d, %d, 2) with N_keep costs"
+                             % (inf["Lg"], inf["n_keep"]))
+        if not np.array_equal(bc[:, 0, 0], self.x_grid.astype(np.float64)):
+            raise ValueError("best_curves must be sampled on the tracer's x-grid")
+        Y = b.read(_lib.BUF_SAMPLES)
+        Y[:inf["n_keep"]] = bc[:, :, 1].T
+        b.write(_lib.BUF_SAMPLES, Y)
+        b.write(_lib.BUF_BEST_IDX, np.arange(inf["n_keep"], dtype=np.int32))
+        b.write(_lib.BUF_BEST_COSTS, costs)
+
+    def kernel_density_estimate(self, best_curves=None, costs=None):
+        """(M, N) float64 density image, min-max normalised in float32 (gpet.py:455-529): of the gradient image when
+        called without curves (what the constructor stores as ``grad_kde``, gpet.py:127), else the cost-weighted KDE of
+        ``best_curves`` (N, N_keep, 2) with ``costs`` (N_keep,)."""
+        b = self._batch
+        if best_curves is None:
+            return b.read(_lib.BUF_GRAD_KDE).astype(np.float64)
+        self._upload_best(best_curves, costs)
+        b.curve_kde()
+        return b.read(_lib.BUF_KDE).astype(np.float64)
+
+    def compute_new_obs(self, pixel_idx, kde_arr, pre_fobs):
+        """Pixel scoring, threshold decay, binning and per-bin argmax (gpet.py:532-618) on ``kde_arr``.
+        ``pre_fobs`` is in yx order like in the reference; the new observation set comes back as xy int64.
+        ``pixel_idx`` is implied by ``kde_arr`` (gpet.py:651-657); a different candidate list is rejected."""
+        kde_arr = np.asarray(kde_arr)
+        cand = np.argwhere(kde_arr > self.kde_thresh)
+        if self.fix_endpoints:
+            cand = cand[(cand[:, 1] > self.x_st) & (cand[:, 1] < self.x_en)]
+        if pixel_idx is not None and not np.array_equal(np.asarray(pixel_idx), cand):
+            raise ValueError("pixel_idx must be the candidates get_best_pixels derives from kde_arr (gpet.py:651-657)")
+        b = self._batch
+        thresh = b.scalars().score_thresh
+        pre = np.asarray(pre_fobs).reshape(-1, 2)[:, [1, 0]].astype(np.int64)
+        b.set_obs(0, pre)
+        sc = b.scalars()
+        sc.score_thresh = thresh
+        b.write_scalars(sc)
+        b.write(_lib.BUF_KDE, kde_arr.astype(np.float32))
+        b.select_pixels_only()
+        self.score_thresh = b.scalars().score_thresh
+        return b.read(_lib.BUF_OBS)
+
+    def get_best_pixels(self, best_curves=None, costs=None, pre_fobs=None):
+        """KDE of the best curves + pixel scoring / binning / non-max suppression on the device (gpet.py:622-662).
+        Arguments given => they are what is used (``pre_fobs`` in yx order, as the reference passes it); arguments
+        omitted => the curves scored last and the observation set already on the device.  Returns the new
+        observation set (xy int64)."""
+        b = self._batch
+        if pre_fobs is not None:
+            thresh = b.scalars().score_thresh
+            b.set_obs(0, np.asarray(pre_fobs).reshape(-1, 2)[:, [1, 0]].astype(np.int64))
+            sc = b.scalars()
+            sc.score_thresh = thresh
+            b.write_scalars(sc)
+        if best_curves is not None:
+            self._upload_best(best_curves, costs)
         b.select_pixels()
+        self.score_thresh = b.scalars().score_thresh
         return b.read(_lib.BUF_OBS)
 
     def __call__(self, print_final_diagnostics=False, show_init_post=False, show_post_iter=False, verbose=False,
@@ -185,8 +262,10 @@ class GP_Edge_Tracing(object):
         b = self._batch
         b.set_obs(0, self.obs)
         n_iter = 0
-        step = 1 if (return_lines or verbose) else 4
         while not b.scalars().done:
+            if n_iter >= max_iter:
+                raise _lib.GpetError(_lib.ERR_ITER_CAP, f"trace did not converge in {max_iter} iterations")
+            step = min(1 if (return_lines or verbose) else 4, max_iter - n_iter)
             st = t.time()
             if verbose:
                 print('Fitting Gaussian process and computing next set of observations...')
@@ -202,8 +281,6 @@ class GP_Edge_Tracing(object):
             if verbose:
                 print(f'Number of observations: {s.n_obs}')
                 print(f'Iteration {n_iter + 1} - Time Elapsed: {round(t.time() - st, 4)}\n\n')
-            if n_iter >= max_iter:
-                raise _lib.GpetError(_lib.ERR_ITER_CAP, f"trace did not converge in {max_iter} iterations")
         self._n_iter = n_iter
         pre_fobs = b.read(_lib.BUF_OBS)
         self.score_thresh = b.scalars().score_thresh
@@ -285,19 +362,37 @@ class GP_Edge_Tracing_Batch(object):
     """
 
     def __init__(self, inits, grad_imgs, seeds, kernel_options=(1, 3, 3), noise_y=1, N_samples=500, score_thresh=1,
-                 delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, device=0,
-                 stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None, fit_farm=None):
-        share = not isinstance(grad_imgs, (list, tuple))
-        imgs = [grad_imgs] if share else list(grad_imgs)
+                 delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, obs=None,
+                 device=0, stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None, fit_farm=None,
+                 grad_device_ptrs=None, grad_shape=None):
+        """``obs``: optional list of per-edge warm-start observation sets (xy), the reference's ``obs`` constructor
+        argument (gpet.py:57-61,100,820).  ``grad_device_ptrs`` + ``grad_shape``: the gradient image(s) already live
+        on this GPU (e.g. a torch tensor an RCCL broadcast filled): integer device addresses of f32 (M, N) arrays,
+        consumed in place instead of ``grad_imgs``."""
+        on_dev = grad_device_ptrs is not None
+        if on_dev:
+            ptrs = list(grad_device_ptrs) if isinstance(grad_device_ptrs, (list, tuple)) else [grad_device_ptrs]
+            share = len(ptrs) == 1
+            shapes = [tuple(grad_shape)] * len(inits)
+        else:
+            share = not isinstance(grad_imgs, (list, tuple))
+            imgs = [grad_imgs] if share else list(grad_imgs)
+            shapes = [np.asarray(imgs[0 if share else e]).shape for e in range(len(inits))]
         B = len(inits)
-        assert len(seeds) == B and (share or len(imgs) == B)
-        self._ps = [resolve_params(inits[e], np.asarray(imgs[0 if share else e]).shape, kernel_options, noise_y,
-                                   np.array([]), N_samples, score_thresh, delta_x, keep_ratio, pixel_thresh,
-                                   int(seeds[e]), return_std, fix_endpoints) for e in range(B)]
+        assert len(seeds) == B and (share or (len(ptrs) if on_dev else len(imgs)) == B)
+        obs = [np.array([])] * B if obs is None else list(obs)
+        self._ps = [resolve_params(inits[e], shapes[e], kernel_options, noise_y, obs[e], N_samples, score_thresh,
+                                   delta_x, keep_ratio, pixel_thresh, int(seeds[e]), return_std, fix_endpoints)
+                    for e in range(B)]
         self._ctx = _ctx if _ctx is not None else _lib.Context(device, stream)
-        g32 = [np.asarray(g).astype(np.float32) for g in imgs]
         abi = [to_abi_params(p, factor_cap=factor_cap, z_cols=z_cols) for p in self._ps]
-        self._batch = _lib.Batch(self._ctx, g32, abi, [p["init"] for p in self._ps], share_image=share)
+        if on_dev:
+            self._batch = _lib.Batch(self._ctx, None, abi, [p["init"] for p in self._ps], share_image=share,
+                                     device_ptrs=ptrs, shape=grad_shape)
+        else:
+            g32 = [np.asarray(g).astype(np.float32) for g in imgs]
+            self._batch = _lib.Batch(self._ctx, g32, abi, [p["init"] for p in self._ps], share_image=share)
+        self._set_obs()
         self.B = B
         self.return_std = return_std
         self.seeds = [int(s) for s in seeds]
@@ -308,8 +403,35 @@ class GP_Edge_Tracing_Batch(object):
         # optional LockstepFarm: worker processes that advance the L-BFGS-B problems of the final fits
         self._farm = fit_farm
 
+    def _set_obs(self):
+        for e, p in enumerate(self._ps):
+            if p["obs"].shape[0]:
+                self._batch.set_obs(e, p["obs"])
+
     def reset(self):
+        """Back to the state right after construction (the warm-start observations included)."""
         self._batch.reset()
+        self._set_obs()
+
+    def set_frame(self, grad_imgs=None, obs=None, seeds=None, grad_device_ptrs=None):
+        """The next frame of an image sequence for the same edges (gpet.py:57-61: the previous trace warm-starts the
+        next through ``obs``): new gradient image(s) -- host arrays, or device addresses with ``grad_device_ptrs`` --
+        new warm-start observations and, optionally, new seeds.  Geometry, kernel and every other parameter stay, so
+        what depends only on them (arena, streams, the prior eigenbasis of the structured loop path) is reused."""
+        if grad_device_ptrs is not None:
+            self._batch.set_images(device_ptrs=list(grad_device_ptrs) if isinstance(grad_device_ptrs, (list, tuple))
+                                   else [grad_device_ptrs])
+        else:
+            imgs = list(grad_imgs) if isinstance(grad_imgs, (list, tuple)) else [grad_imgs]
+            self._batch.set_images([np.asarray(g).astype(np.float32) for g in imgs])
+        obs = [np.array([])] * self.B if obs is None else list(obs)
+        for e, p in enumerate(self._ps):
+            p["obs"] = np.asarray(obs[e]).reshape(-1, 2).astype(np.int64)
+            if seeds is not None:
+                p["seed"] = int(seeds[e])
+        if seeds is not None:
+            self.seeds = [int(v) for v in seeds]
+        self._set_obs()
 
     def run_loop(self, max_iter=1000, chunk=64):
         """The device-resident while-loops of all edges (gpet.py:829-870); returns iterations per edge.

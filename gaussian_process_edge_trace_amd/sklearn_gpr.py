@@ -6,8 +6,9 @@ exercises -- ``fit`` with ``optimizer=None`` and ``predict`` (mean / std) -- wit
 modified ``normalize_y`` semantics (True centres only, False standardises; sklearn_gpr.py:221-234)
 and runs them in libgpet_hip.so (the kernels of the converged fit: Cholesky + alpha + forward
 substitution per query point).  Query points must be an arithmetic progression (the tracer's
-x-grid).  Posterior draws go through ``GP_Edge_Tracing.fit_predict_GP`` (the sample path is built
-around the pixel grid); ``sample_y`` and hyper-parameter optimisation are not offered here.
+x-grid).  ``predict(return_cov=True)``, ``sample_y`` (the device eigen-factor sampler on the query grid)
+and ``log_marginal_likelihood`` run on the device too; hyper-parameter optimisation (``optimizer != None``)
+lives in ``GP_Edge_Tracing`` (the converged fit), not here.
 """
 from __future__ import annotations
 
@@ -99,22 +100,22 @@ class GaussianProcessRegressor(object):
         self.X_train_, self.y_train_ = X, yt
         return self
 
-    def predict(self, X, return_std=False, return_cov=False):
-        if return_cov:
-            raise NotImplementedError("covariances are produced inside GP_Edge_Tracing.fit_predict_GP")
+    def _device_fit_predict(self, X, n_samples=1, want_factor=False):
+        """One throw-away batch of a single edge whose grid is 0..Lq-1 ((x - X_m)/X_s maps it onto the query points):
+        the converged-fit kernels evaluate K, its Cholesky factor, alpha and the posterior at the queries."""
         f = self._fit
         xq = np.asarray(X, dtype=np.float64).reshape(-1)
         Lq = xq.shape[0]
         step = (xq[-1] - xq[0]) / (Lq - 1) if Lq > 1 else 1.0
         if Lq < 4 or step <= 0 or not np.allclose(xq, xq[0] + step * np.arange(Lq), rtol=0, atol=1e-9 * max(1.0, abs(step))):
             raise NotImplementedError("query points must be an increasing arithmetic progression of >= 4 points")
-        # one throw-away batch of a single edge whose grid is 0..Lq-1; (x - X_m)/X_s maps it onto xq
         p = _lib.GpetParams()
         p.kernel_type = _lib.KERNEL_MATERN if f["kt"] == "Matern" else _lib.KERNEL_RBF
         p.nu, p.sigma_f, p.length_scale, p.noise_y = f["nu"], 1.0, f["ell"], 1.0
-        p.n_samples, p.n_keep, p.delta_x, p.pixel_thresh, p.score_thresh = 1, 1, max(2, Lq // 4), 2, 1.0
+        p.n_samples, p.n_keep, p.delta_x, p.pixel_thresh, p.score_thresh = max(1, int(n_samples)), 1, max(2, Lq // 4), 2, 1.0
         p.fix_endpoints, p.x_st, p.x_en, p.n_init = 1, 0, Lq - 1, 1
-        p.obs_cap, p.factor_cap, p.z_cols, p.jitter = max(8, len(f["x"])), 4, 4, 0.0
+        p.obs_cap, p.jitter = max(8, len(f["x"])), 0.0
+        p.factor_cap, p.z_cols = (Lq, Lq) if want_factor else (4, 4)
         img = np.zeros((4, Lq), dtype=np.float32)
         img[0, 0] = 1.0
         b = _lib.Batch(self._ctx, [img], [p], [np.array([[0, 0]], dtype=np.int64)])
@@ -125,10 +126,57 @@ class GaussianProcessRegressor(object):
         par[0, :9] = [f["const"], f["ell"], 1.0, -xq[0] * X_s, X_s, 0.0, 1.0,
                       self._y_train_mean, self._y_train_std]
         mean, std = b.final_predict_all(par)
-        b.close()
+        return b, mean[0, :Lq].copy(), std[0, :Lq].copy()
+
+    def predict(self, X, return_std=False, return_cov=False):
+        """Posterior mean [, std | covariance] at an arithmetic progression of query points (sklearn_gpr.py:323-438)."""
+        if return_std and return_cov:
+            raise RuntimeError("At most one of return_std or return_cov can be requested.")  # sklearn_gpr.py:355-357
+        b, mean, std = self._device_fit_predict(X)
+        try:
+            if return_cov:
+                b.final_cov()  # (K** - V^T V) * y_train_std^2 on the f64 matrix cores
+                return mean, b.read(_lib.BUF_COV)
+        finally:
+            b.close()
         if return_std:
-            return mean[0, :Lq].copy(), std[0, :Lq].copy()
-        return mean[0, :Lq].copy()
+            return mean, std
+        return mean
 
     def sample_y(self, X, n_samples=1, random_state=0):
-        raise NotImplementedError("posterior draws: GP_Edge_Tracing.fit_predict_GP (device eigen-factor sampler)")
+        """``n_samples`` posterior curves at the query points, (N, n_samples), drawn like the reference draws them
+        (sklearn_gpr.py:440-473 -> numpy legacy ``multivariate_normal``): the RandomState(random_state) normal stream
+        times the sqrt(s) v rows of the covariance's symmetric SVD, all on the device.  Eigenvector signs follow the
+        library's convention (include/gpet_hip.h, gpet_gp_factor); LAPACK's are implementation-defined."""
+        n_samples = int(n_samples)
+        b, mean, _ = self._device_fit_predict(X, n_samples, want_factor=True)
+        try:
+            b.final_cov()
+            b.factor()
+            b.normals([int(random_state)])
+            sc = b.scalars()
+            sc.y_s = 1.0
+            b.write_scalars(sc)
+            b.write(_lib.BUF_MEAN, mean)
+            b.sample()
+            return b.read(_lib.BUF_SAMPLES).T.copy()
+        finally:
+            b.close()
+
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False):
+        """Log marginal likelihood of theta = log(constant, length_scale, noise_level) on the training set of ``fit``
+        [and its gradient] (sklearn_gpr.py:475-585), evaluated by the batched objective kernel of the converged fits;
+        theta=None: at the kernel's own hyper-parameters."""
+        f = self._fit
+        if len(f["x"]) > 250:
+            raise NotImplementedError("more than 250 training points")
+        if theta is None:
+            theta = np.log([f["const"], f["ell"], 1.0])
+        b, _, _ = self._device_fit_predict(np.arange(4.0))
+        try:
+            val, grad = b.lml_batch([0], np.asarray(theta, dtype=np.float64).reshape(1, 3))
+        finally:
+            b.close()
+        if eval_gradient:
+            return -float(val[0]), -grad[0]
+        return -float(val[0])

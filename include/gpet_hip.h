@@ -116,11 +116,12 @@ typedef struct gpet_batch gpet_batch;
 /* ---- context ------------------------------------------------------------------------ */
 int gpet_abi_version(void);
 
-/* Process-wide tuning switches (no reference counterpart).  name = "block_jacobi": 1 selects the two-level Jacobi
- * for full-rank posterior covariances (Matern: ~5x faster per iteration at 1024 columns, an equally valid eigen-
- * decomposition, but traces stop matching a LAPACK-based run after a few iterations -- the sampler is chaotic in
- * 1e-12 perturbations there); 0 (default, or environment GPET_JB_BLOCK unset) keeps the scalar rounds the parity
- * tests are passed with.  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
+/* Process-wide tuning switches (no reference counterpart).  name = "scalar_jacobi": 1 factors posterior covariances of
+ * rank > 96 (Matern; short-length-scale RBF) with round 1's whole-GPU scalar Jacobi on the covariance instead of the
+ * default (pivoted Cholesky over the GPU + one-sided block Jacobi on its rows, ~12x faster and closer to LAPACK's
+ * factor); kept as an independent cross-check.  name = "oj_tol_exp" (default 8) / "oj_max_sweeps" (default 16): the
+ * default solver stops after a sweep in which every pair of rows it met was orthogonal to 10^-x relative, or after
+ * that many sweeps.  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
  * run ahead of it (default 1; 0: it starts when the previous iteration's pixel selection is done, so nothing is drawn for
  * finished edges, but it then delays the start of every iteration; larger n only adds draws for edges that finish
  * meanwhile; results are identical).  name = "lml_two_tiles_from": launches of gpet_lml_batch with at least this many
@@ -152,6 +153,12 @@ int gpet_normalise_f32(gpet_ctx* ctx, const float* img, size_t count, float* out
  * edges.  params: B structs.  init_xy: B pointers to i64 [n_init*2], already sorted by x. */
 int gpet_batch_create(gpet_ctx* ctx, int B, int M, int N, const float* const* grad, int share_image,
                       const gpet_params* params, const int64_t* const* init_xy, gpet_batch** out);
+/* The same with flags.  GPET_GRAD_ON_DEVICE: grad[] are DEVICE pointers on the context's device (e.g. the data_ptr()
+ * of the torch tensor an RCCL broadcast over xGMI has just filled): the images are consumed in place, with
+ * no copy through host memory.  init_xy and params stay host pointers. */
+#define GPET_GRAD_ON_DEVICE 1u
+int gpet_batch_create2(gpet_ctx* ctx, int B, int M, int N, const float* const* grad, int share_image,
+                       const gpet_params* params, const int64_t* const* init_xy, unsigned int flags, gpet_batch** out);
 void gpet_batch_destroy(gpet_batch* b);
 int gpet_batch_size(const gpet_batch* b);
 /* out[0..count): Lg, S, n_keep, n_cap, factor_cap, z_cols, factor_rows_cap, n_bins, obs_cap, algo_thresh,
@@ -162,11 +169,19 @@ int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count);
  * iteration counter 0 (a GP_Edge_Tracing instance is single-use in the reference; benches re-run). */
 int gpet_batch_reset(gpet_batch* b);
 
+/* New gradient image(s) for an existing batch of the same geometry and parameters -- the next frame of an image
+ * sequence (gpet.py:57-61: a trace warm-starts the next one through `obs`): grad as in gpet_batch_create2 (one pointer
+ * if the batch shares its image, else B), re-normalised, gradient KDE recomputed (gpet.py:97,127), then
+ * gpet_batch_reset.  The per-edge work that depends only on the geometry and the kernel (the prior eigenbasis of the
+ * structured loop path) is kept. */
+int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int flags);
+
 /* set / get the observation set (xy int64) of edge e (gpet.py:100,820,857). */
 int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs);
 int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes);
 /* Writable: FACTOR (rows = factor rows; marks the factor as injected so gpet_gp_factor leaves
- * it alone), NORMALS, SAMPLES, COSTS, KDE, GRAD_KDE, SCALARS. */
+ * it alone), NORMALS, SAMPLES, COSTS, BEST_IDX, BEST_COSTS (a caller's own choice of best curves for
+ * gpet_curve_kde / gpet_select_pixels, gpet.py:622-648), MEAN, COV, KDE, GRAD_KDE, SCALARS. */
 int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t bytes, int rows);
 int gpet_batch_clear_injected_factor(gpet_batch* b, int e);
 
@@ -190,6 +205,9 @@ int gpet_gp_sample(gpet_batch* b);
 int gpet_score_curves(gpet_batch* b);
 
 /* ---- f1: get_best_pixels (gpet.py:455-662) --------------------------------------------- */
+/* kernel_density_estimate(best_curves, costs) alone (gpet.py:455-529): the normalised KDE of the curves
+ * GPET_BUF_BEST_IDX / _BEST_COSTS select among GPET_BUF_SAMPLES goes to GPET_BUF_KDE. */
+int gpet_curve_kde(gpet_batch* b);
 int gpet_select_pixels(gpet_batch* b);
 /* Pixel scoring / threshold decay / per-bin argmax only (gpet.py:532-618), on whatever curve KDE
  * is currently in GPET_BUF_KDE (tests inject the reference's). */
@@ -218,6 +236,9 @@ int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int st
  * constant, length_scale, noise_level (values, not logs), X_m, X_s, y_m, y_s, m2, s2, 0, 0, 0;
  * mean_out (pixels) and std_out (standardised units, as the reference returns it) are [B*stride]. */
 int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, double* std_out, int stride);
+/* GaussianProcessRegressor.predict(return_cov=True) (sklearn_gpr.py:398-403) for the fit gpet_final_predict_all has
+ * just evaluated: the Lg x Lg posterior covariance on the standardised grid goes to GPET_BUF_COV of every edge. */
+int gpet_final_cov(gpet_batch* b);
 /* Objective of the reference's L-BFGS-B runs for P problems at once: problem i evaluates
  * -log_marginal_likelihood and its gradient wrt theta_i = log(constant, length_scale, noise_level)
  * on edge edge_of[i]'s training set.  theta [P*3], f_out [P], g_out [P*3] (host).  A non-PD

@@ -1,0 +1,242 @@
+"""GPU parity of image-sequence tracing (BASELINE config 5: frames chained through the ``obs`` warm start,
+gp_edge_tracing/gpet.py:57-61,100,820,829; Matern-5/2) against the CPU oracle chained the same way, of the reference's
+per-method seams against the fixture arrays the unmodified reference produced, and of whole traces against the
+REFERENCE's own traces (tier T3, as numbers)."""
+import numpy as np
+import pytest
+
+from oracle import gpet_oracle as orc
+from tests.test_oracle_vs_golden import CTOR, STAGES, TRACES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gaussian_process_edge_trace_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def ctx(amd):
+    return amd._lib.Context(0)
+
+
+def make_sequence(amd, ctx, N, T, seed0=11):
+    """T frames of one drifting sinusoidal edge: amplitude grows 2 % per frame, fresh noise per frame; the end points
+    stay on row N//2 (the wave is zero at both ends), so one ``init`` serves every frame."""
+    frames, truths = [], []
+    for t in range(T):
+        img, truth = orc.synth_sinusoid_image(N, seed0 + t, amplitude=int(0.4 * N * (1.0 + 0.02 * t)))
+        frames.append(amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
+        truths.append(truth)
+    init = truths[0][[0, -1], :][:, [1, 0]]
+    return frames, truths, init
+
+
+def oracle_chain(frames, init, warm_every, seeds, kw):
+    """The reference's usage restated with the oracle: one trace per frame, frame t warm-started from every
+    ``warm_every``-th pixel of trace t-1 (the product's own thinning rule, host logic)."""
+    from gaussian_process_edge_trace_amd.sequence import warm_start_obs
+    out, iters, prev = [], [], None
+    for t, grad in enumerate(frames):
+        p = orc.resolve_params(init, grad, **kw)
+        obs = (np.zeros((0, 2), dtype=np.int64) if prev is None else
+               warm_start_obs(prev, p["x_st"], p["x_en"], warm_every, p["algo_thresh"], p["M"]))
+        et, ci, info = orc.trace(init, grad, obs=obs, seed=seeds[t], sign_convention="harmonic", **kw)
+        out.append(et)
+        iters.append(info["n_iter"])
+        prev = et
+    return out, iters
+
+
+@pytest.mark.parametrize("N,T,chains", [(512, 6, 2), (1024, 4, 2)])
+def test_matern_sequence_bit_exact_vs_chained_oracle(amd, ctx, N, T, chains):
+    """Matern-5/2 (full-rank posterior: the any-rank factor of gpet_eig.hip), T frames in `chains` chains traced as
+    batches of `chains` edges: every frame's trace and iteration count equal the oracle's chained run bit for bit --
+    cold first frames and warm-started later ones."""
+    frames, truths, init = make_sequence(amd, ctx, N, T)
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=300, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    seeds = [3 + t for t in range(T)]
+    st = amd.SequenceTracer(frames, init, n_chains=chains, warm_every=16, seeds=seeds, _ctx=ctx, **kw)
+    got = st()
+    from gaussian_process_edge_trace_amd.sequence import chain_slices
+    mse = []
+    for lo, hi in chain_slices(T, chains):
+        want, iters = oracle_chain(frames[lo:hi], init, 16, seeds[lo:hi], kw)
+        for k in range(hi - lo):
+            assert st.iterations[lo + k] == iters[k], "frame %d" % (lo + k)
+            assert np.array_equal(got[lo + k], want[k]), "frame %d" % (lo + k)
+            mse.append(amd.gpet_utils.trace_MSE(got[lo + k], truths[lo + k]))
+    assert min(st.iterations[lo + 1] for lo, hi in chain_slices(T, chains) if hi - lo > 1) >= 1  # warm frames do iterate
+    print("N=%d: iterations per frame %s, MSE vs truth %s" % (N, st.iterations, np.round(mse, 1)))
+
+
+def test_sequence_single_chain_equals_per_frame_objects(amd, ctx):
+    """One chain through the batch machinery (set_frame on one batch object) == a fresh GP_Edge_Tracing per frame
+    with ``obs`` from the previous trace, the way a user of the reference chains frames (RBF: structured loop path,
+    whose prior eigenbasis is kept across frames)."""
+    from gaussian_process_edge_trace_amd.sequence import warm_start_obs
+    N, T = 256, 4
+    frames, truths, init = make_sequence(amd, ctx, N, T)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 12}, noise_y=1, N_samples=300,
+              score_thresh=1, delta_x=6, keep_ratio=0.1, pixel_thresh=4, fix_endpoints=True)
+    got = amd.trace_sequence(frames, init, n_chains=1, warm_every=12, seed=5, _ctx=ctx, **kw)
+    prev = None
+    for t in range(T):
+        obs = np.array([]) if prev is None else warm_start_obs(prev, 0, N - 1, 12, N // 6 - 3, N)
+        tr = amd.GP_Edge_Tracing(init, frames[t], obs=obs, seed=5, **kw, _ctx=ctx)
+        prev = tr()
+        assert np.array_equal(got[t], prev), "frame %d" % t
+
+
+# ---- the reference's per-method seams against the reference's own arrays -------------------------------------------
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_mat128"])
+def test_seams_get_best_pixels_kde_compute_new_obs(amd, ctx, golden, name):
+    """get_best_curves -> kernel_density_estimate / get_best_pixels / compute_new_obs with the reference's arrays as
+    ARGUMENTS (they are honoured, not replaced by device state): the reference's KDE to f32 ulps, its new observation
+    set and decayed threshold exactly."""
+    g = golden(name)
+    L = amd._lib
+    ref = g["ref_samples_head"]
+    assert ref.shape[1] == int(g["ref_scalars"][2])
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx)
+    tr._batch.write(L.BUF_GRAD_KDE, g["ref_grad_kde"])  # pin the gradient KDE to the reference's
+    np.testing.assert_allclose(tr.kernel_density_estimate(None, None), g["ref_grad_kde"], rtol=0, atol=0)
+    curves, costs, (opt_curve, opt_cost) = tr.get_best_curves(ref)
+    np.testing.assert_allclose(costs, g["ref_best_costs"], rtol=1e-9)
+    np.testing.assert_allclose(opt_curve, g["ref_best_curve0"], rtol=1e-12)
+    # a single curve through cost_funct leaves the scored set intact
+    c0 = tr.cost_funct(g["ref_best_curve0"])
+    np.testing.assert_allclose(c0, g["ref_best_costs"][0], rtol=1e-9)
+    assert np.array_equal(tr._batch.read(L.BUF_BEST_IDX), g["ref_best_idxs"])
+    # scramble the device's own idea of the best curves: the arguments must win
+    tr._batch.write(L.BUF_BEST_IDX, np.zeros(len(costs), dtype=np.int32))
+    kde = tr.kernel_density_estimate(curves, costs)
+    np.testing.assert_allclose(kde, g["ref_kde_arr"], rtol=0, atol=4e-7)
+    pre_yx = g["in_obs"][:, [1, 0]]
+    tr._batch.write(L.BUF_BEST_IDX, np.zeros(len(costs), dtype=np.int32))
+    fobs = tr.get_best_pixels(curves, costs, pre_yx)
+    assert np.array_equal(fobs, g["ref_fobs"])
+    assert tr.score_thresh == float(g["ref_score_thresh_out"])
+    # compute_new_obs on the REFERENCE's KDE array, threshold back at its input value
+    sc = tr._batch.scalars()
+    sc.score_thresh = float(g["in_score_thresh"])
+    tr._batch.write_scalars(sc)
+    kde_ref = g["ref_kde_arr"].astype(np.float64)
+    pix = np.argwhere(kde_ref > 1e-3)
+    if tr.fix_endpoints:
+        pix = pix[(pix[:, 1] > tr.x_st) & (pix[:, 1] < tr.x_en)]
+    fobs2 = tr.compute_new_obs(pix, kde_ref, pre_yx)
+    assert np.array_equal(fobs2, g["ref_fobs"])
+    assert tr.score_thresh == float(g["ref_score_thresh_out"])
+    with pytest.raises(ValueError):
+        tr.compute_new_obs(pix[:-1], kde_ref, pre_yx)
+
+
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_mat128"])
+def test_seam_fit_predict_converged(amd, ctx, golden, name):
+    """fit_predict_GP(obs, converged=True, seed) (gpet.py:232-248,262-266) returns the reference's optimised mean
+    (pixels) and un-rescaled std for the reference's final observation set."""
+    g = golden(name)
+    stage = TRACES[name]
+    tr = amd.GP_Edge_Tracing(g["in_init"], golden(stage)["ref_grad"], **CTOR[stage], _ctx=ctx)
+    n_iter = int(g["ref_n_iter"])
+    mean, std = tr.fit_predict_GP(g["ref_obs_%02d" % n_iter], converged=True, seed=tr.seed + n_iter)
+    np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(mean - 1.96 * std, g["ref_ci_lower"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_mat128"])
+def test_seam_gpr_cov_and_sample_y(amd, ctx, golden, name):
+    """GaussianProcessRegressor.predict(return_cov=True) and sample_y (sklearn_gpr.py:398-403, 440-473) against the
+    reference's covariance and samples for the same fit (samples after aligning eigenvector signs: LAPACK's are
+    implementation-defined)."""
+    g = golden(name)
+    N = g["ref_mean"].shape[0]
+    w = np.where(np.isin(g["ref_X_train"], g["in_init"][:, 0]), 1e-7 if CTOR[name]["fix_endpoints"] else 0.5, 1.0)
+    kern = {'kernel': str(g["ref_kernel_type"]), 'constant': float(g["ref_amp"]), 'length_scale': float(g["ref_sigma"][1]),
+            'nu': float(g["ref_sigma"][2]),
+            'white': amd.sklearn_gpr.WeightedWhiteKernel(w, N, noise_level=float(CTOR[name]["noise_y"]))}
+    gp = amd.GaussianProcessRegressor(kernel=kern, alpha=1e-6, optimizer=None, normalize_y=True, _ctx=ctx)
+    # y as fit_predict_GP hands it over (already divided by y_s; the fixture stores it centred)
+    gp.fit(g["ref_X_train"][:, None], g["ref_y_train"] + float(g["ref_y_train_mean"]))
+    xq = (np.arange(N) + int(g["in_init"][:, 0].min())).astype(float)
+    mean, cov = gp.predict(xq[:, None], return_cov=True)
+    np.testing.assert_allclose(mean, g["ref_mean"], rtol=1e-8)
+    np.testing.assert_allclose(cov, g["ref_cov"], rtol=0, atol=1e-9 * np.abs(g["ref_cov"]).max())
+    S = g["ref_samples_head"].shape[1]
+    Y = gp.sample_y(xq[:, None], S, random_state=int(g["in_gp_seed"]))
+    assert Y.shape == (N, S)
+    # the reference's samples (pixel units there: divide by y_s) differ by the signs of the factor rows only
+    F = g["ref_factor"]
+    sgn = np.where(F @ (1.0 / np.arange(1, N + 1)) < 0, -1.0, 1.0)
+    Z = orc.legacy_standard_normal(int(g["in_gp_seed"]), S * N).reshape(S, N)
+    want = (Z * sgn[None, :]) @ F + g["ref_mean"]
+    np.testing.assert_allclose(Y.T, want, rtol=0, atol=2e-6 * np.sqrt(np.abs(g["ref_cov"]).max()) + 1e-8)
+
+
+# ---- T3: the device trace against the REFERENCE's own trace, as numbers ---------------------------------------------
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_rbf500"])
+def test_t3_device_trace_vs_reference_trace(amd, ctx, golden, name):
+    """The reference samples with LAPACK's singular-vector signs, the library with its documented convention
+    (sum_j row[j]/(j+1) >= 0): the same posterior, different draws.  What that costs against the reference's own run
+    for the same seed: iteration count within 25 %, trace within a few pixels on average, quality vs truth in the
+    reference's band."""
+    g = golden(name)
+    stage = TRACES[name]
+    tr = amd.GP_Edge_Tracing(g["in_init"], golden(stage)["ref_grad"], **CTOR[stage], _ctx=ctx)
+    et = tr()
+    ref = g["ref_edge_trace"]
+    truth = g["in_true_edge"]
+    d = np.abs(et[:, 0] - ref[:, 0])
+    it_ref = int(g["ref_n_iter"])
+    mse, mse_ref = amd.gpet_utils.trace_MSE(et, truth), amd.gpet_utils.trace_MSE(ref, truth)
+    dice, dice_ref = amd.gpet_utils.trace_dicecoef(et, truth), amd.gpet_utils.trace_dicecoef(ref, truth)
+    print("%s: |edge_trace - ref_edge_trace| max %d mean %.2f px; iterations %d vs %d; MSE vs truth %.1f (reference %.1f); "
+          "DICE %.4f (reference %.4f)" % (name, d.max(), d.mean(), tr._n_iter, it_ref, mse, mse_ref, dice, dice_ref))
+    assert abs(tr._n_iter - it_ref) <= max(2, it_ref // 4)
+    if name == "trace_rbf500":
+        # this image (seed 1) is bistable in the reference itself: its oracle lands on MSE 692 or 8443 depending on the
+        # seed and on the sign convention (test_trace_quality_band); the other branch is what the library's signs select
+        assert dice >= 0.85
+    else:
+        assert d.mean() <= 3.0
+        assert dice >= dice_ref - 0.02
+
+
+def test_rbf_without_fix_endpoints_partial_width_takes_generic_path(amd, ctx):
+    """fix_endpoints=False lets the pixel selection accept columns outside [x_st, x_en] (gpet.py:655-657 filters only
+    when it is set); those are not on the grid the structured loop path indexes, so such an edge must run the generic
+    path -- and still match the oracle bit for bit (round-1 advisor finding: out-of-range Q0 reads)."""
+    N = 128
+    img, truth = orc.synth_sinusoid_image(N, 3)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[20, 107], :][:, [1, 0]]  # partial width: x_st = 20, x_en = 107
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 20, 'length_scale': 10}, noise_y=1, N_samples=256,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=2, fix_endpoints=False)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    assert tr._batch.info()["structured"] == 0
+    rec = []
+    et_o, ci_o, info = orc.trace(init, grad, record=rec, sign_convention="harmonic", **kw)
+    et, (all_samples, all_obs, curves) = tr(return_lines=True)
+    assert tr._n_iter == info["n_iter"]
+    for i, r in enumerate(rec):
+        assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
+    assert np.array_equal(et, et_o)
+    # the same edge with fix_endpoints=True keeps the fast path
+    tr2 = amd.GP_Edge_Tracing(init, grad, **dict(kw, fix_endpoints=True), _ctx=ctx)
+    assert tr2._batch.info()["structured"] == 1
+
+
+def test_out_of_image_observations_are_rejected(amd, ctx):
+    N = 64
+    img, truth = orc.synth_sinusoid_image(N, 3)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    tr = amd.GP_Edge_Tracing(init, grad, **CTOR["stage_rbf64"], _ctx=ctx)
+    for bad in ([[10, 64]], [[10, -1]], [[64, 10]], [[-1, 10]]):
+        with pytest.raises(amd._lib.GpetError) as ei:
+            tr._batch.set_obs(0, np.array(bad, dtype=np.int64))
+        assert ei.value.code == amd._lib.ERR_BAD_ARG
