@@ -19,7 +19,7 @@ OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_ITER_CAP, ERR_RANK_CAP, ERR_UNSUPPORTE
 # gpet_buf
 (BUF_X_TRAIN, BUF_Y_TRAIN, BUF_CHOL, BUF_ALPHA, BUF_MEAN, BUF_STD, BUF_COV, BUF_FACTOR, BUF_EIGVALS, BUF_NORMALS,
  BUF_SAMPLES, BUF_COSTS, BUF_BEST_IDX, BUF_BEST_COSTS, BUF_SCALARS, BUF_OBS, BUF_KDE, BUF_GRAD_KDE, BUF_GRAD,
- BUF_NOISE_W) = range(20)
+ BUF_NOISE_W, BUF_FIN_TRAIN, BUF_FIN_PAR, BUF_FIN_STARTS) = range(23)
 
 KERNEL_RBF, KERNEL_MATERN = 0, 1
 GRAD_ON_DEVICE = 1  # gpet_batch_create2 / gpet_batch_set_images flag: the gradient image pointers are device pointers
@@ -91,6 +91,7 @@ SYMBOLS = {
     "gpet_batch_read_obs_all": (C.c_int, [_P, _P, _P, C.c_int]),
     "gpet_batch_read_scalars_all": (C.c_int, [_P, _P]),
     "gpet_final_predict_all": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "gpet_final_fit_all": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -184,7 +185,8 @@ _DT = {BUF_X_TRAIN: np.float64, BUF_Y_TRAIN: np.float64, BUF_CHOL: np.float64, B
        BUF_MEAN: np.float64, BUF_STD: np.float64, BUF_COV: np.float64, BUF_FACTOR: np.float64,
        BUF_EIGVALS: np.float64, BUF_NORMALS: np.float64, BUF_SAMPLES: np.float64, BUF_COSTS: np.float64,
        BUF_BEST_IDX: np.int32, BUF_BEST_COSTS: np.float64, BUF_OBS: np.int64, BUF_KDE: np.float32,
-       BUF_GRAD_KDE: np.float32, BUF_GRAD: np.float32, BUF_NOISE_W: np.float64}
+       BUF_GRAD_KDE: np.float32, BUF_GRAD: np.float32, BUF_NOISE_W: np.float64, BUF_FIN_TRAIN: np.float64,
+       BUF_FIN_PAR: np.float64, BUF_FIN_STARTS: np.float64}
 
 
 class Batch:
@@ -278,7 +280,8 @@ class Batch:
                  BUF_FACTOR: (s.rank, Lg), BUF_EIGVALS: (s.rank,), BUF_NORMALS: (S, inf["z_cols"]),
                  BUF_SAMPLES: (S, Lg), BUF_COSTS: (S,), BUF_BEST_IDX: (inf["n_keep"],),
                  BUF_BEST_COSTS: (inf["n_keep"],), BUF_OBS: (s.n_obs, 2), BUF_KDE: (self.M, self.N),
-                 BUF_GRAD_KDE: (self.M, self.N), BUF_GRAD: (self.M, self.N)}[which]
+                 BUF_GRAD_KDE: (self.M, self.N), BUF_GRAD: (self.M, self.N), BUF_FIN_TRAIN: (3, inf["n_cap"]),
+                 BUF_FIN_PAR: (12,), BUF_FIN_STARTS: (13, 3)}[which]
         out = np.zeros(shape, dtype=_DT[which])
         if out.size:
             self.ctx.check(self.lib.gpet_batch_read(self.h, e, which, out.ctypes.data, out.nbytes))
@@ -348,6 +351,19 @@ class Batch:
         std = np.zeros((self.B, Lg))
         self.ctx.check(self.lib.gpet_final_predict_all(self.h, par.ctypes.data, mean.ctypes.data, std.ctypes.data, Lg))
         return mean, std
+
+    def final_fit_all(self, seeds):
+        """Converged fits of every edge on the device (gpet_final_fit_all).  Returns (mean [B, Lg_max] in pixels,
+        std [B, Lg_max] in standardised units, theta [B, 3], minimum of -LML [B], objective launches)."""
+        s = (C.c_uint32 * self.B)(*[int(v) & 0xFFFFFFFF for v in seeds])
+        Lg = self._max_info("Lg")
+        mean = np.zeros((self.B, Lg))
+        std = np.zeros((self.B, Lg))
+        th = np.zeros((self.B, 4))
+        rounds = C.c_int32()
+        self.ctx.check(self.lib.gpet_final_fit_all(self.h, s, mean.ctypes.data, std.ctypes.data, th.ctypes.data, Lg,
+                                                   C.byref(rounds)))
+        return mean, std, th[:, :3].copy(), th[:, 3].copy(), rounds.value
 
     def lml_batch(self, edge_of, theta):
         edge_of = np.ascontiguousarray(edge_of, dtype=np.int32)

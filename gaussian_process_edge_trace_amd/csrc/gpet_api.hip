@@ -68,6 +68,16 @@ struct gpet_batch {
   int lml_launches = 0;
   int* d_edge_of = nullptr;
   double *d_theta = nullptr, *d_f = nullptr, *d_g = nullptr;
+  // device-resident converged fits (gpet_final_fit_all): one allocation, carved
+  char* lb_mem = nullptr;
+  void* lb_probs = nullptr;
+  double *lb_starts = nullptr, *lb_scratch = nullptr, *lb_f = nullptr, *lb_g = nullptr, *lb_theta_out = nullptr;
+  int* lb_slot_edge[2] = {nullptr, nullptr};
+  double* lb_slot_theta[2] = {nullptr, nullptr};
+  int* lb_slot_src[2] = {nullptr, nullptr};
+  int* lb_count = nullptr;
+  unsigned int* lb_seeds = nullptr;
+  int lb_scratch_stride = 0;
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
@@ -632,6 +642,7 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_theta) (void)hipFree(b->d_theta);
   if (b->d_f) (void)hipFree(b->d_f);
   if (b->d_g) (void)hipFree(b->d_g);
+  if (b->lb_mem) (void)hipFree(b->lb_mem);
   delete b;
 }
 
@@ -745,6 +756,21 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
     case GPET_BUF_SCALARS:
       memcpy(dst, &s, bytes < sizeof s ? bytes : sizeof s);
       return GPET_OK;
+    case GPET_BUF_FIN_PAR: src = E.fin_par; avail = 12 * 8; break;
+    case GPET_BUF_FIN_STARTS:
+      if (!b->lb_starts) return fail(c, GPET_ERR_STATE, "no converged fit has run on this batch yet");
+      src = b->lb_starts + (size_t)e * 39;
+      avail = 39 * 8;
+      break;
+    case GPET_BUF_FIN_TRAIN: {
+      const size_t nc = E.n_cap;
+      if (bytes < 3 * nc * 8) return fail(c, GPET_ERR_BAD_ARG, "FIN_TRAIN read needs %zu bytes", 3 * nc * 8);
+      HIPCHK(c, hipMemcpyAsync((char*)dst, E.fin_x, nc * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync((char*)dst + nc * 8, E.fin_y, nc * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync((char*)dst + 2 * nc * 8, E.fin_w, nc * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return GPET_OK;
+    }
     case GPET_BUF_CHOL: {
       // compact n x n lower-triangular copy (upper part zeroed)
       if (bytes < n * n * 8) return fail(c, GPET_ERR_BAD_ARG, "CHOL read needs %zu bytes", n * n * 8);
@@ -1149,6 +1175,90 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
   b->lml_evals += P;
   b->lml_launches += 1;
   return GPET_OK;
+}
+
+int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
+                       int stride, int32_t* rounds_out) {
+  if (!b || !seeds || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fetch_all_scalars(b);  // (synchronises the loop's stream: the observation sets are final)
+  if (rc) return rc;
+  const int B = b->B, P = 13 * B;
+  int n_max = 0;
+  for (int e = 0; e < B; ++e) {
+    const int n = b->h_edges[e].n_init + b->h_scalars[e].n_obs;
+    if (n > 250)
+      return fail(c, GPET_ERR_UNSUPPORTED, "converged fit: edge %d has %d training points; the objective kernels take <= 250", e, n);
+    if (n > b->h_edges[e].n_cap) return fail(c, GPET_ERR_BAD_ARG, "converged fit: edge %d n=%d exceeds n_cap", e, n);
+    b->h_edges[e].fin_n = n;
+    if (n > n_max) n_max = n;
+  }
+  if (!b->lb_mem) {
+    b->lb_scratch_stride = b->bd.n_cap > 256 ? b->bd.n_cap : 256;
+    Carver meas;
+    for (int pass = 0; pass < 2; ++pass) {
+      Carver cv;
+      cv.base = pass ? b->lb_mem : nullptr;
+      b->lb_probs = cv.take<char>(lb_prob_bytes() * (size_t)P);
+      b->lb_starts = cv.take<double>((size_t)P * 3);
+      b->lb_scratch = cv.take<double>((size_t)B * b->lb_scratch_stride);
+      b->lb_f = cv.take<double>((size_t)P);
+      b->lb_g = cv.take<double>((size_t)P * 3);
+      b->lb_theta_out = cv.take<double>((size_t)B * 4);
+      for (int h = 0; h < 2; ++h) {
+        b->lb_slot_edge[h] = cv.take<int>((size_t)P);
+        b->lb_slot_theta[h] = cv.take<double>((size_t)P * 3);
+        b->lb_slot_src[h] = cv.take<int>((size_t)P);
+      }
+      b->lb_count = cv.take<int>(4);
+      b->lb_seeds = cv.take<unsigned int>((size_t)B);
+      if (!pass) HIPCHK(c, hipMalloc(&b->lb_mem, cv.off + 256));
+    }
+  }
+  hipStream_t st = b->fit;
+  if (!b->ev_l0) {
+    HIPCHK(c, hipEventCreate(&b->ev_l0));
+    HIPCHK(c, hipEventCreate(&b->ev_l1));
+  }
+  HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride));
+  HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0]));
+  int n_active = P, cur = 0, rounds = 0;
+  while (n_active > 0) {
+    if (rounds >= 4000) return fail(c, GPET_ERR_ITER_CAP, "converged fit: %d problems still running after %d rounds", n_active, rounds);
+    HIPCHK(c, hipMemsetAsync(b->lb_count, 0, sizeof(int), st));
+    HIPCHK(c, hipEventRecord(b->ev_l0, st));
+    HIPCHK(c, launch_lml(st, b->d_edges, n_active, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g));
+    HIPCHK(c, hipEventRecord(b->ev_l1, st));
+    HIPCHK(c, launch_lb_advance(st, b->lb_probs, n_active, b->lb_slot_src[cur], b->lb_f, b->lb_g, b->lb_count,
+                                b->lb_slot_edge[1 - cur], b->lb_slot_theta[1 - cur], b->lb_slot_src[1 - cur]));
+    int h_count = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_count, b->lb_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->ev_l0, b->ev_l1) == hipSuccess) b->lml_ms += (double)ms;
+    b->lml_evals += n_active;
+    b->lml_launches += 1;
+    n_active = h_count;
+    cur ^= 1;
+    rounds += 1;
+  }
+  HIPCHK(c, launch_lb_pick(st, b->d_edges, B, b->lb_probs, b->lb_theta_out));
+  HIPCHK(c, launch_final_predict(st, b->d_edges, B, b->bd));
+  std::vector<double> host((size_t)B * 2 * b->bd.Lg), th((size_t)B * 4);
+  HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(th.data(), b->lb_theta_out, th.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  for (int e = 0; e < B; ++e) {
+    const int Lg = b->h_edges[e].Lg;
+    memcpy(mean_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg, sizeof(double) * Lg);
+    memcpy(std_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg + b->bd.Lg, sizeof(double) * Lg);
+    if (theta_out) memcpy(theta_out + (size_t)e * 4, th.data() + (size_t)e * 4, sizeof(double) * 4);
+  }
+  if (rounds_out) *rounds_out = rounds;
+  b->have_fit = false;  // the loop's L/alpha were overwritten by the converged fit
+  return check_device_status(b);
 }
 
 int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches) {

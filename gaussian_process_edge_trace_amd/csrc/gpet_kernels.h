@@ -49,6 +49,16 @@ hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const Ba
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int rank_max = 0);
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
 
+// converged fit on the device (gpet_lbfgsb.hip): training sets + start points, L-BFGS-B state machines, best restart
+size_t lb_prob_bytes();
+hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, double* d_starts,
+                              double* d_scratch, int scratch_stride);
+hipError_t launch_lb_init(hipStream_t st, void* d_probs, int P, const double* d_starts, int* slot_edge, double* slot_theta,
+                          int* slot_src);
+hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_active, const int* slot_src, const double* d_f,
+                             const double* d_g, int* next_count, int* next_edge, double* next_theta, int* next_src);
+hipError_t launch_lb_pick(hipStream_t st, EdgeDev* d_edges, int B, const void* d_probs, double* d_theta_out);
+
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
                       double* d_f, double* d_g);
 

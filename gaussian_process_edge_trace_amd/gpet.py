@@ -251,8 +251,6 @@ class GP_Edge_Tracing(object):
                  return_lines=False, max_iter=1000):
         """Runs the trace (gpet.py:768-908).  The while-loop of the reference (gpet.py:829-870)
         lives on the device; the host only polls the per-edge ``done`` flag."""
-        from ._final_fit import converged_fit_predict
-
         all_samples, all_obs = [], [self.obs]
         iter_optimal_curves, iter_optimal_costs = [], []
         if show_init_post or show_post_iter or print_final_diagnostics:
@@ -284,14 +282,9 @@ class GP_Edge_Tracing(object):
         self._n_iter = n_iter
         pre_fobs = b.read(_lib.BUF_OBS)
         self.score_thresh = b.scalars().score_thresh
-        # final hyper-parameter-optimised fit (gpet.py:874-876), seed = seed + N_iter
-        if pre_fobs.shape[0] + self.N_inits <= 250:
-            fits, _ = device_final_fits(b, [dict(self._p, seed=self.seed)], [pre_fobs], [n_iter])
-            y_mean_optim, y_std, self._theta = fits[0]
-        else:  # more training points than the LDS-resident LML kernel takes: host objective
-            y_mean_optim, y_std, self._theta = converged_fit_predict(
-                self.init, pre_fobs, self.x_grid, self.kernel_type, self.kernel_nu, self.noise_y,
-                self.fix_endpoints, self.seed + n_iter)
+        # final hyper-parameter-optimised fit (gpet.py:874-876), seed = seed + N_iter; on the device
+        fits, _ = device_final_fits(b, [dict(self._p, seed=self.seed)], None, [n_iter])
+        y_mean_optim, y_std, self._theta = fits[0]
         cred_interval = (y_mean_optim - 1.96 * y_std, y_mean_optim + 1.96 * y_std)
         all_samples.append(y_mean_optim)
         all_obs.append(pre_fobs)
@@ -307,46 +300,18 @@ class GP_Edge_Tracing(object):
         return edge_trace, (all_samples, all_obs, iter_optimal_curves)
 
 
-def device_final_fits(batch, ps, obs_list, iters, farm=None):
-    """Converged fits (gpet.py:874) of every edge of a batch at once.
-
-    Host: standardisation of the <=250-point training sets (numpy, as the reference does it) and
-    scipy's own L-BFGS-B routine, driven in lock step for all (edge, restart) problems
-    (``_lbfgsb_lockstep``, optionally spread over worker processes).  Device: every round of
-    objective evaluations is one batched launch of the LML kernel (gpet_lml_batch), and the
-    posterior at the optimum is one more launch (gpet_final_predict_all).
-    Returns ([(mean, std, theta)] per edge, number of optimiser rounds)."""
-    from . import _final_fit as ff
-    from ._lbfgsb_lockstep import minimize_many
-
-    preps = ff.prepare_many([p["init"] for p in ps], obs_list, [p["x_grid"] for p in ps],
-                            [p["fix_endpoints"] for p in ps])
-    x0s = ff.start_points_many([p["noise_y"] for p in ps], [p["seed"] + iters[e] for e, p in enumerate(ps)])
-    n_start = len(x0s) // len(ps)  # 1 + 12 restarts for every edge
-    edge_of = np.repeat(np.arange(len(ps), dtype=np.int32), n_start)
-    batch.final_set_training_all([pr["xs"] for pr in preps], [pr["yt"] for pr in preps], [pr["w"] for pr in preps])
-
-    def eval_batch(idx, X):
-        return batch.lml_batch(edge_of[idx], X)
-
-    if farm is not None:
-        X, F, rounds = farm.minimize(eval_batch, x0s, ff.BOUNDS)
-    else:
-        X, F, rounds = minimize_many(eval_batch, x0s, ff.BOUNDS)
-    best = np.argmin(F.reshape(len(ps), n_start), axis=1)  # first minimum per edge, like np.argmin in sklearn_gpr.py:292
-    thetas = [X[e * n_start + int(best[e])] for e in range(len(ps))]
-    par = np.zeros((len(ps), 12))
-    par[:, :3] = np.exp(np.asarray(thetas))
-    for e, pr in enumerate(preps):
-        par[e, 3:9] = [pr["X_m"], pr["X_s"], pr["y_m"], pr["y_s"], pr["m2"], pr["s2"]]
-    mean, std = batch.final_predict_all(par)
-    out = [(mean[e, :len(p["x_grid"])].copy(), std[e, :len(p["x_grid"])].copy(), thetas[e]) for e, p in enumerate(ps)]
+def device_final_fits(batch, ps, obs_list, iters):
+    """Converged fits (gpet.py:874) of every edge of a batch at once, entirely on the device (gpet_final_fit_all):
+    training sets from the observation sets on the device (``obs_list`` given => those are set first), standardised
+    like the reference does, theta0 + 12 restarts from ``RandomState(seed + iters[e])``, L-BFGS-B for all 13 B
+    problems in lock step with one batched objective launch per round, best restart, posterior at the optimum.
+    Returns ([(mean in pixels, std in standardised units, theta)] per edge, number of optimiser rounds)."""
+    if obs_list is not None:
+        for e, o in enumerate(obs_list):
+            batch.set_obs(e, np.asarray(o).reshape(-1, 2).astype(np.int64))
+    mean, std, theta, fmin, rounds = batch.final_fit_all([p["seed"] + iters[e] for e, p in enumerate(ps)])
+    out = [(mean[e, :len(p["x_grid"])].copy(), std[e, :len(p["x_grid"])].copy(), theta[e].copy()) for e, p in enumerate(ps)]
     return out, rounds
-
-
-def _final_fit_job(args):
-    from ._final_fit import converged_fit_predict
-    return converged_fit_predict(*args)
 
 
 class GP_Edge_Tracing_Batch(object):
@@ -363,8 +328,7 @@ class GP_Edge_Tracing_Batch(object):
 
     def __init__(self, inits, grad_imgs, seeds, kernel_options=(1, 3, 3), noise_y=1, N_samples=500, score_thresh=1,
                  delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, obs=None,
-                 device=0, stream=None, factor_cap=0, z_cols=0, _ctx=None, fit_pool=None, fit_farm=None,
-                 grad_device_ptrs=None, grad_shape=None):
+                 device=0, stream=None, factor_cap=0, z_cols=0, _ctx=None, grad_device_ptrs=None, grad_shape=None):
         """``obs``: optional list of per-edge warm-start observation sets (xy), the reference's ``obs`` constructor
         argument (gpet.py:57-61,100,820).  ``grad_device_ptrs`` + ``grad_shape``: the gradient image(s) already live
         on this GPU (e.g. a torch tensor an RCCL broadcast filled): integer device addresses of f32 (M, N) arrays,
@@ -397,11 +361,6 @@ class GP_Edge_Tracing_Batch(object):
         self.return_std = return_std
         self.seeds = [int(s) for s in seeds]
         self.timings = {}
-        # optional multiprocessing pool for the host-side final fits; create it BEFORE the process
-        # touches the GPU (make_fit_pool) -- never fork/spawn after HIP is initialised
-        self._pool = fit_pool
-        # optional LockstepFarm: worker processes that advance the L-BFGS-B problems of the final fits
-        self._farm = fit_farm
 
     def _set_obs(self):
         for e, p in enumerate(self._ps):
@@ -452,19 +411,8 @@ class GP_Edge_Tracing_Batch(object):
         return [s.iter for s in self._batch.all_scalars()]
 
     def final_fits(self, iters):
-        jobs = []
-        b = self._batch
-        all_obs = b.read_obs_all()
-        for e, p in enumerate(self._ps):
-            obs = all_obs[e]
-            jobs.append((p["init"], obs, p["x_grid"], p["kernel_type"], p["kernel_nu"], p["noise_y"],
-                         p["fix_endpoints"], p["seed"] + iters[e]))
-        if self._pool is not None and len(jobs) > 1:
-            return self._pool.map(_final_fit_job, jobs)
-        if all(len(j[1]) + len(j[0]) <= 250 for j in jobs):
-            fits, self._fit_rounds = device_final_fits(b, self._ps, [j[1] for j in jobs], iters, self._farm)
-            return fits
-        return [_final_fit_job(j) for j in jobs]  # > 250 training points: host objective
+        fits, self._fit_rounds = device_final_fits(self._batch, self._ps, None, iters)
+        return fits
 
     def finish(self, iters):
         """Converged fits + rounding of the means to pixel indices (gpet.py:874-886) for every edge."""
@@ -484,43 +432,3 @@ class GP_Edge_Tracing_Batch(object):
         t2 = t.time()
         self.timings = dict(loop_s=t1 - t0, final_fit_s=t2 - t1, iters=iters)
         return out
-
-
-def make_fit_pool(workers):
-    """Worker processes for the host-side final fits.  Call before anything initialises HIP: the
-    fork server is exec'ed here, and later workers are forked from it (a GPU-free process).
-    Workers run single-threaded BLAS (the matrices are ~100x100; oversubscription is fatal)."""
-    import multiprocessing as mp
-    import os
-    saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
-    for k in saved:
-        os.environ[k] = "1"
-    try:
-        ctx = mp.get_context("forkserver")
-        ctx.set_forkserver_preload(["numpy", "scipy.optimize", "scipy.linalg"])
-        pool = ctx.Pool(workers, initializer=_limit_blas_threads)
-        pool.map(_noop, range(workers))  # make sure every worker exists before HIP is initialised
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    return pool
-
-
-def _noop(x):
-    return x
-
-
-_BLAS_LIMITER = None
-
-
-def _limit_blas_threads():
-    """Worker initialiser: one BLAS thread per worker (tiny matrices; oversubscription is fatal)."""
-    global _BLAS_LIMITER
-    try:
-        from threadpoolctl import threadpool_limits
-        _BLAS_LIMITER = threadpool_limits(limits=1)  # kept alive: limits hold while it exists
-    except Exception:
-        pass

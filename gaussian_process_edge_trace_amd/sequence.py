@@ -53,8 +53,7 @@ class SequenceTracer(object):
     constructor's (gpet.py:22-35).  ``__call__`` returns the list of T results in frame order, each what
     ``GP_Edge_Tracing.__call__`` returns for that frame (trace, or (trace, credible interval) with ``return_std``)."""
 
-    def __init__(self, frames, init, n_chains=1, warm_every=None, seed=42, seeds=None, *, device=0, _ctx=None,
-                 fit_farm=None, **kw):
+    def __init__(self, frames, init, n_chains=1, warm_every=None, seed=42, seeds=None, *, device=0, _ctx=None, **kw):
         self.frames = frames
         self.T = len(frames)
         self.init = np.asarray(init)
@@ -68,7 +67,7 @@ class SequenceTracer(object):
                                                                                "fix_endpoints")})
         self._p = p
         self.warm_every = int(warm_every) if warm_every else 2 * p["delta_x"]
-        self.device, self._ctx, self._farm = device, _ctx, fit_farm
+        self.device, self._ctx = device, _ctx
         self.iterations = [0] * self.T
         self._tracer = None
 
@@ -92,7 +91,7 @@ class SequenceTracer(object):
             if self._tracer is None or len(active) != self._tracer.B:
                 # (first step, or the shorter chains have run out: a smaller batch from here on)
                 self._tracer = GP_Edge_Tracing_Batch([self.init] * len(active), imgs, seeds, obs=obs, device=self.device,
-                                                     _ctx=self._ctx, fit_farm=self._farm, **self.kw)
+                                                     _ctx=self._ctx, **self.kw)
                 if self._ctx is None:
                     self._ctx = self._tracer._ctx
             else:

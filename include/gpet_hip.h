@@ -89,7 +89,13 @@ typedef enum gpet_buf {
                            *                 the band rows only and normalises inside its pixel kernels) */
   GPET_BUF_GRAD_KDE = 17, /* f32 [M*N]      normalised gradient KDE        gpet.py:127 */
   GPET_BUF_GRAD = 18,     /* f32 [M*N]      normalised gradient image      gpet.py:97 */
-  GPET_BUF_NOISE_W = 19   /* f64 [n]        per-point noise weights        gpet.py:209-213 */
+  GPET_BUF_NOISE_W = 19,  /* f64 [n]        per-point noise weights        gpet.py:209-213 */
+  GPET_BUF_FIN_TRAIN = 20,  /* f64 [3][n_cap] converged fit: standardised x | y | noise weights, n = n_init + n_obs used
+                             *                (gpet.py:235-238; sklearn_gpr.py:229-234), as gpet_final_fit_all built them */
+  GPET_BUF_FIN_PAR = 21,  /* f64 [12]       optimum and transforms: constant, length_scale, noise_level, X_m, X_s, y_m,
+                           *                y_s, m2, s2, 0, 0, 0 */
+  GPET_BUF_FIN_STARTS = 22  /* f64 [13][3]  theta0 + the 12 restart points of the last gpet_final_fit_all
+                             *                (gpet.py:244-245; sklearn_gpr.py:283-288) */
 } gpet_buf;
 
 /* Per-edge scalar state kept on the device (GPET_BUF_SCALARS). */
@@ -244,6 +250,16 @@ int gpet_final_cov(gpet_batch* b);
  * on edge edge_of[i]'s training set.  theta [P*3], f_out [P], g_out [P*3] (host).  A non-PD
  * kernel matrix gives f = +inf, g = 0 (sklearn_gpr.py:521-522). */
 int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out);
+
+/* The whole converged fit of every edge of the batch on the device (gpet.py:874-876 -> :232-248, 262-266;
+ * sklearn_gpr.py:254-295): training sets from the current observation sets, standardised as the reference does;
+ * theta0 + 12 restarts from RandomState(seeds[e]).uniform (the caller passes seed + N_iter, gpet.py:874); L-BFGS-B
+ * (scipy.optimize.minimize's algorithm and defaults) for all 13 B problems in lock step, one batched objective launch
+ * per round; best restart; posterior at the optimum.  mean_out (pixels) and std_out (standardised units, as the
+ * reference returns it) are [B*stride]; theta_out (optional) [B*4] = log(constant, length_scale, noise_level) and the
+ * minimum of -log marginal likelihood; rounds_out (optional) = objective launches.  At most 250 training points. */
+int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
+                       int stride, int32_t* rounds_out);
 
 /* Device time of the LML kernel launches of this batch since the last reset (hipEvents around each launch), the
  * number of objective evaluations and of launches; any of the outputs may be NULL.  (bench.py's roofline leg.) */

@@ -165,6 +165,59 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
         assert np.array_equal(np.rint(mean).astype(int), g["ref_edge_trace"][:, 0])
 
 
+def test_device_training_sets_and_start_points_equal_numpy(amd, ctx, golden):
+    """gpet_final_fit_all builds its inputs on the device: sorted training set standardised twice (gpet.py:235-238,
+    sklearn_gpr.py:229-234) with numpy's pairwise summation order, and theta0 + 12 restarts from MT19937
+    (sklearn_gpr.py:283-288).  Bit-identical to the NumPy restatement (= the reference's own arithmetic)."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    L = amd._lib
+    for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128"), ("trace_rbf65", "stage_rbf65")]:
+        g = golden(name)
+        tr = amd.GP_Edge_Tracing(g["in_init"], golden(stage)["ref_grad"], **CTOR[stage], _ctx=ctx)
+        n_iter = int(g["ref_n_iter"])
+        obs = g["ref_obs_%02d" % n_iter]
+        b = tr._batch
+        b.set_obs(0, obs)
+        seed = tr.seed + n_iter
+        b.final_fit_all([seed])
+        pr = ff.prepare(tr.init, obs, tr.x_grid, tr.fix_endpoints)
+        n = pr["xs"].shape[0]
+        train = b.read(L.BUF_FIN_TRAIN)
+        assert np.array_equal(train[0, :n], pr["xs"]) and np.array_equal(train[1, :n], pr["yt"])
+        assert np.array_equal(train[2, :n], pr["w"])
+        par = b.read(L.BUF_FIN_PAR)
+        assert np.array_equal(par[3:9], [pr["X_m"], pr["X_s"], pr["y_m"], pr["y_s"], pr["m2"], pr["s2"]])
+        assert np.array_equal(b.read(L.BUF_FIN_STARTS), np.asarray(ff.start_points(tr.noise_y, seed)))
+
+
+def test_device_lbfgsb_against_scipy_on_the_same_objective(amd, ctx, golden):
+    """The device's L-BFGS-B state machines against scipy.optimize.minimize(method="L-BFGS-B") (what the reference
+    calls, sklearn_gpr.py:589) driving the SAME device objective from the same 13 start points: per restart the same
+    minimum to 1e-7 relative (flat noise directions aside, theta to 1e-3), and the same best restart."""
+    import scipy.optimize
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    L = amd._lib
+    for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128")]:
+        g = golden(name)
+        tr = amd.GP_Edge_Tracing(g["in_init"], golden(stage)["ref_grad"], **CTOR[stage], _ctx=ctx)
+        n_iter = int(g["ref_n_iter"])
+        b = tr._batch
+        b.set_obs(0, g["ref_obs_%02d" % n_iter])
+        mean, std, theta, fmin, rounds = b.final_fit_all([tr.seed + n_iter])
+        assert 5 < rounds < 400
+        starts = b.read(L.BUF_FIN_STARTS)
+
+        def obj(th):
+            f, gr = b.lml_batch(np.zeros(1, dtype=np.int32), np.asarray(th).reshape(1, 3))
+            return float(f[0]), gr[0].copy()
+        res = [scipy.optimize.minimize(obj, th0, method="L-BFGS-B", jac=True, bounds=list(map(tuple, ff.BOUNDS))) for th0 in starts]
+        fs = np.array([r.fun for r in res])
+        best = int(np.argmin(fs))
+        np.testing.assert_allclose(fmin[0], fs[best], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(theta[0][:2], res[best].x[:2], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(theta[0][:2], g["ref_final_theta"][:2], rtol=1e-4, atol=1e-5)
+
+
 def test_structured_loop_path_equals_generic(amd, ctx, golden):
     """The loop's prior-eigenbasis path (H = c Lam - U^T U in the eigenbasis of the grid's Toeplitz
     correlation matrix) must produce the factor, mean and samples of the generic path

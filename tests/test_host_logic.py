@@ -3,11 +3,9 @@ quirks, kernel presets, the synthetic generator, metrics, the lock-step L-BFGS-B
 host objective of the converged fit."""
 import numpy as np
 import pytest
-import scipy.optimize
 
 from gaussian_process_edge_trace_amd import gpet as G
 from gaussian_process_edge_trace_amd import _final_fit as ff
-from gaussian_process_edge_trace_amd._lbfgsb_lockstep import minimize_many
 from oracle import gpet_oracle as orc
 
 CASES = [
@@ -70,77 +68,14 @@ def test_kernel_builder_and_synthetic_generator_match_oracle():
     assert U.trace_MSE(shifted, edge) == 9.0 and 0.9 < U.trace_dicecoef(shifted, edge) < 1.0
 
 
-def test_lockstep_lbfgsb_equals_scipy_minimize():
-    rng = np.random.default_rng(0)
-    bounds = np.array([[-2.0, 2.0], [-1.0, 3.0], [0.5, 2.5]])
-
-    def fg(x):
-        f = (1 - x[0]) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2 + (x[2] - 1.2) ** 4
-        g = np.array([-2 * (1 - x[0]) - 400 * x[0] * (x[1] - x[0] ** 2), 200 * (x[1] - x[0] ** 2), 4 * (x[2] - 1.2) ** 3])
-        return f, g
-
-    x0s = [rng.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(9)] + [np.array([5.0, -7.0, 0.0])]
-    ref = [scipy.optimize.minimize(fg, x0, method="L-BFGS-B", jac=True, bounds=bounds) for x0 in x0s]
-
-    def eval_batch(idx, X):
-        out = [fg(x) for x in X]
-        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
-
-    X, F, rounds = minimize_many(eval_batch, x0s, bounds)
-    for i, r in enumerate(ref):
-        assert np.array_equal(X[i], r.x) and F[i] == r.fun
-    assert rounds == max(r.nfev for r in ref)
-
-
-def test_host_final_fit_matches_oracle(golden):
-    g = golden("trace_rbf64")
-    init = g["in_init"][np.argsort(g["in_init"][:, 0])]
-    obs = g["ref_obs_%02d" % int(g["ref_n_iter"])]
-    xg = np.arange(init[0, 0], init[-1, 0] + 1)
-    mean, std, theta = ff.converged_fit_predict(init, obs, xg, "RBF", 2.5, 1, True, 1 + int(g["ref_n_iter"]))
-    p = dict(fix_endpoints=True, x_grid=xg, kernel_type="RBF", nu=2.5, noise_y=1)
-    mo, so, info = orc.converged_fit_predict(init, obs, p, 1 + int(g["ref_n_iter"]))
-    np.testing.assert_allclose(theta, info["theta"], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(mean, mo, rtol=1e-9)
-    np.testing.assert_allclose(theta, g["ref_final_theta"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=1e-6, atol=1e-6)
-
-
-def _quartic_problems(seed, P):
-    r = np.random.default_rng(seed)
-    A, c, x0 = r.uniform(0.5, 5, (P, 3)), r.uniform(-2, 2, (P, 3)), r.uniform(-3, 3, (P, 3))
-
-    def ev(idx, X):
-        d = X - c[idx]
-        return np.sum(A[idx] * d ** 4 + d * d, axis=1), 4 * A[idx] * d ** 3 + 2 * d
-    return list(x0), ev
-
-
-def test_lockstep_farm_two_concurrent_jobs_equal_the_in_process_driver():
-    """Worker processes shared by two job slots (as the pipelined bench uses them): each job follows exactly the
-    iterates of the in-process lock-step driver (= scipy.optimize.minimize, previous test), also when a slot is reused."""
-    import threading
-    from gaussian_process_edge_trace_amd._lbfgsb_lockstep import LockstepFarm, minimize_many
-    bounds = np.array([[-3.0, 3.0]] * 3)
-    farm = LockstepFarm(3, slots=2)
-    try:
-        res = {}
-
-        def run(slot, seed, P):
-            x0, ev = _quartic_problems(seed, P)
-            res[slot] = farm.slot(slot).minimize(ev, x0, bounds)
-        ts = [threading.Thread(target=run, args=(0, 1, 40)), threading.Thread(target=run, args=(1, 2, 55))]
-        [t.start() for t in ts]
-        [t.join(timeout=60) for t in ts]
-        assert not any(t.is_alive() for t in ts)
-        run(0, 3, 20)  # slot reuse
-        for slot, (seed, P) in {1: (2, 55), 0: (3, 20)}.items():
-            x0, ev = _quartic_problems(seed, P)
-            Xr, Fr, _ = minimize_many(ev, x0, bounds)
-            X, F, rounds = res[slot]
-            assert rounds > 3 and np.array_equal(X, Xr) and np.array_equal(F, Fr)
-    finally:
-        farm.close()
+def test_host_start_points_are_the_reference_restarts():
+    """``start_points`` = theta of the kernel (gpet.py:244-245) + RandomState(seed).uniform over the log-bounds
+    (sklearn_gpr.py:283-288) -- the oracle draws the same numbers from its own MT19937."""
+    for seed in (0, 1, 42, 2**32 - 1):
+        th = np.asarray(ff.start_points(0.5, seed))
+        u = orc.legacy_uniform(seed, 36).reshape(12, 3)
+        assert np.array_equal(th[1:], ff.BOUNDS[:, 0] + (ff.BOUNDS[:, 1] - ff.BOUNDS[:, 0]) * u)
+        assert np.array_equal(th[0], np.log([5.0, 5.0, 0.5]))
 
 
 def test_committed_bench_line_keeps_the_driver_contract():
@@ -166,42 +101,3 @@ def test_committed_bench_line_keeps_the_driver_contract():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 50 * c["value"]  # north_star target: >= 50x the CPU path on one GPU
-
-
-def test_prepare_many_is_bit_identical_to_prepare():
-    """The grouped (stacked, axis=1) standardisation of many training sets equals the per-edge one bit for bit:
-    same argsort permutation, means, stds and standardised values, including a set that fills the whole x-grid
-    (weights zeroed) and sets with repeated x."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
-    rng = np.random.default_rng(5)
-    inits, obs, grids, fes = [], [], [], []
-    for e in range(40):
-        n_obs = [30, 31, 30, 97, 30][e % 5]
-        xg = np.arange(0, 500) if e % 7 else np.arange(0, n_obs + 2)
-        x = rng.choice(np.arange(1, len(xg) - 1), size=n_obs, replace=(e % 3 == 0)) if len(xg) > n_obs + 2 else np.arange(1, n_obs + 1)
-        inits.append(np.array([[0, rng.integers(0, 400)], [len(xg) - 1, rng.integers(0, 400)]]))
-        obs.append(np.stack([x, rng.integers(0, 400, size=n_obs)], axis=1).astype(np.int64))
-        grids.append(xg)
-        fes.append(bool(e % 2))
-    many = ff.prepare_many(inits, obs, grids, fes)
-    for e in range(40):
-        one = ff.prepare(inits[e], obs[e], grids[e], fes[e])
-        for k in ("xs", "yt", "w"):
-            assert np.array_equal(many[e][k], one[k]), (e, k)
-        for k in ("y_m", "y_s", "X_m", "X_s", "m2", "s2"):
-            assert many[e][k] == one[k], (e, k)
-
-
-def test_start_points_many_equals_randomstate_per_edge():
-    """Vectorised legacy seeding (init_genrand for all seeds at once) + one reused RandomState: the restart points
-    equal ``start_points`` (= ``RandomState(seed).uniform``) bit for bit, including the extreme seeds."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
-    seeds = [0, 1, 2, 42, 12345, 2**31 - 1, 2**31, 2**32 - 1] + list(range(100, 140))
-    noise = [1.0, 0.5] * (len(seeds) // 2)
-    many = ff.start_points_many(noise, seeds)
-    k = 0
-    for nz, sd in zip(noise, seeds):
-        for th in ff.start_points(nz, sd):
-            assert np.array_equal(many[k], th), (sd, k)
-            k += 1
-    assert k == len(many)
