@@ -48,7 +48,8 @@ def cpu_baseline(N, img_seed, n_traces, per_curve=True):
     """The CPU oracle (NumPy/SciPy port of the reference algorithm: LAPACK-SVD sampling, per-curve
     Simpson scoring, scipy L-BFGS-B final fit) timed on this host.  Checker code used as the timed
     baseline only.  Timed with 1 BLAS thread and with 16 (the reference is BLAS-thread sensitive,
-    BASELINE.md section 2); the faster setting is reported with its thread count."""
+    BASELINE.md section 2); the faster setting is reported with its thread count.  A trace includes the
+    constructor (gradient-image KDE), as a reference user pays it per edge; its share is timed separately."""
     from oracle import gpet_oracle as orc
     from threadpoolctl import threadpool_limits
     img, edge = orc.synth_sinusoid_image(N, img_seed)
@@ -63,15 +64,19 @@ def cpu_baseline(N, img_seed, n_traces, per_curve=True):
                 _, _, info = orc.trace(init, grad, per_curve=per_curve, seed=1 + k, **README_KW)
                 iters.append(info["n_iter"])
             dt = time.time() - t0
-        log("cpu baseline: %d BLAS thread(s): %.2f s per trace" % (threads, dt / n_traces))
+            tc = time.time()
+            orc.kde_of_gradient(orc.normalise(grad, (0, 1), np.float64))
+            ctor = time.time() - tc
+        log("cpu baseline: %d BLAS thread(s): %.2f s per trace (constructor %.2f s of it)" % (threads, dt / n_traces, ctor))
         if best is None or dt < best[0]:
-            best = (dt, threads, iters)
-    dt, threads, iters = best
+            best = (dt, threads, iters, ctor)
+    dt, threads, iters, ctor = best
     return dict(value=n_traces / dt, unit="edge-traces/s", cores=int(threads), kind="port",
                 sample="%d full trace(s) of the 500x500 README edge (RBF sf=75 l=20, S=1000, dx=5, pixel_thresh=5), "
                        "%s iterations, oracle/gpet_oracle.py: per-curve scoring loop + LAPACK SVD sampling + "
-                       "scipy L-BFGS-B x13; best of 1 and 16 BLAS threads" % (n_traces, iters),
-                seconds=dt)
+                       "scipy L-BFGS-B x13, constructor (gradient KDE) included; best of 1 and 16 BLAS threads" % (n_traces, iters),
+                seconds=dt, host_cores=usable_cpus(), ctor_s_per_trace=ctor,
+                value_ctor_excluded=n_traces / max(1e-9, dt - n_traces * ctor))
 
 
 def log(msg):
@@ -98,6 +103,118 @@ def usable_cpus():
     return max(2, n)
 
 
+def timed_steps(tracers, n_steps, depth, executor, fit_walls):
+    """n_steps passes of the hot path over the batch objects in `tracers` (round robin).  Pipelined (depth > 0): while the
+    converged fits of step k run -- device-resident L-BFGS-B, ~80 rounds of small launches on the batch's fit stream,
+    driven by a host thread that only enqueues and waits -- the device loop of step k+1 runs on another batch object /
+    HIP stream.  Returns (seconds in device loops, seconds of fits nothing overlapped, iterations, traces of the last step)."""
+    loop_s = fit_s = 0.0
+    iters_, traces_, pending = [], None, []
+    for k in range(n_steps):
+        tr_ = tracers[k % len(tracers)]
+        while len(pending) > depth:  # a batch object is reused only after its previous fits were collected
+            traces_ = pending.pop(0).result()
+        t_a = time.time()
+        tr_.reset()
+        iters_ = tr_.run_loop()
+        t_b2 = time.time()
+        loop_s += t_b2 - t_a
+        if depth > 0:
+            def timed_finish(tr__=tr_, it__=iters_):
+                t_f = time.time()
+                out_ = tr__.finish(it__)
+                fit_walls.append(time.time() - t_f)
+                return out_
+            pending.append(executor.submit(timed_finish))
+        else:
+            traces_ = tr_.finish(iters_)
+            fit_walls.append(time.time() - t_b2)
+            fit_s += time.time() - t_b2
+    t_c = time.time()
+    while pending:
+        traces_ = pending.pop(0).result()
+    if depth > 0:
+        fit_s += time.time() - t_c
+    return loop_s, fit_s, iters_, traces_
+
+
+def secondary_config3(pkg, ctx):
+    """BASELINE config 3's shape: 2048x2048 image, 1498 observations (+2 inits = 1500 training points), N_samples=4000:
+    ms of one GP iteration (fit + predict + covariance, factor, sample GEMM) and of the scoring, per stage."""
+    N = 2048
+    img, truth = synth_image(N, 0)
+    grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    rng = np.random.default_rng(0)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=1498, replace=False))
+    obs = np.stack([cols, np.clip(truth[cols, 0] + rng.integers(-2, 3, size=cols.size), 0, N - 1)], axis=1).astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=4000,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
+    tr = pkg.GP_Edge_Tracing(init, grad, obs=obs, **kw, _ctx=ctx)
+    b = tr._batch
+    b.set_obs(0, obs)
+
+    def timed(fn, reps=3):
+        """host wall time of a per-stage entry point (they enqueue on the context's stream; synchronised here)"""
+        fn()
+        ctx.sync()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return 1e3 * (time.time() - t0) / reps
+    ms = dict(fit_predict_cov=timed(lambda: b.fit_predict(True)), factor=timed(b.factor))
+    b.normals([7])
+    ms["sample_gemm"] = timed(b.sample)
+    ms["score_topk"] = timed(b.score)
+    s_ = b.scalars()
+    return dict(config="2048x2048, n=1500 training points, N_samples=4000, RBF sigma_f=300 l=80; per-stage entry points "
+                       "(1498 observations exceed algo_thresh, so the loop itself would not iterate: SURVEY 8d C3)",
+                gp_iter_ms=ms["fit_predict_cov"] + ms["factor"] + ms["sample_gemm"], scoring_ms=ms["score_topk"], stage_ms=ms,
+                n_train=int(s_.n), factor_rank=int(s_.rank), timing="host wall clock around the entry points, 3 repetitions")
+
+
+def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=2):
+    """BASELINE config 5's shape on ONE GPU: a 1024x1024 image sequence, Matern-5/2 (sigma_f ~154, l ~41), frames
+    chained by the warm start, `n_chains` chains traced as batches of `n_chains` edges (one frame per chain and step)."""
+    N = 1024
+    T = n_chains * frames_per_chain
+    frames = []
+    for t in range(T):
+        img, truth = pkg.gpet_utils.construct_test_img((N, N), int(0.4 * N * (1.0 + 0.01 * (t % frames_per_chain))), 4, 0.05,
+                                                       'sinusoidal', 0.3, gaps=True, seed=100 + t)
+        frames.append(pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41}, noise_y=1, N_samples=1000,
+              score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    st = pkg.SequenceTracer(frames, init, n_chains=n_chains, warm_every=16, seed=3, _ctx=ctx, **kw)
+    t0 = time.time()
+    st()
+    dt = time.time() - t0
+    # the factor alone at a mid-trace state: 8 edges, warm-start observations, not finished
+    warm = truth[16:-16:16][:, [1, 0]].astype(np.int64)
+    fb = pkg.GP_Edge_Tracing_Batch([init] * n_chains, frames[:n_chains], [3] * n_chains, obs=[warm] * n_chains, _ctx=ctx, **kw)
+    fb._batch.fit_predict(True)
+    fb._batch.factor()
+    fac = fb._batch.profile_stage(1, 2)
+    sweeps = int(fb._batch.scalars().lml)
+    fb._batch.close()
+    one1 = pkg.GP_Edge_Tracing_Batch([init], frames[:1], [3], obs=[warm], _ctx=ctx, **kw)
+    one1._batch.fit_predict(True)
+    one1._batch.factor()
+    fac1 = one1._batch.profile_stage(1, 2)
+    one1._batch.close()
+    one = pkg.SequenceTracer(frames[:frames_per_chain], init, n_chains=1, warm_every=16, seed=3, _ctx=ctx, **kw)
+    t1 = time.time()
+    one()
+    dt1 = time.time() - t1
+    return dict(config="1024x1024, Matern-5/2 sigma_f=154 l=41, N_samples=1000, delta_x=8; %d frames = %d chains x %d "
+                       "(cold first frame, warm-started later ones), one GPU, constructor of the batch included" % (T, n_chains, frames_per_chain),
+                frames_per_s=T / dt, seconds_total=dt, iterations_per_frame=st.iterations,
+                single_chain_s_per_frame=dt1 / frames_per_chain, single_chain_iterations=one.iterations,
+                factor_ms_batch_of_chains=fac, factor_ms_single_edge=fac1, factor_jacobi_sweeps=sweeps, chains=n_chains)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,23 +222,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--edges", type=int, default=1024,
                     help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges; "
-                         "measured on one MI355X: 256 edges 3.6 k traces/s, 512 4.0 k, 1024 4.2 k, 2048 4.2 k -- the loop's "
-                         "kernels are latency-bound below ~4 workgroups per CU)")
+                         "the loop's kernels are latency-bound below ~4 workgroups per CU, so the default fills the GPU; "
+                         "the 256-edge figure of config 4 is reported next to it)")
     ap.add_argument("--size", type=int, default=500)
-    ap.add_argument("--fit-workers", type=int, default=int(os.environ.get("GPET_FIT_WORKERS", "0")),
-                    help="0: final fits on the GPU (batched LML kernel); >1: host worker processes instead")
-    ap.add_argument("--lbfgs-workers", type=int, default=max(1, min(12, usable_cpus() - 2)),
-                    help="worker processes advancing scipy's L-BFGS-B routine in lock step (final fits)")
     ap.add_argument("--pipeline-depth", type=int, default=3,
-                    help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1)")
-    ap.add_argument("--concurrent-steps", action="store_true",
-                    help="experiment: one driver thread per batch object (device loop + fits of a step back to back), "
-                         "so that device loops of different batch objects overlap too (measured: slower, DESIGN.md)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="trace the steps strictly one after the other (default: the converged fits of step k overlap "
-                         "the device loop of step k+1 on a second batch object / HIP stream)")
+                    help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1; 0 = none)")
     ap.add_argument("--cpu-traces", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ctor included, 256 edges, "
+                    "distinct images, configs 3 and 5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,20 +239,8 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print("warning: WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
-    # worker processes for the host-side final fits: forked BEFORE anything touches the GPU
-    from gaussian_process_edge_trace_amd.gpet import make_fit_pool
-    from gaussian_process_edge_trace_amd._lbfgsb_lockstep import LockstepFarm
-    pool = make_fit_pool(args.fit_workers) if args.fit_workers > 1 else None
-    # L-BFGS-B state machines of the final fits advance in worker processes (the objective runs on
-    # the GPU); also created before HIP is initialised
-    n_lbfgs = max(2, min(args.lbfgs_workers, (usable_cpus() - 2) // max(1, world))) if args.lbfgs_workers > 1 else 0
-    pipeline = (not args.no_pipeline) and pool is None
-    depth = max(1, args.pipeline_depth) if pipeline else 0
-    n_farms = depth + 1 if pipeline else 1
-    # one farm, one job slot per batch object: a fit running alone (the last of a run) gets every worker
-    big_farm = LockstepFarm(n_lbfgs, slots=n_farms, pmax=max(16384, 13 * args.edges)) if (n_lbfgs > 1 and pool is None) else None
-    farms = [big_farm.slot(i) if big_farm is not None else None for i in range(n_farms)]
-    farm = farms[0]
+    depth = max(0, args.pipeline_depth)
+    pipeline = depth > 0
     import torch
     dist = None
     # GPET_BENCH_BACKEND=gloo + GPET_BENCH_SHARE_GPU=1: rehearsal of the N>1 path on a one-GPU box
@@ -163,11 +260,13 @@ def main():
     L = pkg._lib
     ctx = L.Context(dev_index)
 
-    # ---- inputs: one shared gradient image, produced on rank 0's GPU, broadcast over RCCL/xGMI
+    # ---- inputs: one shared gradient image, produced on rank 0's GPU, broadcast over RCCL/xGMI and consumed where the
+    #      collective put it (device pointer -> gpet_batch_create2 / GPET_GRAD_ON_DEVICE)
     N = args.size
     img, truth = synth_image(N, 3)
     init = truth[[0, -1], :][:, [1, 0]]
     t_b = 0.0
+    grad_kw = {}
     if world > 1:
         g = torch.empty((N, N), dtype=torch.float32, device=coll_dev)
         if rank == 0:
@@ -177,19 +276,27 @@ def main():
         dist.broadcast(g, src=0)
         torch.cuda.synchronize()
         t_b = time.time() - tb0
-        grad = g.cpu().numpy()
+        if coll_dev == "cuda":
+            grad, grad_kw = None, dict(grad_device_ptrs=[g.data_ptr()], grad_shape=(N, N))
+        else:
+            grad = g.numpy()
     else:
         grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
 
     E = args.edges
     seeds = [1 + rank * E + e for e in range(E)]  # independent edges: distinct RNG streams
-    tracer = pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx,
-                                       fit_pool=pool, fit_farm=farm)
+
+    def make_tracer(n_edges, ctx_, images=None, inits=None, sds=None):
+        return pkg.GP_Edge_Tracing_Batch(inits if inits is not None else [init] * n_edges,
+                                         images if images is not None else grad, sds if sds is not None else seeds[:n_edges],
+                                         **README_KW, _ctx=ctx_, **(grad_kw if images is None else {}))
+
+    tracer = make_tracer(E, ctx)
     tracers = [tracer]
-    for d_ in range(depth):  # more batch objects, each with its own context (= HIP stream) and worker farm
-        ctx_d = L.Context(dev_index)
-        tracers.append(pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx_d,
-                                                 fit_farm=farms[d_ + 1]))
+    for d_ in range(depth):  # more batch objects, each with its own context (= HIP stream)
+        tracers.append(make_tracer(E, L.Context(dev_index)))
+    if grad is None:
+        grad = g.cpu().numpy()  # (the secondary figures below build batches from host arrays)
 
     def barrier():
         for tr_ in tracers:
@@ -200,55 +307,11 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
     executor = ThreadPoolExecutor(max_workers=max(1, depth))
-    drivers = [ThreadPoolExecutor(max_workers=1) for _ in tracers] if args.concurrent_steps else []
-
     fit_walls = []  # wall time of every step's converged fits (they run concurrently with later device loops)
 
     def run_steps(n_steps, timed):
-        """n_steps passes of the hot path.  Pipelined: while the converged fits of step k run (host-driven
-        lock-step L-BFGS-B + LML kernels on stream A) the device loop of step k+1 runs on stream B."""
-        loop_s = fit_s = 0.0
-        iters_, traces_, pending = [], None, []
         fit_walls.clear()
-        if pipeline and args.concurrent_steps:
-            def one_step(tr__):
-                t_a = time.time()
-                tr__.reset()
-                it__ = tr__.run_loop()
-                t_m = time.time()
-                out_ = tr__.finish(it__)
-                return it__, out_, t_m - t_a, time.time() - t_m
-            futs = [drivers[k % len(tracers)].submit(one_step, tracers[k % len(tracers)]) for k in range(n_steps)]
-            for f_ in futs:
-                iters_, traces_, lw, fw = f_.result()
-                loop_s += lw
-                fit_walls.append(fw)
-            return loop_s, 0.0, iters_, traces_
-        for k in range(n_steps):
-            tr_ = tracers[k % len(tracers)]
-            # a batch object is reused only after its previous fits (depth+1 steps ago) were collected
-            while len(pending) > depth:
-                traces_ = pending.pop(0).result()
-            t_a = time.time()
-            tr_.reset()
-            iters_ = tr_.run_loop()
-            t_b2 = time.time()
-            loop_s += t_b2 - t_a
-            if pipeline:
-                def timed_finish(tr__=tr_, it__=iters_):
-                    t_f = time.time()
-                    out_ = tr__.finish(it__)
-                    fit_walls.append(time.time() - t_f)
-                    return out_
-                pending.append(executor.submit(timed_finish))
-            else:
-                traces_ = tr_.finish(iters_)
-                fit_s += time.time() - t_b2
-        t_c = time.time()
-        while pending:
-            traces_ = pending.pop(0).result()
-        if pipeline:
-            fit_s += time.time() - t_c
+        loop_s, fit_s, iters_, traces_ = timed_steps(tracers, n_steps, depth, executor, fit_walls)
         if timed:
             log("%d step(s): device loops %.3fs, fits %s" % (n_steps, loop_s, ("%.3fs" % fit_s) if not pipeline else "overlapped (tail %.3fs)" % fit_s))
         return loop_s, fit_s, iters_, traces_
@@ -268,10 +331,6 @@ def main():
     value = total_traces / elapsed
 
     if rank != 0:
-        if pool is not None:
-            pool.terminate()
-        if big_farm is not None:
-            big_farm.close()
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -279,6 +338,71 @@ def main():
 
     # ---- quality of this rank's traces vs ground truth (sanity band, not the metric)
     mse = float(np.mean([pkg.gpet_utils.trace_MSE(tr, truth) for tr in traces]))
+
+    # ---- secondary figures (N = 1 only): what the headline leaves out, each a short run of its own
+    secondary = None
+    if world == 1 and not args.no_secondary:
+        secondary = {}
+        # (a) constructor INCLUDED: a fresh batch object per step (arena, image upload + re-normalisation, gradient KDE,
+        #     prior eigenbasis of every edge), then loop + fits, nothing overlapped
+        ctx2 = L.Context(dev_index)
+        t_c = []
+        for _ in range(3):
+            t1 = time.time()
+            fresh = make_tracer(E, ctx2)
+            t2 = time.time()
+            fresh()
+            ctx2.sync()
+            t_c.append((time.time() - t1, t2 - t1))
+            fresh._batch.close()
+            del fresh
+        best = min(t_c)
+        secondary["ctor_included"] = dict(traces_per_s=E / best[0], s_per_step=best[0], ctor_s=best[1], edges=E,
+                                          note="fresh GP_Edge_Tracing_Batch per step, loop + converged fits not overlapped with anything")
+        # (b) the same without pipelining (ctor excluded): the loop and the fits of ONE batch object back to back
+        fw = []
+        l1, f1, _, _ = timed_steps([tracer], 3, 0, executor, fw)
+        secondary["no_pipeline"] = dict(traces_per_s=3 * E / (l1 + f1), loop_s_per_step=l1 / 3, fit_s_per_step=f1 / 3, edges=E)
+        # (c) BASELINE config 4's batch size: 256 edges per step (pipelined like the headline)
+        small = [make_tracer(256, tr_._ctx) for tr_ in tracers]
+        timed_steps(small, len(small), depth, executor, [])
+        for tr_ in small:
+            tr_._ctx.sync()
+        t1 = time.time()
+        l2, f2, it2, _ = timed_steps(small, 8, depth, executor, [])
+        for tr_ in small:
+            tr_._ctx.sync()
+        dt2 = time.time() - t1
+        secondary["edges_256"] = dict(traces_per_s=8 * 256 / dt2, ms_per_step=1e3 * dt2 / 8, iterations=sorted(set(it2)))
+        for tr_ in small:
+            tr_._batch.close()
+        del small
+        # (d) distinct images and inits: 256 edges, every edge its own noise realisation of the image (own gradient image,
+        #     own gradient KDE) and its own end points -- nothing shared through L2
+        imgs, inits_d = [], []
+        for e in range(256):
+            im_e, tr_e = synth_image(N, 1000 + e)
+            imgs.append(pkg.gpet_utils.comp_grad_img(im_e, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
+            inits_d.append(tr_e[[0, -1], :][:, [1, 0]])
+        dist_tr = [make_tracer(256, tr_._ctx, images=imgs, inits=inits_d, sds=seeds[:256]) for tr_ in tracers[:2]]
+        timed_steps(dist_tr, 2, min(depth, 1), executor, [])
+        t1 = time.time()
+        timed_steps(dist_tr, 6, min(depth, 1), executor, [])
+        for tr_ in dist_tr:
+            tr_._ctx.sync()
+        dt3 = time.time() - t1
+        secondary["edges_256_distinct_images"] = dict(traces_per_s=6 * 256 / dt3, ms_per_step=1e3 * dt3 / 6)
+        for tr_ in dist_tr:
+            tr_._batch.close()
+        del dist_tr, imgs
+        log("secondary: ctor included %.0f traces/s, no pipeline %.0f, 256 edges %.0f, 256 distinct images %.0f"
+            % (secondary["ctor_included"]["traces_per_s"], secondary["no_pipeline"]["traces_per_s"],
+               secondary["edges_256"]["traces_per_s"], secondary["edges_256_distinct_images"]["traces_per_s"]))
+        secondary["config3"] = secondary_config3(pkg, ctx)
+        log("secondary: config 3 GP iteration %.2f ms + scoring %.2f ms" % (secondary["config3"]["gp_iter_ms"], secondary["config3"]["scoring_ms"]))
+        secondary["config5"] = secondary_config5(pkg, ctx)
+        log("secondary: config 5 %.2f frames/s (8 chains), single chain %.3f s per frame"
+            % (secondary["config5"]["frames_per_s"], secondary["config5"]["single_chain_s_per_frame"]))
 
     # ---- one step alone (nothing else on the GPU): device time of the LML kernel launches of its converged fits,
     #      hipEvents around every launch on the fit stream (gpet_lml_stats)
@@ -357,7 +481,7 @@ def main():
     ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)  # flop per byte
     use_flops = (a_flops / a_bytes) > ridge
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tp):
         prof = json.load(open(tp))
         if prof.get("edges") == E and prof.get("image") == [N, N] and dom in prof.get("kernels", {}):
@@ -395,8 +519,12 @@ def main():
                                "delta_x=5, pixel_thresh=5) x %d independent edges per GPU and step (config 4's batch of independent edges, sized to fill the GPU), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
                    "edges_per_gpu": E, "image": [N, N], "iterations_per_trace": iters[:4],
-                   "final_fit": ("scipy L-BFGS-B routine x13 starts in lock step (%d worker processes), objective = batched LML kernel on the GPU" % n_lbfgs
-                                 if args.fit_workers <= 1 else "host objective, %d worker processes" % args.fit_workers)},
+                   "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
+                                "all on the GPU (gpet_final_fit_all); no host workers"},
+        "host": {"cpus_usable": usable_cpus(), "cpus_machine": os.cpu_count(), "lbfgs_workers": 0,
+                 "host_threads": 1 + max(1, depth), "note": "the host only enqueues launches and waits: one driver thread for the "
+                 "device loops plus one per converged fit in flight"},
+        "secondary": secondary,
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},
         "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
@@ -409,10 +537,6 @@ def main():
     if cpu:
         out["speedup_vs_cpu_port"] = value / cpu["value"]
     print(json.dumps(out))
-    if pool is not None:
-        pool.terminate()
-    if big_farm is not None:
-        big_farm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
