@@ -71,3 +71,106 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
               score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
     single = np.stack([orc.trace(init, grad, seed=s, **kw)[0] for s in range(1, 6)])
     assert np.array_equal(a, single)
+
+
+def test_sequence_partition_covers_frames_in_whole_chains():
+    from gaussian_process_edge_trace_amd.sharding import sequence_partition
+    from gaussian_process_edge_trace_amd.sequence import chain_slices
+    for T, C, W in [(64, 8, 8), (64, 8, 2), (10, 4, 3), (5, 8, 2), (7, 2, 4)]:
+        chains = chain_slices(T, C)
+        seen, nloc = [], 0
+        for r in range(W):
+            f0, f1, nc = sequence_partition(T, C, W, r)
+            nloc += nc
+            if nc:
+                assert (f0, f1) == (chains[len(seen)][0], chains[len(seen) + nc - 1][1])
+                # the local re-slicing of the block reproduces the global chain boundaries
+                assert [(a + f0, b + f0) for a, b in chain_slices(f1 - f0, nc)] == chains[len(seen):len(seen) + nc]
+                seen += chains[len(seen):len(seen) + nc]
+        assert nloc == len(chains) and seen == chains
+
+
+GPU_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+import gaussian_process_edge_trace_amd as amd
+from gaussian_process_edge_trace_amd.sharding import trace_sharded, trace_sequence_sharded
+
+KW = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 20, 'length_scale': 10}, noise_y=1, N_samples=256,
+          score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+MKW = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 20, 'length_scale': 6}, noise_y=1, N_samples=200,
+           score_thresh=1, delta_x=6, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+ctx = amd._lib.Context(0)          # both ranks share the box's one GPU
+
+def tracer(grad, inits, seeds):     # the PRODUCT tracer: one batch of this rank's block of edges
+    return amd.GP_Edge_Tracing_Batch(inits, np.asarray(grad), seeds, **KW, _ctx=ctx)()
+
+N = 128
+img, edge = amd.gpet_utils.construct_test_img((N, N), int(0.4 * N), 4, 0.05, 'sinusoidal', 0.3, gaps=True, seed=3)
+init = edge[[0, -1], :][:, [1, 0]]
+grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx) if rank == 0 else None
+n = 7
+out = trace_sharded(grad, (N, N), [init] * n, list(range(1, n + 1)), tracer, dist)
+np.save(os.path.join(%(tmp)r, "edges_rank%%d.npy" %% rank), out)
+
+T = 6
+frames = None
+if rank == 0:
+    frames = np.stack([amd.gpet_utils.comp_grad_img(
+        amd.gpet_utils.construct_test_img((N, N), int(0.4 * N * (1 + 0.02 * t)), 4, 0.05, 'sinusoidal', 0.3, gaps=True, seed=20 + t)[0],
+        amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx) for t in range(T)])
+
+def seq_tracer(block, first_frame, n_chains):
+    return amd.SequenceTracer(list(np.asarray(block)), init, n_chains=n_chains, warm_every=12, seed=5, _ctx=ctx, **MKW)()
+
+seq = trace_sequence_sharded(frames, (N, N), T, init, 3, seq_tracer, dist)
+np.save(os.path.join(%(tmp)r, "seq_rank%%d.npy" %% rank), seq)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_gpu_tracer_equals_single_process(tmp_path):
+    """Two ranks (fresh child processes, gloo, both on device 0) run trace_sharded and trace_sequence_sharded with the
+    GPU tracer: the gathered result is identical on both ranks and bit-identical to the single-process batch /
+    sequence -- edges and chains are independent, so the partition must not change a pixel."""
+    import gaussian_process_edge_trace_amd as amd
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER % dict(root=ROOT, port=port, tmp=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    a, b = np.load(tmp_path / "edges_rank0.npy"), np.load(tmp_path / "edges_rank1.npy")
+    assert np.array_equal(a, b) and a.shape == (7, 128, 2)
+    sa, sb = np.load(tmp_path / "seq_rank0.npy"), np.load(tmp_path / "seq_rank1.npy")
+    assert np.array_equal(sa, sb) and sa.shape == (6, 128, 2)
+    # single process, one batch / one sequence tracer
+    ctx = amd._lib.Context(0)
+    N = 128
+    img, edge = amd.gpet_utils.construct_test_img((N, N), int(0.4 * N), 4, 0.05, 'sinusoidal', 0.3, gaps=True, seed=3)
+    init = edge[[0, -1], :][:, [1, 0]]
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 20, 'length_scale': 10}, noise_y=1, N_samples=256,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    single = np.stack(amd.GP_Edge_Tracing_Batch([init] * 7, grad, list(range(1, 8)), **kw, _ctx=ctx)())
+    assert np.array_equal(a, single)
+    mkw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 20, 'length_scale': 6}, noise_y=1, N_samples=200,
+               score_thresh=1, delta_x=6, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    frames = [amd.gpet_utils.comp_grad_img(
+        amd.gpet_utils.construct_test_img((N, N), int(0.4 * N * (1 + 0.02 * t)), 4, 0.05, 'sinusoidal', 0.3, gaps=True, seed=20 + t)[0],
+        amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx) for t in range(6)]
+    seq1 = np.stack(amd.SequenceTracer(frames, init, n_chains=3, warm_every=12, seed=5, _ctx=ctx, **mkw)())
+    assert np.array_equal(sa, seq1)
