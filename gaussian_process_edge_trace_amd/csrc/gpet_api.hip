@@ -885,7 +885,7 @@ int gpet_gp_factor(gpet_batch* b) {
   if (!b->have_fit) return fail(c, GPET_ERR_STATE, "gpet_gp_factor before gpet_gp_fit_predict");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
-  HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+  HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, ~0u, b->h_edges.data()));
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   b->have_factor = true;
   return check_device_status(b);
@@ -1008,7 +1008,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         break;
       case 1:
         if (b->structured) HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 4u | 8u));
-        else HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd));
+        else HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, ~0u, b->h_edges.data()));
         break;
       case 120: case 121: case 122: case 123:  // structured path: fit, (U, H, mean), Jacobi, factor rows
         HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
@@ -1365,7 +1365,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         HIPCHK(c, launch_struct_iteration(c->stream, edges_l, B_l, b->bd));
       } else {
         HIPCHK(c, launch_fit_predict(c->stream, edges_l, B_l, b->bd, 1));
-        HIPCHK(c, launch_factor(c->stream, edges_l, B_l, b->bd));
+        HIPCHK(c, launch_factor(c->stream, edges_l, B_l, b->bd, ~0u, edges_l == b->d_edges ? b->h_edges.data() : b->h_edges_act.data()));
       }
       HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
       HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, b->structured ? b->bd.r0_max : 0));

@@ -19,6 +19,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace gpet {
 
@@ -26,6 +27,7 @@ namespace gpet {
 #define PCX_COLS 32
 #define OJ_B 8
 #define OJ_M 16
+#define OJ_ARGS_MAXB 8     // batches up to this size get their per-edge pointers in the kernel arguments
 #define OJ_STAGE_MAX 1024  // widest edge whose 16-row panel (16 x Lg doubles) is staged in LDS
 #define OJ_PF 16  // 16-column tiles per wave whose operands are prefetched into registers (4 waves x 16 x 16 = 1024 columns)
 
@@ -104,8 +106,37 @@ __global__ void __launch_bounds__(256) k_pcx_init(EdgeDev* edges, int nw_max) {
 // table; {state, candidates, this wave's remaining diagonals}; {the pivot's previous entries, the pivot's covariance
 // row, the previous entries of this wave's 8 columns}.  No LDS and no workgroup barrier: every wave finds the pivot
 // itself and reads the pivot's entries itself, a wave owns 8 columns, lane = previous row index s (mod 64).
-__global__ void __launch_bounds__(256) k_pcx_step(EdgeDev* edges, int t, int nw_max) {
-  const EdgeDev E = edges[blockIdx.y];
+struct PcxEdge {
+  double *G, *Gt, *pcx_d, *pcx_cand;
+  const double* cov;
+  int* perm;
+  EigState* eig;
+  const gpet_scalars* sc;
+  int Lg, r_cap, factor_injected, pad;
+};
+struct PcxArgs {
+  PcxEdge e[OJ_ARGS_MAXB];
+};
+
+template <bool ARGS>
+__global__ void __launch_bounds__(256) k_pcx_step(PcxArgs args, EdgeDev* edges, int t, int nw_max) {
+  PcxEdge E;
+  if (ARGS) {
+    E = args.e[blockIdx.y];
+  } else {
+    const EdgeDev& Et = edges[blockIdx.y];
+    E.G = Et.G;
+    E.Gt = Et.Gt;
+    E.pcx_d = Et.pcx_d;
+    E.pcx_cand = Et.pcx_cand;
+    E.cov = Et.cov;
+    E.perm = Et.perm;
+    E.eig = Et.eig;
+    E.sc = Et.sc;
+    E.Lg = Et.Lg;
+    E.r_cap = Et.r_cap;
+    E.factor_injected = Et.factor_injected;
+  }
   const int Lg = E.Lg, j0 = blockIdx.x * PCX_COLS, tid = threadIdx.x;
   if (j0 >= Lg || t >= E.r_cap) return;
   const int lane = tid & 63, w = tid >> 6;
@@ -330,16 +361,45 @@ __device__ __forceinline__ int oj_krow(int jj, int lg) { return 8 * (lg & 1) + 4
 // read from HBM/L2 ONCE into LDS with fully coalesced loads; the Gram matrix and the row update both take their
 // matrix-core operands from there.  Not STAGED (Lg > OJ_STAGE_MAX): operands straight from global memory, the update's
 // operands requested before the sweep so that they arrive while wave 0 rotates.
-template <bool STAGED>
-__global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int nblk) {
-  const EdgeDev E = edges[blockIdx.y];
-  if (eig_skip(E)) return;
-  EigState* st = E.eig;
-  if (st->converged) return;
-  const int rank = st->rank, Lg = E.Lg;
+// What a round needs of an edge.  For batches of up to OJ_ARGS_MAXB edges the launcher passes these by value in the
+// kernel arguments, which removes the dependent round trip through the edge table from every one of the ~1 600 round
+// launches of a factorisation (a launch starts with cold caches: every dependent global access costs ~2 us).
+struct OjEdge {
+  double* G;
+  EigState* st;
+  const gpet_scalars* sc;
+  int Lg, r_cap, injected, pad;
+};
+struct OjArgs {
+  OjEdge e[OJ_ARGS_MAXB];
+};
+
+template <bool STAGED, bool ARGS>
+__global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, int round, int nblk) {
+  OjEdge D;
+  if (ARGS) {
+    D = args.e[blockIdx.y];
+  } else {
+    const EdgeDev& Et = edges[blockIdx.y];
+    D.G = Et.G;
+    D.st = Et.eig;
+    D.sc = Et.sc;
+    D.Lg = Et.Lg;
+    D.r_cap = Et.r_cap;
+    D.injected = Et.factor_injected;
+  }
+  struct {
+    double* G;
+    int Lg;
+  } E = {D.G, D.Lg};
+  EigState* st = D.st;
+  // the edge's state and (STAGED) its 16 rows are requested together: one round trip instead of two.  The rows are
+  // read before the rank is known, so the row index is clamped to the buffer and the mask is applied afterwards.
+  const int s_done = D.sc->done, s_force = D.sc->force, s_status = D.sc->status;
+  const int s_conv = st->converged, rank = st->rank;
+  const int Lg = E.Lg;
   int bI, bJ;
   oj_rr_pair(nblk - 1, round, blockIdx.x, bI, bJ);
-  if (bI * OJ_B >= rank) return;  // (bI < bJ: both blocks are empty)
   extern __shared__ double s_X[];  // STAGED: [16][ldx]
   __shared__ double s_part[4][OJ_M][OJ_M + 1];
   __shared__ double s_C[OJ_M][OJ_M + 1];
@@ -348,34 +408,35 @@ __global__ void __launch_bounds__(256) k_oj_round(EdgeDev* edges, int round, int
   const int lr = lane & 15, lg = lane >> 4;
   const int nch = (Lg + 15) >> 4;  // 16-column chunks = 16-column tiles of the update below
   const int ldx = ((Lg + 31) & ~31) + 2;
+  double v[STAGED ? 16 : 1][4];
   if (STAGED) {
     // -- stage: thread t takes columns t, t + 256, ... of every row: 512 contiguous bytes per wave instruction
-    const int kmax = nch * 16;
-    for (int r0 = 0; r0 < OJ_M; r0 += 16) {
-      double v[16][4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gi = oj_row(bI, bJ, r0 + r);
-        const double* __restrict__ xrow = E.G + (size_t)gi * Lg;
+    for (int r = 0; r < 16; ++r) {
+      int gi = oj_row(bI, bJ, r);
+      gi = gi < D.r_cap ? gi : D.r_cap - 1;
+      const double* __restrict__ xrow = E.G + (size_t)gi * Lg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = tid + 256 * i;
-          v[r][i] = (gi < rank && k < Lg) ? xrow[k] : 0.0;
-        }
+      for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        v[r][i] = (k < Lg) ? xrow[k] : 0.0;
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = tid + 256 * i;
-          if (k < kmax) s_X[(r0 + r) * ldx + k] = v[r][i];
-        }
     }
-    for (int k = 1024 + tid; k < kmax; k += 256)  // (STAGED is only launched for Lg <= 1024; kept for safety)
-      for (int r = 0; r < OJ_M; ++r) {
-        const int gi = oj_row(bI, bJ, r);
-        s_X[r * ldx + k] = (gi < rank && k < Lg) ? E.G[(size_t)gi * Lg + k] : 0.0;
+  }
+  asm volatile("" ::: "memory");  // (the loads above stay above the exits below)
+  if ((s_done && !s_force) || s_status != GPET_OK || D.injected || s_conv) return;
+  if (bI * OJ_B >= rank) return;  // (bI < bJ: both blocks are empty)
+  if (STAGED) {
+    const int kmax = nch * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool live = oj_row(bI, bJ, r) < rank;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        if (k < kmax) s_X[r * ldx + k] = live ? v[r][i] : 0.0;
       }
+    }
     __syncthreads();
     // -- Gram matrix: A operand == B operand == X[row lr][k]; four independent accumulators per wave
     v4f64e acc[4];
@@ -581,13 +642,47 @@ __global__ void __launch_bounds__(256) k_oj_rows(EdgeDev* edges) {
 
 // Enqueues the whole factorisation.  Nothing is read back: a fixed budget of pivot steps and sweeps is launched and
 // the kernels turn into no-ops once the device-side tests (tolerance reached / converged) have fired.
-hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const EdgeDev* h_edges) {
   (void)hipGetLastError();
+  // small batches: the per-edge pointers travel in the kernel arguments (h_edges = host copy of the edge table)
+  OjArgs oj_args;
+  memset(&oj_args, 0, sizeof oj_args);
+  const bool use_args = h_edges != nullptr && B <= OJ_ARGS_MAXB && !getenv("GPET_OJ_NO_ARGS");
+  if (use_args)
+    for (int e = 0; e < B; ++e) {
+      OjEdge& d = oj_args.e[e];
+      d.G = h_edges[e].G;
+      d.st = h_edges[e].eig;
+      d.sc = h_edges[e].sc;
+      d.Lg = h_edges[e].Lg;
+      d.r_cap = h_edges[e].r_cap;
+      d.injected = h_edges[e].factor_injected;
+    }
   const int nw = cdiv_h(bd.Lg, PCX_COLS);
   hipLaunchKernelGGL(k_pcx_init, dim3(nw, B), dim3(256), 0, st, d_edges, nw);
   const int steps = bd.r_cap < bd.Lg ? bd.r_cap : bd.Lg;
-  for (int t = 0; t < steps; ++t)
-    hipLaunchKernelGGL(k_pcx_step, dim3(nw, B), dim3(256), 0, st, d_edges, t, nw);
+  PcxArgs px_args;
+  memset(&px_args, 0, sizeof px_args);
+  if (use_args)
+    for (int e = 0; e < B; ++e) {
+      PcxEdge& d = px_args.e[e];
+      const EdgeDev& h = h_edges[e];
+      d.G = h.G;
+      d.Gt = h.Gt;
+      d.pcx_d = h.pcx_d;
+      d.pcx_cand = h.pcx_cand;
+      d.cov = h.cov;
+      d.perm = h.perm;
+      d.eig = h.eig;
+      d.sc = h.sc;
+      d.Lg = h.Lg;
+      d.r_cap = h.r_cap;
+      d.factor_injected = h.factor_injected;
+    }
+  for (int t = 0; t < steps; ++t) {
+    if (use_args) hipLaunchKernelGGL((k_pcx_step<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+    else hipLaunchKernelGGL((k_pcx_step<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+  }
   hipLaunchKernelGGL(k_pcx_fin, dim3(B), dim3(64), 0, st, d_edges, steps, nw);
   const int nblk = 2 * cdiv_h(steps, 2 * OJ_B);
   const int max_sweeps = gpet_opt_oj_max_sweeps();
@@ -598,17 +693,20 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-      (void)hipFuncSetAttribute((const void*)k_oj_round<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_oj_round<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_oj_round<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
       attr_done[dev] = 1;
     }
   }
   const double tol2 = pow(10.0, -2.0 * (double)gpet_opt_oj_tol_exp());
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int round = 0; round < nblk - 1; ++round) {
-      if (staged)
-        hipLaunchKernelGGL((k_oj_round<true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, d_edges, round, nblk);
+      if (staged && use_args)
+        hipLaunchKernelGGL((k_oj_round<true, true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk);
+      else if (staged)
+        hipLaunchKernelGGL((k_oj_round<true, false>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk);
       else
-        hipLaunchKernelGGL((k_oj_round<false>), dim3(nblk / 2, B), dim3(256), 0, st, d_edges, round, nblk);
+        hipLaunchKernelGGL((k_oj_round<false, false>), dim3(nblk / 2, B), dim3(256), 0, st, oj_args, d_edges, round, nblk);
     }
     hipLaunchKernelGGL(k_oj_check, dim3(B), dim3(64), 0, st, d_edges, tol2);
   }

@@ -17,7 +17,8 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
                               unsigned parts = ~0u);
 hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_final_cov(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
-hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
+hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u,
+                         const EdgeDev* h_edges = nullptr);
 // dynamic LDS available to k_struct_H (the structured path needs at least U + one row of L + beta in it)
 #define STRUCT_H_LDS_MAX (150 * 1024)
 hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
@@ -28,7 +29,7 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
                       int raw_band = 0);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
 // any-rank factor (gpet_eig.hip): pivoted Cholesky over the whole GPU + one-sided block Jacobi on its rows
-hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
+hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const EdgeDev* h_edges = nullptr);
 // gpet_set_option "oj_max_sweeps" (default 16; environment GPET_OJ_MAX_SWEEPS): sweep budget of that Jacobi
 int& gpet_opt_oj_max_sweeps();
 // gpet_set_option "oj_tol_exp" (default 8; environment GPET_OJ_TOL_EXP): the Jacobi stops after a sweep in which every

@@ -3455,9 +3455,9 @@ int& gpet_opt_scalar_jacobi() {
   return v;
 }
 
-hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
+hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts, const EdgeDev* h_edges) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  if (bd.r_cap > 96 && !gpet_opt_scalar_jacobi()) return launch_factor_big(st, d_edges, B, bd);
+  if (bd.r_cap > 96 && !gpet_opt_scalar_jacobi()) return launch_factor_big(st, d_edges, B, bd, h_edges);
   if (bd.r_cap > 96) {
     // gpet_set_option("scalar_jacobi", 1): the round-1 solver, kept as an independent cross-check of the one above --
     // cyclic two-sided Jacobi directly on the covariance, one parameter + one apply kernel per round.  A fixed budget

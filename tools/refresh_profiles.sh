@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates profiles/r01_* on the GPU box (run through gpurun from the repo root):
+# Regenerates profiles/r02_* on the GPU box (run through gpurun from the repo root):
 #   bench line, rocprofv3 --kernel-trace --stats of the same command, the dominant kernel alone, PMC traffic.
 # Every rocprofv3 pass is its own run (PMC passes never share a run with a trace), program directly after `--`.
 set -e
@@ -20,20 +20,26 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stages.py $E 2 > $O/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_lml_f -- python3 tools/prof_final.py $E 0 > $O/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_lml_w -- python3 tools/prof_final.py $E 0 > $O/pmc4.log 2>&1
+echo "== full-rank factor (config 5 frame shape) under rocprofv3 --kernel-trace --stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/eig_trace -- python3 tools/prof_matern_factor.py 1024 1 3 > $O/eig.log 2>&1
+python3 tools/prof_matern_factor.py 1024 8 3 >> $O/eig.log 2>&1
 echo "== summaries"
 mkdir -p gpurun_out/profiles_new
 python3 tools/make_traffic_profile.py $E 500 > $O/traffic.log
-cp profiles/r01_pmc_traffic.json gpurun_out/profiles_new/
-grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('gpurun_out/profiles_new/r01_bench_n1.json','w'), indent=1)"
-cp $(ls $O/bench_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r01_bench_kernel_stats.csv
-cp $(ls $O/stage_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r01_stage_kernel_stats.csv
+cp profiles/r02_pmc_traffic.json gpurun_out/profiles_new/
+grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('gpurun_out/profiles_new/r02_bench_n1.json','w'), indent=1)"
+cp $(ls $O/bench_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r02_bench_kernel_stats.csv
+cp $(ls $O/stage_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r02_stage_kernel_stats.csv
+cp $(ls $O/eig_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r02_matern_factor_kernel_stats.csv
+python3 tools/trace_gaps.py $O/eig_trace > gpurun_out/profiles_new/r02_matern_factor_launches.txt
+grep "^N=" $O/eig.log >> gpurun_out/profiles_new/r02_matern_factor_launches.txt
 DOM=$(grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel'])")
 echo "dominant kernel: $DOM"
 if [ "$DOM" = "k_lml" ]; then
   NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//4)")
-  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r01_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
+  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r02_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
 else
-  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/r01_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
+  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/r02_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
 fi
-rm -rf $O/bench_trace $O/stage_trace $O/lml_trace gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
+rm -rf $O/bench_trace $O/stage_trace $O/lml_trace $O/eig_trace gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 ls -la gpurun_out/profiles_new
