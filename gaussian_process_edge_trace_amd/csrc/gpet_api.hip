@@ -78,6 +78,7 @@ struct gpet_batch {
   int* lb_count = nullptr;
   unsigned int* lb_seeds = nullptr;
   int lb_scratch_stride = 0;
+  std::vector<hipEvent_t> lb_events;  // pairs around every objective launch of a converged fit (gpet_lml_stats)
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
@@ -194,8 +195,8 @@ int gpet_set_option(const char* name, int value) {
   if (name && strcmp(name, "rng_lookahead") == 0) {
     int& v = gpet_opt_rng_lookahead();
     const int old = v;
-    v = value < 0 ? 0 : (value > 15 ? 15 : value);
-    return old;
+    v = value < 0 ? -1 : (value > 15 ? 15 : value);
+    return old < 0 ? 16 : old;  // (16 = "chosen by batch size")
   }
   if (name && strcmp(name, "scalar_jacobi") == 0) {
     int& v = gpet_opt_scalar_jacobi();
@@ -643,6 +644,7 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_f) (void)hipFree(b->d_f);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->lb_mem) (void)hipFree(b->lb_mem);
+  for (hipEvent_t ev : b->lb_events) (void)hipEventDestroy(ev);
   delete b;
 }
 
@@ -1217,32 +1219,50 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
     }
   }
   hipStream_t st = b->fit;
-  if (!b->ev_l0) {
-    HIPCHK(c, hipEventCreate(&b->ev_l0));
-    HIPCHK(c, hipEventCreate(&b->ev_l1));
-  }
   HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
   HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride));
   HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0]));
-  int n_active = P, cur = 0, rounds = 0;
-  while (n_active > 0) {
-    if (rounds >= 4000) return fail(c, GPET_ERR_ITER_CAP, "converged fit: %d problems still running after %d rounds", n_active, rounds);
-    HIPCHK(c, hipMemsetAsync(b->lb_count, 0, sizeof(int), st));
-    HIPCHK(c, hipEventRecord(b->ev_l0, st));
-    HIPCHK(c, launch_lml(st, b->d_edges, n_active, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g));
-    HIPCHK(c, hipEventRecord(b->ev_l1, st));
-    HIPCHK(c, launch_lb_advance(st, b->lb_probs, n_active, b->lb_slot_src[cur], b->lb_f, b->lb_g, b->lb_count,
+  // Rounds.  The number of running problems lives on the device (lb_count[round & 1]); the host reads it only every
+  // LB_CHECK rounds and sizes the launches by its last known value in between -- workgroups beyond the true count
+  // evaluate stale (valid) slots, threads of the advance kernel beyond it return.  A round costs the GPU ~80 us for one
+  // edge; a host round trip per round would double that.
+  constexpr int LB_CHECK = 4;
+  int h_count[2] = {P, 0};
+  HIPCHK(c, hipMemcpyAsync(b->lb_count, h_count, sizeof h_count, hipMemcpyHostToDevice, st));
+  int n_upper = P, cur = 0, rounds = 0;
+  size_t ev_used = 0;
+  while (n_upper > 0) {
+    if (rounds >= 4000) return fail(c, GPET_ERR_ITER_CAP, "converged fit: %d problems still running after %d rounds", n_upper, rounds);
+    int* cnt_cur = b->lb_count + (rounds & 1);
+    int* cnt_next = b->lb_count + ((rounds + 1) & 1);
+    HIPCHK(c, hipMemsetAsync(cnt_next, 0, sizeof(int), st));
+    if (b->lb_events.size() < ev_used + 2) {
+      hipEvent_t e0, e1;
+      HIPCHK(c, hipEventCreate(&e0));
+      b->lb_events.push_back(e0);
+      HIPCHK(c, hipEventCreate(&e1));
+      b->lb_events.push_back(e1);
+    }
+    HIPCHK(c, hipEventRecord(b->lb_events[ev_used], st));
+    HIPCHK(c, launch_lml(st, b->d_edges, n_upper, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g));
+    HIPCHK(c, hipEventRecord(b->lb_events[ev_used + 1], st));
+    ev_used += 2;
+    HIPCHK(c, launch_lb_advance(st, b->lb_probs, n_upper, cnt_cur, b->lb_slot_src[cur], b->lb_f, b->lb_g, cnt_next,
                                 b->lb_slot_edge[1 - cur], b->lb_slot_theta[1 - cur], b->lb_slot_src[1 - cur]));
-    int h_count = 0;
-    HIPCHK(c, hipMemcpyAsync(&h_count, b->lb_count, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->ev_l0, b->ev_l1) == hipSuccess) b->lml_ms += (double)ms;
-    b->lml_evals += n_active;
+    b->lml_evals += n_upper;
     b->lml_launches += 1;
-    n_active = h_count;
     cur ^= 1;
     rounds += 1;
+    if (rounds % LB_CHECK == 0) {
+      int h_next = 0;
+      HIPCHK(c, hipMemcpyAsync(&h_next, cnt_next, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+      n_upper = h_next;
+    }
+  }
+  for (size_t q = 0; q + 1 < ev_used; q += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->lb_events[q], b->lb_events[q + 1]) == hipSuccess) b->lml_ms += (double)ms;
   }
   HIPCHK(c, launch_lb_pick(st, b->d_edges, B, b->lb_probs, b->lb_theta_out));
   HIPCHK(c, launch_final_predict(st, b->d_edges, B, b->bd));
@@ -1302,6 +1322,12 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   // that read it (one ring earlier) has completed.
   const int ring = b->bd.z_ring;
   int look = gpet_opt_rng_lookahead();
+  // Automatic (default): a batch that fills the GPU is throughput-bound in the generator, so one iteration ahead wastes
+  // the least; a small batch is LATENCY-bound in it -- a stream is sequential, one workgroup per (edge, iteration),
+  // 2.1 ms for the 500 k normals of a 500-column edge against 0.9 ms for the rest of an iteration -- so the streams of
+  // the next 8 iterations are generated side by side, by one launch, across group boundaries.
+  const bool deep = look < 0 ? (b->B <= 64) : (look > 4);
+  if (look < 0) look = deep ? 8 : 1;
   if (look > ring - 1) look = ring - 1;
   // The iterations are enqueued in groups of 8, then 4 and -- once the first edges have finished -- 2: after every
   // group the host reads the `done` flags, stops if no edge is left and otherwise launches the next group on a
@@ -1350,7 +1376,18 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     for (int it = 0; it < n_it; ++it) {
       // every kernel skips edges whose `done` flag is set, so edges that finish inside a group cost little.
       const int cur = first + it;
-      while (b->norm_issued <= cur + look && b->norm_issued < horizon) {
+      if (deep && b->norm_issued - cur <= look / 2) {
+        // small batch: the streams of the next `n` iterations in ONE launch (blockIdx.x = iteration), side by side.
+        // Their ring slots were last read by the sample GEMMs of iterations <= cur - 1 (outstanding + n <= ring).
+        const int j = b->norm_issued;
+        int n = ring - (j - cur);
+        if (n > look) n = look;
+        if (cur - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(cur - 1) % 16], 0));
+        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, n));
+        for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
+        b->norm_issued = j + n;
+      }
+      while (!deep && b->norm_issued <= cur + look && b->norm_issued < horizon) {
         const int j = b->norm_issued;
         if (look == 0) {
           if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));

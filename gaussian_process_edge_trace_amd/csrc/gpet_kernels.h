@@ -56,8 +56,9 @@ hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const uns
                               double* d_scratch, int scratch_stride);
 hipError_t launch_lb_init(hipStream_t st, void* d_probs, int P, const double* d_starts, int* slot_edge, double* slot_theta,
                           int* slot_src);
-hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_active, const int* slot_src, const double* d_f,
-                             const double* d_g, int* next_count, int* next_edge, double* next_theta, int* next_src);
+hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_upper, const int* cur_count, const int* slot_src,
+                             const double* d_f, const double* d_g, int* next_count, int* next_edge, double* next_theta,
+                             int* next_src);
 hipError_t launch_lb_pick(hipStream_t st, EdgeDev* d_edges, int B, const void* d_probs, double* d_theta_out);
 
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,

@@ -3446,7 +3446,7 @@ int& gpet_opt_lml_two_tiles_from() {
 }
 
 int& gpet_opt_rng_lookahead() {
-  static int v = getenv("GPET_RNG_LOOKAHEAD") != nullptr ? atoi(getenv("GPET_RNG_LOOKAHEAD")) : 1;
+  static int v = getenv("GPET_RNG_LOOKAHEAD") != nullptr ? atoi(getenv("GPET_RNG_LOOKAHEAD")) : -1;  // -1: by batch size
   return v;
 }
 

@@ -696,12 +696,14 @@ __global__ void __launch_bounds__(256) k_lb_init(LbProb* probs, int P, const dou
 }
 
 // slot k of the round just evaluated -> its problem advances; problems still running claim a slot of the next round
-__global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, int n_active, const int* slot_src, const double* f,
+__global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, const int* cur_count, const int* slot_src, const double* f,
                                                    const double* g, int* next_count, int* next_edge, double* next_theta,
                                                    int* next_src) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_active) return;
+  // the launch is sized by the host's last KNOWN count (it reads the counter only every few rounds); the true number of
+  // running problems is on the device
+  if (k >= *cur_count) return;
   const int pid = slot_src[k];
   LbProb p = probs[pid];
   double lo[3], hi[3];
@@ -757,10 +759,11 @@ hipError_t launch_lb_init(hipStream_t st, void* d_probs, int P, const double* d_
   return hipGetLastError();
 }
 
-hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_active, const int* slot_src, const double* d_f,
-                             const double* d_g, int* next_count, int* next_edge, double* next_theta, int* next_src) {
+hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_upper, const int* cur_count, const int* slot_src,
+                             const double* d_f, const double* d_g, int* next_count, int* next_edge, double* next_theta,
+                             int* next_src) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(k_lb_advance, dim3((n_active + 63) / 64), dim3(64), 0, st, (LbProb*)d_probs, n_active, slot_src, d_f,
+  hipLaunchKernelGGL(k_lb_advance, dim3((n_upper + 63) / 64), dim3(64), 0, st, (LbProb*)d_probs, cur_count, slot_src, d_f,
                      d_g, next_count, next_edge, next_theta, next_src);
   return hipGetLastError();
 }

@@ -128,9 +128,10 @@ int gpet_abi_version(void);
  * factor); kept as an independent cross-check.  name = "oj_tol_exp" (default 8) / "oj_max_sweeps" (default 16): the
  * default solver stops after a sweep in which every pair of rows it met was orthogonal to 10^-x relative, or after
  * that many sweeps.  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
- * run ahead of it (default 1; 0: it starts when the previous iteration's pixel selection is done, so nothing is drawn for
- * finished edges, but it then delays the start of every iteration; larger n only adds draws for edges that finish
- * meanwhile; results are identical).  name = "lml_two_tiles_from": launches of gpet_lml_batch with at least this many
+ * run ahead of it (default -1 = by batch size: 8 for batches of up to 64 edges, whose loop is bound by the latency of
+ * one sequential stream per edge and iteration, 1 for larger ones, which are bound by the generator's throughput; 0: it
+ * starts when the previous iteration's pixel selection is done, so nothing is drawn for finished edges, but it then
+ * delays the start of every iteration; larger n only adds draws for edges that finish meanwhile; results are identical).  name = "lml_two_tiles_from": launches of gpet_lml_batch with at least this many
  * problems use the two-tiles-per-thread objective kernel also below 129 training points (default 600; same pivots and
  * element updates, the final sums are added in a different order).  Returns the previous value, or -1 for an unknown name. */
 int gpet_set_option(const char* name, int value);

@@ -238,10 +238,9 @@ def test_lml_objective_every_size_class(amd, ctx, two_tiles_from):
 
 
 def test_converged_fit_on_device_beyond_128_points(amd, ctx):
-    """The converged fit of an edge with 129..250 observations runs in lock step on the device objective and
-    lands on the optimum of the host-side objective (scipy L-BFGS-B on the oracle's function)."""
+    """The converged fit of an edge with 129..250 observations (two objective tiles per thread) on the device lands on
+    the optimum of the oracle's converged fit (scipy L-BFGS-B on the oracle's NumPy objective)."""
     from gaussian_process_edge_trace_amd.gpet import device_final_fits
-    from gaussian_process_edge_trace_amd._final_fit import converged_fit_predict
     grad, truth = _image(320, 5)
     init = truth[[0, -1], :][:, [1, 0]]
     kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 12}, noise_y=1, N_samples=200,
@@ -253,8 +252,9 @@ def test_converged_fit_on_device_beyond_128_points(amd, ctx):
     assert 128 < obs.shape[0] + 2 <= 250
     fits, _ = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [7])
     mean, std, theta = fits[0]
-    m_h, s_h, th_h = converged_fit_predict(tr.init, obs, tr.x_grid, tr.kernel_type, tr.kernel_nu, tr.noise_y,
-                                           tr.fix_endpoints, tr.seed + 7)
+    p = dict(fix_endpoints=tr.fix_endpoints, x_grid=tr.x_grid, kernel_type=tr.kernel_type, nu=tr.kernel_nu, noise_y=tr.noise_y)
+    m_h, s_h, info_h = orc.converged_fit_predict(tr.init, obs, p, tr.seed + 7)
+    th_h = info_h["theta"]
     np.testing.assert_allclose(theta[:2], th_h[:2], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(np.exp(theta[2]), np.exp(th_h[2]), rtol=1e-3, atol=1e-9)
     np.testing.assert_allclose(mean, m_h, rtol=1e-5, atol=1e-4)

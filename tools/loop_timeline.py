@@ -17,7 +17,7 @@ def run():
     img, truth = bench.synth_image(500, 3)
     init = truth[[0, -1], :][:, [1, 0]]
     grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
-    E = 256
+    E = int(os.environ.get("GPET_TL_EDGES", "256"))
     tr = pkg.GP_Edge_Tracing_Batch([init] * E, grad, [1 + e for e in range(E)], **bench.README_KW, _ctx=ctx)
     for _ in range(3):
         tr.reset()
