@@ -78,7 +78,12 @@ struct gpet_batch {
   int* lb_count = nullptr;
   unsigned int* lb_seeds = nullptr;
   int lb_scratch_stride = 0;
-  std::vector<hipEvent_t> lb_events;  // pairs around every objective launch of a converged fit (gpet_lml_stats)
+  std::vector<hipEvent_t> lb_events;
+  // objective for more than 250 training points (launch_lml_big): virtual-edge table + per-problem scratch
+  char* big_mem = nullptr;
+  int big_chunk = 0, big_ncap = 0;
+  void *big_vedges = nullptr, *big_vsc = nullptr;
+  double *big_scratch = nullptr, *big_part = nullptr;  // pairs around every objective launch of a converged fit (gpet_lml_stats)
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
@@ -180,6 +185,8 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
 }  // namespace
 
 static int fetch_all_scalars(gpet_batch* b);
+static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                          double* d_f, double* d_g);
 
 extern "C" {
 
@@ -644,6 +651,7 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_f) (void)hipFree(b->d_f);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->lb_mem) (void)hipFree(b->lb_mem);
+  if (b->big_mem) (void)hipFree(b->big_mem);
   for (hipEvent_t ev : b->lb_events) (void)hipEventDestroy(ev);
   delete b;
 }
@@ -1044,7 +1052,6 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
   if (n > E.n_cap) return fail(c, GPET_ERR_BAD_ARG, "final fit: n=%d exceeds n_cap=%d", n, E.n_cap);
-  if (n > 250) return fail(c, GPET_ERR_UNSUPPORTED, "final fit on the device needs n <= 250 (got %d)", n);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(E.fin_x, xs, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(E.fin_y, ys, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
@@ -1167,7 +1174,10 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
     HIPCHK(c, hipEventCreate(&b->ev_l1));
   }
   HIPCHK(c, hipEventRecord(b->ev_l0, b->fit));
-  HIPCHK(c, launch_lml(b->fit, b->d_edges, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g));
+  {
+    int rco = eval_objective(b, b->fit, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g);
+    if (rco) return rco;
+  }
   HIPCHK(c, hipEventRecord(b->ev_l1, b->fit));
   HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, b->fit));
   HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, b->fit));
@@ -1176,6 +1186,53 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
   if (hipEventElapsedTime(&ms, b->ev_l0, b->ev_l1) == hipSuccess) b->lml_ms += (double)ms;
   b->lml_evals += P;
   b->lml_launches += 1;
+  return GPET_OK;
+}
+
+// -log marginal likelihood + gradient of P problems on stream st: the register-tile kernels up to 250 training points,
+// the blocked HBM path (virtual edges, per-problem scratch, evaluated in chunks that fit a 6 GB budget) above.
+static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                          double* d_f, double* d_g) {
+  gpet_ctx* c = b->ctx;
+  if (n_max <= 250) {
+    HIPCHK(c, launch_lml(st, b->d_edges, P, n_max, d_edge_of, d_theta, d_f, d_g));
+    return GPET_OK;
+  }
+  const int ncap_v = ((n_max + 63) / 64) * 64 + 64;
+  if (!b->big_mem || b->big_ncap < ncap_v) {
+    if (b->big_mem) {
+      HIPCHK(c, hipStreamSynchronize(st));
+      (void)hipFree(b->big_mem);
+      b->big_mem = nullptr;
+    }
+    const size_t per = lmlbig_scratch_doubles(ncap_v) * sizeof(double);
+    int chunk = (int)((6ull << 30) / per);
+    if (chunk < 1) chunk = 1;
+    if (chunk > 13 * b->B) chunk = 13 * b->B;
+    const int nt = ncap_v / 64;
+    for (int pass = 0; pass < 2; ++pass) {
+      Carver cv;
+      cv.base = pass ? b->big_mem : nullptr;
+      b->big_vedges = cv.take<EdgeDev>((size_t)chunk);
+      b->big_vsc = cv.take<gpet_scalars>((size_t)chunk);
+      b->big_part = cv.take<double>((size_t)chunk * nt * nt * 3);
+      b->big_scratch = cv.take<double>((size_t)chunk * lmlbig_scratch_doubles(ncap_v));
+      if (!pass) {
+        hipError_t he = hipMalloc(&b->big_mem, cv.off + 256);
+        if (he != hipSuccess) {
+          b->big_mem = nullptr;
+          return fail(c, GPET_ERR_HIP, "converged fit with %d training points: hipMalloc(%zu bytes) failed: %s", n_max, cv.off + 256, hipGetErrorString(he));
+        }
+      }
+    }
+    b->big_chunk = chunk;
+    b->big_ncap = ncap_v;
+  }
+  for (int p0 = 0; p0 < P; p0 += b->big_chunk) {
+    const int pc = (P - p0) < b->big_chunk ? (P - p0) : b->big_chunk;
+    HIPCHK(c, launch_lml_big(st, b->d_edges, pc, n_max, d_edge_of + p0, d_theta + 3 * (size_t)p0, d_f + p0, d_g + 3 * (size_t)p0,
+                             b->big_vedges, b->big_vsc, b->big_scratch, b->big_part, b->big_ncap));
+  }
   return GPET_OK;
 }
 
@@ -1190,8 +1247,6 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
   int n_max = 0;
   for (int e = 0; e < B; ++e) {
     const int n = b->h_edges[e].n_init + b->h_scalars[e].n_obs;
-    if (n > 250)
-      return fail(c, GPET_ERR_UNSUPPORTED, "converged fit: edge %d has %d training points; the objective kernels take <= 250", e, n);
     if (n > b->h_edges[e].n_cap) return fail(c, GPET_ERR_BAD_ARG, "converged fit: edge %d n=%d exceeds n_cap", e, n);
     b->h_edges[e].fin_n = n;
     if (n > n_max) n_max = n;
@@ -1244,7 +1299,10 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
       b->lb_events.push_back(e1);
     }
     HIPCHK(c, hipEventRecord(b->lb_events[ev_used], st));
-    HIPCHK(c, launch_lml(st, b->d_edges, n_upper, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g));
+    {
+      int rco = eval_objective(b, st, n_upper, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g);
+      if (rco) return rco;
+    }
     HIPCHK(c, hipEventRecord(b->lb_events[ev_used + 1], st));
     ev_used += 2;
     HIPCHK(c, launch_lb_advance(st, b->lb_probs, n_upper, cnt_cur, b->lb_slot_src[cur], b->lb_f, b->lb_g, cnt_next,

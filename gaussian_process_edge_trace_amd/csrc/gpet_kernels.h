@@ -61,6 +61,11 @@ hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_upper, const i
                              int* next_src);
 hipError_t launch_lb_pick(hipStream_t st, EdgeDev* d_edges, int B, const void* d_probs, double* d_theta_out);
 
+// objective for more than 250 training points: blocked HBM kernels over a scratch table of virtual edges
+size_t lmlbig_scratch_doubles(int ncap_v);
+hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                          double* d_f, double* d_g, void* d_vedges, void* d_vsc, double* d_scratch, double* d_part,
+                          int ncap_v);
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
                       double* d_f, double* d_g);
 

@@ -3294,6 +3294,192 @@ hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const 
 }
 
 // ---------------------------------------------------------------------------------------
+// f2 for MORE than 250 training points (wide edges with a small delta_x): the objective of one L-BFGS-B problem is
+// evaluated with the blocked HBM kernels of the many-point fit -- every problem becomes a VIRTUAL edge of a scratch
+// table (training set = the edge's standardised set, K / L / alpha / L^-1 in per-problem scratch, amplitude, length
+// scale and noise level = the problem's theta):
+//   K tiles -> blocked Cholesky (MFMA SYRK) -> alpha -> X = L^-1 (blocked substitution on the identity) ->
+//   tiles of K^-1 = X^T X on the matrix cores, contracted on the fly with dK/dtheta (k_lmlbig_grad) -> f, g.
+// ~2.5 n^3 flops per evaluation instead of n^3, ~100 launches per round: a rare path, kept simple.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_lmlbig_setup(EdgeDev* edges, int P, const int* edge_of, const double* theta,
+                                                     EdgeDev* vedges, gpet_scalars* vsc, double* scratch, size_t per_prob,
+                                                     int ncap_v) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const EdgeDev E = edges[edge_of[p]];
+  EdgeDev V = E;
+  const double c = exp(theta[3 * p]), l = exp(theta[3 * p + 1]), nl = exp(theta[3 * p + 2]);
+  double* base = scratch + (size_t)p * per_prob;
+  V.xt = E.fin_x;
+  V.yt = E.fin_y;
+  V.wt = E.fin_w;
+  V.K = base;
+  V.V = base + (size_t)ncap_v * ncap_v;
+  V.alpha = V.V + (size_t)ncap_v * ncap_v;
+  V.n_cap = ncap_v;
+  V.Lg = ncap_v;  // column count / stride of V in the blocked substitution; != n, so the weights are not zeroed again
+  V.length_scale = l;
+  V.noise_y = nl;
+  V.jitter = 1e-6;
+  V.structured = 0;
+  V.sc = vsc + p;
+  gpet_scalars s;
+  s.y_s = 1.0;
+  s.amp = c;
+  s.y_mean = 0.0;
+  s.y_std = 1.0;
+  s.score_thresh = 0.0;
+  s.lml = 0.0;
+  s.n = E.fin_n;
+  s.n_obs = 0;
+  s.rank = 0;
+  s.status = GPET_OK;
+  s.iter = 0;
+  s.done = 0;
+  s.n_removed = 0;
+  s.force = 1;
+  vsc[p] = s;
+  vedges[p] = V;
+}
+
+__global__ void __launch_bounds__(256) k_lmlbig_identity(EdgeDev* vedges) {
+  const EdgeDev E = vedges[blockIdx.y];
+  const int n = E.sc->n, ldu = E.Lg;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)n * ldu; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / ldu), j = (int)(e - (size_t)i * ldu);
+    E.V[e] = (i == j) ? 1.0 : 0.0;
+  }
+}
+
+// tile (bi >= bj) of K^-1 = X^T X, X = L^-1 rows in V, contracted with the three dK/dtheta: partial sums per tile
+__global__ void __launch_bounds__(256) k_lmlbig_grad(EdgeDev* vedges, double* part, int nt) {
+  const EdgeDev E = vedges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  double* out = part + ((size_t)blockIdx.z * nt * nt + (size_t)bi * nt + bj) * 3;
+  const int tid = threadIdx.x;
+  if (tid < 3) out[tid] = 0.0;
+  if (sc->status != GPET_OK || bj > bi) return;
+  const int n = sc->n, ldu = E.Lg;
+  const int i0 = bi * 64, j0 = bj * 64;
+  if (i0 >= n) return;
+  __shared__ double sr[32][65];
+  __shared__ double sc_[32][65];
+  __shared__ double s_red[16];
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  // X is lower triangular: rows k < i0 contribute nothing to columns >= i0
+  for (int k0 = (i0 / 32) * 32; k0 < n; k0 += 32) {
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int jj = e & 63, kk = e >> 6;
+      const int k = k0 + kk;
+      sr[kk][jj] = (k < n && i0 + jj < n) ? E.V[(size_t)k * ldu + i0 + jj] : 0.0;
+      sc_[kk][jj] = (k < n && j0 + jj < n) ? E.V[(size_t)k * ldu + j0 + jj] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+      const double a = sr[kk + lq][16 * w + li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sc_[kk + lq][16 * t + li], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const double c = sc->amp, length = E.length_scale, nl = E.noise_y;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + 16 * t + li;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = i0 + 16 * w + lq + 4 * g;
+      if (i >= n || j > i) continue;
+      const double inner = E.alpha[i] * E.alpha[j] - acc[t][g];
+      if (i == j) {
+        s1 += inner * c;            // d K / d log c on the diagonal: c * 1
+        s3 += inner * nl * E.wt[i]; // d K / d log noise_level
+      } else {
+        double R, dR;
+        corr_and_dlog(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length, R, dR);
+        s1 += 2.0 * inner * (c * R);
+        s2 += 2.0 * inner * (c * dR);
+      }
+    }
+  }
+  s1 = block_sum(s1, s_red);
+  s2 = block_sum(s2, s_red);
+  s3 = block_sum(s3, s_red);
+  if (tid == 0) {
+    out[0] = s1;
+    out[1] = s2;
+    out[2] = s3;
+  }
+}
+
+// f = -log marginal likelihood, g = its gradient (sklearn_gpr.py:521-585); non-PD -> +inf, 0
+__global__ void __launch_bounds__(256) k_lmlbig_finish(EdgeDev* vedges, const double* part, int nt, double* f_out, double* g_out) {
+  const int p = blockIdx.x;
+  const EdgeDev E = vedges[p];
+  const gpet_scalars* sc = E.sc;
+  __shared__ double s_red[16];
+  const int tid = threadIdx.x, n = sc->n, ld = E.n_cap;
+  if (sc->status != GPET_OK) {
+    if (tid == 0) {
+      f_out[p] = INFINITY;
+      g_out[3 * p] = g_out[3 * p + 1] = g_out[3 * p + 2] = 0.0;
+    }
+    return;
+  }
+  double ya = 0.0, ld_ = 0.0;
+  for (int i = tid; i < n; i += blockDim.x) {
+    ya += E.yt[i] * E.alpha[i];
+    ld_ += log(E.K[(size_t)i * ld + i]);
+  }
+  ya = block_sum(ya, s_red);
+  ld_ = block_sum(ld_, s_red);
+  if (tid == 0) {
+    double s[3] = {0.0, 0.0, 0.0};
+    const double* pp = part + (size_t)p * nt * nt * 3;
+    for (int t = 0; t < nt * nt; ++t)  // fixed order: reproducible sums
+      for (int q = 0; q < 3; ++q) s[q] += pp[3 * t + q];
+    f_out[p] = 0.5 * ya + ld_ + 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    for (int q = 0; q < 3; ++q) g_out[3 * p + q] = -0.5 * s[q];
+  }
+}
+
+size_t lmlbig_scratch_doubles(int ncap_v) { return 2 * (size_t)ncap_v * ncap_v + ncap_v; }
+
+hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
+                          double* d_f, double* d_g, void* d_vedges, void* d_vsc, double* d_scratch, double* d_part,
+                          int ncap_v) {
+  (void)hipGetLastError();
+  EdgeDev* ve = (EdgeDev*)d_vedges;
+  const int nt = ncap_v / CB;
+  hipLaunchKernelGGL(k_lmlbig_setup, dim3(cdiv(P, 64)), dim3(64), 0, st, d_edges, P, d_edge_of, d_theta, ve,
+                     (gpet_scalars*)d_vsc, d_scratch, lmlbig_scratch_doubles(ncap_v), ncap_v);
+  const int ntn = cdiv(n_max, CB);  // tiles that can hold training points
+  hipLaunchKernelGGL(k_fit_kbuild, dim3(ntn, ntn, P), dim3(256), 0, st, ve);
+  for (int k0 = 0; k0 < n_max; k0 += CB) {
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, P), dim3(256), 0, st, ve, k0);
+    const int below = cdiv(n_max - k0 - CB, CB);
+    if (below > 0) {
+      hipLaunchKernelGGL(k_chol_trsm, dim3(below, P), dim3(256), 0, st, ve, k0);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, P), dim3(256), 0, st, ve, k0);
+    }
+  }
+  hipLaunchKernelGGL(k_chol_solve, dim3(1, P), dim3(256), (size_t)ncap_v * sizeof(double), st, ve);
+  hipLaunchKernelGGL(k_lmlbig_identity, dim3(256, P), dim3(256), 0, st, ve);
+  const int cgroups = cdiv(n_max, SB_COLS);
+  for (int k0 = 0; k0 < n_max; k0 += CB) hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, P), dim3(256), 0, st, ve, k0, 1);
+  hipLaunchKernelGGL(k_lmlbig_grad, dim3(nt, nt, P), dim3(256), 0, st, ve, d_part, nt);
+  hipLaunchKernelGGL(k_lmlbig_finish, dim3(P), dim3(256), 0, st, ve, d_part, nt, d_f, d_g);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 

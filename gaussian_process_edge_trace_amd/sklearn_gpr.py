@@ -168,8 +168,6 @@ class GaussianProcessRegressor(object):
         [and its gradient] (sklearn_gpr.py:475-585), evaluated by the batched objective kernel of the converged fits;
         theta=None: at the kernel's own hyper-parameters."""
         f = self._fit
-        if len(f["x"]) > 250:
-            raise NotImplementedError("more than 250 training points")
         if theta is None:
             theta = np.log([f["const"], f["ell"], 1.0])
         b, _, _ = self._device_fit_predict(np.arange(4.0))

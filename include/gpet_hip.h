@@ -230,7 +230,8 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
 
 /* ---- f2: converged fit (gpet.py:232-248; sklearn_gpr.py:254-295, 475-585) ----------------- */
 /* Upload edge e's standardised training set (x, y standardised as gpet.py:235-238 and
- * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= 250 (one 4x4 tile per thread up to 128 points, two beyond). */
+ * sklearn_gpr.py:229-234 do; w = per-point noise weights), n <= the batch's training-set capacity (register-tile objective
+ * kernels up to 250 points; above, the blocked HBM path: Cholesky, L^-1 and K^-1 tiles on the matrix cores). */
 int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n);
 /* The same for every edge of the batch in one call: xs/ys/w are [B*stride], n [B]. */
 int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* ys, const double* w, const int32_t* n,
@@ -258,7 +259,8 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
  * (scipy.optimize.minimize's algorithm and defaults) for all 13 B problems in lock step, one batched objective launch
  * per round; best restart; posterior at the optimum.  mean_out (pixels) and std_out (standardised units, as the
  * reference returns it) are [B*stride]; theta_out (optional) [B*4] = log(constant, length_scale, noise_level) and the
- * minimum of -log marginal likelihood; rounds_out (optional) = objective launches.  At most 250 training points. */
+ * minimum of -log marginal likelihood; rounds_out (optional) = objective rounds.  Any number of training points the
+ * batch was created for (more than 250: the blocked objective, ~100 launches per round -- a rare, slower path). */
 int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
                        int stride, int32_t* rounds_out);
 

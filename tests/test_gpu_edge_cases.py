@@ -351,3 +351,66 @@ def test_batch_with_edges_of_different_length(amd, ctx):
     for e, (init, seed) in enumerate(zip(inits, seeds)):
         single = amd.GP_Edge_Tracing(init, grad, seed=seed, **kw, _ctx=ctx)()
         assert out[e].shape == single.shape and np.array_equal(out[e], single), "edge %d" % e
+
+
+@pytest.mark.parametrize("kernel,nu,n", [("RBF", 2.5, 251), ("Matern", 2.5, 400), ("Matern", 1.5, 700)])
+def test_lml_objective_beyond_250_points_blocked_path(amd, ctx, kernel, nu, n):
+    """More than 250 training points (wide edge, delta_x = 2): the objective runs on the blocked HBM path -- virtual
+    edges, blocked Cholesky, L^-1, tiles of K^-1 on the matrix cores contracted with dK/dtheta -- vs the oracle."""
+    from gaussian_process_edge_trace_amd import _final_fit as ff
+    N = 2 * n + 8
+    grad, truth = _image(N, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    ko = {'kernel': kernel, 'sigma_f': 40, 'length_scale': 12}
+    if kernel == "Matern":
+        ko['nu'] = nu
+    tr = amd.GP_Edge_Tracing(init, grad, kernel_options=ko, noise_y=1, N_samples=64, score_thresh=1, delta_x=2,
+                             keep_ratio=0.1, pixel_thresh=20, seed=4, fix_endpoints=True, _ctx=ctx)
+    rng = np.random.default_rng(n)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=n - 2, replace=False))
+    obs = np.stack([cols, np.clip(truth[cols, 0] + rng.integers(-3, 4, size=n - 2), 0, N - 1)], axis=1)
+    pr = ff.prepare(tr.init, obs, tr.x_grid, tr.fix_endpoints)
+    assert pr["xs"].shape[0] == n
+    b = tr._batch
+    b.final_set_training(0, pr["xs"], pr["yt"], pr["w"])
+    th = ff.BOUNDS[:, 0] + (ff.BOUNDS[:, 1] - ff.BOUNDS[:, 0]) * rng.uniform(size=(8, 3))
+    th[:, 2] = np.log(rng.uniform(1e-3, 1.0, size=8))
+    th[0] = np.log([5.0, 5.0, 1.0])
+    th[1] = np.log([10.0, 50.0, 1e-10])   # near-singular K
+    f, gr = b.lml_batch(np.zeros(8, dtype=np.int32), th)
+    finite = 0
+    for i in range(8):
+        lml, g_o = orc.lml_and_grad(th[i], pr["xs"], pr["yt"], pr["w"], tr.kernel_type, tr.kernel_nu)
+        if not np.isfinite(lml):
+            assert np.isinf(f[i]) and f[i] > 0
+            continue
+        if not np.isfinite(f[i]):
+            assert th[i, 2] < np.log(1e-6)
+            continue
+        finite += 1
+        np.testing.assert_allclose(f[i], -lml, rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gr[i], -g_o, rtol=1e-5, atol=1e-5 * (1 + np.abs(g_o).max()))
+    assert finite >= 6
+
+
+def test_converged_fit_beyond_250_points(amd, ctx):
+    """A trace that ends with 300 observations (608-column edge, delta_x = 2): the converged fit runs on the device --
+    blocked objective -- and lands on the oracle's optimum; before round 2 this was a host NumPy path."""
+    from gaussian_process_edge_trace_amd.gpet import device_final_fits
+    N = 608
+    grad, truth = _image(N, 5)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 60, 'length_scale': 18}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=2, keep_ratio=0.1, pixel_thresh=20, seed=4, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    rng = np.random.default_rng(2)
+    cols = np.arange(3, N - 3, 2)[:300]
+    obs = np.stack([cols, np.clip(truth[cols, 0] + rng.integers(-2, 3, size=cols.size), 0, N - 1)], axis=1)
+    assert obs.shape[0] + 2 > 250
+    fits, rounds = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [5])
+    mean, std, theta = fits[0]
+    p = dict(fix_endpoints=tr.fix_endpoints, x_grid=tr.x_grid, kernel_type=tr.kernel_type, nu=tr.kernel_nu, noise_y=tr.noise_y)
+    m_h, s_h, info_h = orc.converged_fit_predict(tr.init, obs, p, tr.seed + 5)
+    np.testing.assert_allclose(theta[:2], info_h["theta"][:2], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(mean, m_h, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(std, s_h, rtol=1e-4, atol=1e-6)
