@@ -121,6 +121,7 @@ int nu_to_code(double nu) {
   if (nu == 0.5) return 0;
   if (nu == 1.5) return 1;
   if (nu == 2.5) return 2;
+  if (nu > 0.0 && nu <= 1e6) return 3;  // any other smoothness: Bessel form by quadrature (gpet.py:134)
   return -1;
 }
 
@@ -150,6 +151,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.lam0 = cv.take<double>(rc);
   E.beta = cv.take<double>(rc);
   E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
+  E.rho_tab = cv.take<double>((size_t)E.N);
   E.eig = cv.take<EigState>(1);
   E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);
   E.pcx_d = cv.take<double>(Lg);
@@ -416,7 +418,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   BatchDims bd{};
   bd.M = M;
   bd.N = N;
-  bool any_big = false;
+  bool any_big = false, any_gen_nu = false;
   for (int e = 0; e < B; ++e) {
     const int Lg_e = params[e].x_en - params[e].x_st + 1;
     const int cap = params[e].factor_cap > 0 ? params[e].factor_cap : 96;
@@ -431,7 +433,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
         p.n_keep > p.n_samples || p.delta_x < 1 || p.length_scale <= 0)
       return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_create: edge %d has inconsistent parameters", e);
     if (p.kernel_type == GPET_KERNEL_MATERN && nu_to_code(p.nu) < 0)
-      return fail(c, GPET_ERR_UNSUPPORTED, "Matern nu=%g not supported (0.5, 1.5, 2.5 only)", p.nu);
+      return fail(c, GPET_ERR_UNSUPPORTED, "Matern nu=%g is not a positive finite smoothness", p.nu);
     E.M = M;
     E.N = N;
     E.x_st = p.x_st;
@@ -459,6 +461,10 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : 16;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
+    E.nu_gen = p.nu;
+    E.inv_gamma_nu = (E.nu_code == 3) ? 1.0 / tgamma(p.nu) : 1.0;
+    E.tab_ok = 1;
+    if (E.nu_code == 3) any_gen_nu = true;
     E.fix_endpoints = p.fix_endpoints;
     E.delta_x = p.delta_x;
     E.pixel_thresh = p.pixel_thresh;
@@ -561,6 +567,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
+  if (any_gen_nu) HIPCHK(c, launch_rho_tab(c->stream, b->d_edges, B, N));
   // gradient KDE of every distinct image (gpet.py:127)
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : B, b->bd, 1));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -19,7 +19,10 @@ struct EigState {
 struct EdgeDev {
   // geometry / clamped ctor parameters (gpet.py:95-158)
   int M, N, x_st, x_en, Lg, S, n_keep, z_cols, r_cap, n_cap, obs_cap, n_init;
-  int kernel_type, nu_code;  // nu_code: 0 -> 0.5, 1 -> 1.5, 2 -> 2.5
+  int kernel_type, nu_code;  // nu_code: 0 -> 0.5, 1 -> 1.5, 2 -> 2.5, 3 -> any other nu > 0 (nu_gen; Bessel form by quadrature)
+  double nu_gen, inv_gamma_nu;  // general Matern smoothness and 1 / Gamma(nu)
+  double* rho_tab;              // [N] general nu: correlation at the integer lags of the pixel grid for this edge's length scale
+  int tab_ok, pad_tab;          // 1: coordinates are pixels and the length scale is the constructor's: rho_tab applies
   int fix_endpoints, delta_x, pixel_thresh, algo_thresh, n_bins, a_rows_cap;
   int factor_injected, z_ring;  // z_ring: slots of pre-generated normals (one per upcoming iteration)
   double sigma_f, length_scale, noise_y, jitter;

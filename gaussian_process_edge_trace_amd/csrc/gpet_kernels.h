@@ -45,6 +45,7 @@ int& gpet_opt_rng_lookahead();
 // the two-tiles-per-thread kernel also below 129 training points (fewer instructions per problem, longer latency)
 int& gpet_opt_lml_two_tiles_from();
 hipError_t launch_set_force(hipStream_t st, EdgeDev* d_edges, int B, int v);
+hipError_t launch_rho_tab(hipStream_t st, EdgeDev* d_edges, int B, int N);
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride);
 hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int rank_max = 0);

@@ -32,19 +32,59 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return t;
 }
 
+// General-nu Matern correlation (sklearn kernels.py Matern.__call__, the Bessel-K branch the reference reaches with
+// kernel_options = {'kernel': 'Matern', 'nu': ...}, gpet.py:134):
+//   rho(r) = 2^(1-nu) / Gamma(nu) (sqrt(2 nu) r)^nu K_nu(sqrt(2 nu) r)  =  1 / Gamma(nu) int exp(nu s - e^s - q e^-s) ds,
+// q = nu r^2 / 2  (substitute u = e^s in the Gamma-mixture-of-Gaussians form of x^nu K_nu(x)).  The integrand decays
+// doubly exponentially on both sides, so the trapezoid rule converges geometrically: absolute error <= 3e-14 against
+// scipy.special.kv for nu in [0.7, 20] with the step below (~60-400 nodes).  Also d rho / d log(length_scale)
+// = 2 q / Gamma(nu) int exp((nu - 1) s - e^s - q e^-s) ds -- analytic, where sklearn differentiates numerically.
+__device__ double matern_gen(double nu, double inv_gamma, double r, double* dlogl) {
+  const double q = 0.5 * nu * r * r;
+  double h = 0.45 * rsqrt(nu);
+  if (h > 0.2) h = 0.2;
+  const double s_hi = log(45.0 + 4.0 * nu) + 0.5;
+  double lo_a;
+  if (dlogl != nullptr && nu > 1.0) lo_a = -40.0 / fmin(nu, fmax(nu - 1.0, 0.25));
+  else lo_a = -40.0 / fmin(nu, 1.0);
+  double s_lo = lo_a;
+  if (q > 0.0) s_lo = fmax(log(q / 45.0), lo_a);
+  const int n0 = (int)floor(s_lo / h), n1 = (int)ceil(s_hi / h);
+  double sum = 0.0, dsum = 0.0;
+  for (int k = n0; k <= n1; ++k) {
+    const double sv = (double)k * h;
+    const double es = exp(sv);
+    const double w = exp(nu * sv - es - q / es);
+    sum += w;
+    dsum += w / es;
+  }
+  if (dlogl != nullptr) *dlogl = 2.0 * q * h * dsum * inv_gamma;
+  return h * sum * inv_gamma;
+}
+
 // sklearn kernels.py RBF / Matern on pre-scaled 1-D inputs a = x_i / l, b = x_j / l.
-__device__ __forceinline__ double corr_fn(int kernel_type, int nu_code, double a, double b) {
+__device__ __forceinline__ double corr_fn(const EdgeDev& E, double a, double b) {
   const double d = a - b;
   const double d2 = d * d;
-  if (kernel_type == GPET_KERNEL_RBF) return exp(-0.5 * d2);
+  if (E.kernel_type == GPET_KERNEL_RBF) return exp(-0.5 * d2);
   const double r = sqrt(d2);
-  if (nu_code == 0) return exp(-r);
-  if (nu_code == 1) {
+  if (E.nu_code == 0) return exp(-r);
+  if (E.nu_code == 1) {
     const double k = r * 1.7320508075688772;  // math.sqrt(3)
     return (1.0 + k) * exp(-k);
   }
+  if (E.nu_code == 3) return matern_gen(E.nu_gen, E.inv_gamma_nu, r, nullptr);
   const double k = r * 2.23606797749979;  // math.sqrt(5)
   return (1.0 + k + k * k / 3.0) * exp(-k);
+}
+// The same for two PIXEL coordinates of the loop (integer lags, constructor length scale): general nu reads the lag
+// table built at construction instead of integrating again.
+__device__ __forceinline__ double corr_px(const EdgeDev& E, double xi, double xj, double length) {
+  if (E.kernel_type == GPET_KERNEL_MATERN && E.nu_code == 3 && E.tab_ok) {
+    const double lag = fabs(xi - xj);
+    return E.rho_tab[(int)(lag + 0.5)];
+  }
+  return corr_fn(E, xi / length, xj / length);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -240,7 +280,7 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
       v = v + ((zero_noise && !FINAL) ? 0.0 : noise_lvl * E.wt[i]);  // (FINAL: the host already zeroed w)
       v = v + jit;
     } else {
-      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length);
+      v = amp * (FINAL ? corr_fn(E, E.xt[i] / length, E.xt[j] / length) : corr_px(E, E.xt[i], E.xt[j], length));
     }
     K[(size_t)i * ld + j] = v;
   }
@@ -435,7 +475,7 @@ __global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
       v = v + (zero_noise ? 0.0 : E.noise_y * E.wt[i]);
       v = v + E.jitter;
     } else {
-      v = amp * corr_fn(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length);
+      v = amp * corr_px(E, E.xt[i], E.xt[j], length);  // (virtual edges of the blocked objective: tab_ok = 0)
     }
     E.K[(size_t)i * ld + j] = v;
   }
@@ -675,7 +715,7 @@ __global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) 
       const double* ri = E.K + (size_t)i * ld;
       for (int t = lane; t <= i; t += 64) s_l[t] = ri[t];
       __syncthreads();
-      const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, s_x[i]);
+      const double ki = amp * ((!FINAL && E.nu_code == 3) ? corr_px(E, (double)(E.x_st + (live ? j : 0)), E.xt[i], length) : corr_fn(E, xq, s_x[i]));
       double acc = ki;
       for (int t = 0; t < i; ++t) acc -= s_l[t] * s_v[t * 64 + lane];
       const double v = acc / s_l[i];
@@ -687,7 +727,7 @@ __global__ void __launch_bounds__(64) k_predict(EdgeDev* edges, int out_stride) 
   } else {
     if (!live) return;
     for (int i = 0; i < n; ++i) {
-      const double ki = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / length);
+      const double ki = amp * ((!FINAL && E.nu_code == 3) ? corr_px(E, (double)(E.x_st + j), E.xt[i], length) : corr_fn(E, xq, E.xt[i] / length));
       const double* ri = E.K + (size_t)i * ld;
       double acc = ki;
       for (int t = 0; t < i; ++t) acc -= ri[t] * E.V[(size_t)t * Lg + j];
@@ -1149,7 +1189,7 @@ __global__ void __launch_bounds__(256) k_rho_fill(EdgeDev* edges) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < (size_t)Lg * Lg; e += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(e / Lg), j = (int)(e - (size_t)i * Lg);
     E.cov[e] = (i == j) ? 1.0
-                        : corr_fn(E.kernel_type, E.nu_code, (double)(E.x_st + i) / E.length_scale,
+                        : corr_fn(E, (double)(E.x_st + i) / E.length_scale,
                                   (double)(E.x_st + j) / E.length_scale);
   }
 }
@@ -2080,7 +2120,9 @@ __global__ void __launch_bounds__(256) k_cov_mfma(EdgeDev* edges, int final_mode
       const int r = r0 + 16 * w + lq + 4 * g;
       if (r >= Lg) continue;
       if (bx == by && c < r) continue;  // diagonal tile: the mirror write below covers it
-      const double k = (r == c) ? amp : amp * corr_fn(E.kernel_type, E.nu_code, (((double)(E.x_st + r) - xoff) / xsc) / length, xc);
+      const double k = (r == c) ? amp
+                              : amp * ((!final_mode && E.nu_code == 3) ? corr_px(E, (double)r, (double)c, length)
+                                                                        : corr_fn(E, (((double)(E.x_st + r) - xoff) / xsc) / length, xc));
       const double val = (k - acc[t][g]) * s2;
       E.cov[(size_t)r * Lg + c] = val;
       E.cov[(size_t)c * Lg + r] = val;
@@ -2905,7 +2947,8 @@ __global__ void __launch_bounds__(64) k_pix_select(EdgeDev* edges) {
 //     sklearn_gpr.py:512-585 on the standardised training set (gpet.py:235-248).
 //     One workgroup per (edge, restart) problem; L and L^-1 packed-lower in LDS (n <= 128).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, double a, double b, double& R, double& dR) {
+__device__ __forceinline__ void corr_and_dlog(const EdgeDev& E, double a, double b, double& R, double& dR) {
+  const int kernel_type = E.kernel_type, nu_code = E.nu_code;
   const double d = a - b;
   const double D = d * d;
   if (kernel_type == GPET_KERNEL_RBF) {
@@ -2917,6 +2960,8 @@ __device__ __forceinline__ void corr_and_dlog(int kernel_type, int nu_code, doub
   if (nu_code == 0) {
     R = exp(-r);
     dR = (r > 0.0) ? R * D / r : 0.0;
+  } else if (nu_code == 3) {
+    R = matern_gen(E.nu_gen, E.inv_gamma_nu, r, &dR);
   } else if (nu_code == 1) {
     const double k = r * 1.7320508075688772;
     R = (1.0 + k) * exp(-k);
@@ -2978,7 +3023,7 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
           v = c + nl * s_w[i];
           v = v + 1e-6;
         } else {
-          v = c * corr_fn(E.kernel_type, E.nu_code, s_x[i], s_x[j]);
+          v = c * corr_fn(E, s_x[i], s_x[j]);
         }
       }
       T[a][b] = v;
@@ -3075,7 +3120,7 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
             gn += inner * (nl * s_w[i]);
           } else {
             double R, dR;
-            corr_and_dlog(E.kernel_type, E.nu_code, s_x[i], s_x[j], R, dR);
+            corr_and_dlog(E, s_x[i], s_x[j], R, dR);
             gc += wt * inner * (c * R);
             gl += wt * inner * (c * dR);
           }
@@ -3148,7 +3193,7 @@ __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_o
             v = c + nl * s_w[i];
             v = v + 1e-6;
           } else {
-            v = c * corr_fn(E.kernel_type, E.nu_code, s_x[i], s_x[j]);
+            v = c * corr_fn(E, s_x[i], s_x[j]);
           }
         }
         T[s][a][b] = v;
@@ -3251,7 +3296,7 @@ __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_o
               gn += inner * (nl * s_w[i]);
             } else {
               double R, dR;
-              corr_and_dlog(E.kernel_type, E.nu_code, s_x[i], s_x[j], R, dR);
+              corr_and_dlog(E, s_x[i], s_x[j], R, dR);
               gc += wt * inner * (c * R);
               gl += wt * inner * (c * dR);
             }
@@ -3323,6 +3368,7 @@ __global__ void __launch_bounds__(64) k_lmlbig_setup(EdgeDev* edges, int P, cons
   V.noise_y = nl;
   V.jitter = 1e-6;
   V.structured = 0;
+  V.tab_ok = 0;  // standardised coordinates, the problem's own length scale
   V.sc = vsc + p;
   gpet_scalars s;
   s.y_s = 1.0;
@@ -3403,7 +3449,7 @@ __global__ void __launch_bounds__(256) k_lmlbig_grad(EdgeDev* vedges, double* pa
         s3 += inner * nl * E.wt[i]; // d K / d log noise_level
       } else {
         double R, dR;
-        corr_and_dlog(E.kernel_type, E.nu_code, E.xt[i] / length, E.xt[j] / length, R, dR);
+        corr_and_dlog(E, E.xt[i] / length, E.xt[j] / length, R, dR);
         s1 += 2.0 * inner * (c * R);
         s2 += 2.0 * inner * (c * dR);
       }
@@ -3518,7 +3564,7 @@ __global__ void __launch_bounds__(256) k_kstar_build(EdgeDev* edges) {
   if (j >= Lg) return;
   const double xq = (double)(E.x_st + j) / length;
   for (int i = blockIdx.y * 4 + (threadIdx.x >> 6); i < n; i += gridDim.y * 4)
-    E.V[(size_t)i * Lg + j] = amp * corr_fn(E.kernel_type, E.nu_code, xq, E.xt[i] / length);
+    E.V[(size_t)i * Lg + j] = amp * corr_px(E, (double)(E.x_st + j), E.xt[i], length);
 }
 // mean_j = y_std * sum_i K_*[i][j] alpha_i + y_mean   (sklearn_gpr.py:381-385; before V is overwritten)
 __global__ void __launch_bounds__(256) k_pred_mean_big(EdgeDev* edges) {
@@ -3806,6 +3852,20 @@ __global__ void __launch_bounds__(128) k_fin_scatter(EdgeDev* edges, const doubl
 hipError_t launch_fin_scatter(hipStream_t st, EdgeDev* d_edges, int B, const double* d_stage, const int* d_n, int stride) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(k_fin_scatter, dim3(B), dim3(128), 0, st, d_edges, d_stage, d_n, stride, B);
+  return hipGetLastError();
+}
+
+// general-nu Matern: correlation at the integer lags 0..N-1 of the pixel grid, once per edge at construction
+__global__ void __launch_bounds__(256) k_rho_tab(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (E.kernel_type != GPET_KERNEL_MATERN || E.nu_code != 3) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E.N) return;
+  E.rho_tab[k] = matern_gen(E.nu_gen, E.inv_gamma_nu, (double)k / E.length_scale, nullptr);
+}
+hipError_t launch_rho_tab(hipStream_t st, EdgeDev* d_edges, int B, int N) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_rho_tab, dim3(cdiv(N, 256), B), dim3(256), 0, st, d_edges);
   return hipGetLastError();
 }
 

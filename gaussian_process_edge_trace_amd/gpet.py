@@ -78,6 +78,8 @@ def to_abi_params(p, obs_cap=None, factor_cap=0, z_cols=0):
     q = _lib.GpetParams()
     q.kernel_type = _lib.KERNEL_MATERN if p["kernel_type"] == "Matern" else _lib.KERNEL_RBF
     q.nu = float(p["kernel_nu"])
+    if q.kernel_type == _lib.KERNEL_MATERN and np.isinf(q.nu):  # sklearn's Matern(nu=inf) IS the RBF kernel
+        q.kernel_type, q.nu = _lib.KERNEL_RBF, 2.5
     q.sigma_f = float(p["sigma_f"])
     q.length_scale = float(p["sigma_l"])
     q.noise_y = float(p["noise_y"])

@@ -38,7 +38,7 @@ typedef enum gpet_status {
   GPET_ERR_NOT_PD = 3,       /* Cholesky met a non-positive pivot (sklearn_gpr.py:306-314 LinAlgError) */
   GPET_ERR_ITER_CAP = 4,     /* trace did not converge within the iteration cap */
   GPET_ERR_RANK_CAP = 5,     /* posterior covariance rank exceeded the factor capacity */
-  GPET_ERR_UNSUPPORTED = 6,  /* e.g. Matern nu outside {0.5, 1.5, 2.5} */
+  GPET_ERR_UNSUPPORTED = 6,  /* e.g. a Matern nu that is not a positive finite number */
   GPET_ERR_NO_DEVICE = 7,
   GPET_ERR_STATE = 8         /* call sequence error (stage input not produced yet) */
 } gpet_status;
@@ -48,7 +48,8 @@ typedef enum gpet_kernel_type { GPET_KERNEL_RBF = 0, GPET_KERNEL_MATERN = 1 } gp
 /* Clamped constructor arguments of GP_Edge_Tracing.__init__ (gpet.py:95-158), resolved by the host. */
 typedef struct gpet_params {
   int32_t kernel_type;   /* gpet_kernel_type                  gpet.py:133,142 */
-  double nu;             /* Matern smoothness (0.5/1.5/2.5)   gpet.py:134,143 */
+  double nu;             /* Matern smoothness: 0.5 / 1.5 / 2.5 in closed form, any other nu > 0 through the
+                          * Bessel form (quadrature; lag table for the loop)      gpet.py:134,143 */
   double sigma_f;        /* amplitude                         gpet.py:131,147 */
   double length_scale;   /*                                   gpet.py:132,151 */
   double noise_y;        /*                                   gpet.py:98 */

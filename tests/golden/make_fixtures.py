@@ -185,6 +185,12 @@ if __name__ == "__main__":
                                                     delta_x=6, keep_ratio=0.1, pixel_thresh=2, seed=3,
                                                     fix_endpoints=True),
                       np.zeros((0, 2), dtype=np.int64), 4)
+    mat35 = dict(kernel_options={'kernel': 'Matern', 'nu': 3.5, 'sigma_f': 15, 'length_scale': 10}, noise_y=1, N_samples=200,
+                 score_thresh=1, delta_x=6, keep_ratio=0.1, pixel_thresh=3, seed=5, fix_endpoints=True)
+    if want("stage_mat35_96"):  # general-nu Matern: the Bessel-K branch of sklearn's kernel (gpet.py:134)
+        stage_fixture("stage_mat35_96", 96, 2, dict(mat35), np.array([[30, 50], [60, 40], [15, 52]], dtype=np.int64), 9)
+    if want("trace_mat35_96"):
+        trace_fixture("trace_mat35_96", 96, 2, dict(mat35))
     readme = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, N_samples=1000,
                   score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
     if want("stage_rbf500"):

@@ -98,8 +98,9 @@ def test_batch_of_edges_equals_single_edge_runs(amd, ctx):
 
 
 def test_error_codes_rank_cap_unsupported_nu_bad_state(amd, ctx):
-    """Error behaviour of the boundary: factor capacity exceeded -> 5; general-nu Matern
-    (needs Bessel K_nu) -> 6; stage called out of order -> 8; bad arguments -> 1.  Each leaves the context usable."""
+    """Error behaviour of the boundary: factor capacity exceeded -> 5; a Matern smoothness
+    that is not a positive finite number -> 6; stage called out of order -> 8; bad arguments -> 1.  Each leaves the
+    context usable."""
     L = amd._lib
     grad, truth = _image(64, 4)
     init = truth[[0, -1], :][:, [1, 0]]
@@ -110,7 +111,7 @@ def test_error_codes_rank_cap_unsupported_nu_bad_state(amd, ctx):
         tr()
     assert ei.value.code == L.ERR_RANK_CAP
     with pytest.raises(L.GpetError) as ei:
-        amd.GP_Edge_Tracing(init, grad, **dict(kw, kernel_options={'kernel': 'Matern', 'nu': 0.9, 'sigma_f': 10,
+        amd.GP_Edge_Tracing(init, grad, **dict(kw, kernel_options={'kernel': 'Matern', 'nu': -1.0, 'sigma_f': 10,
                                                                    'length_scale': 8}), _ctx=ctx)
     assert ei.value.code == L.ERR_UNSUPPORTED
     ok = amd.GP_Edge_Tracing(init, grad, **dict(kw, kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}),

@@ -26,7 +26,7 @@ def _tracer(amd, ctx, g, name, **extra):
     return amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx, **extra)
 
 
-@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96"])
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_mat35_96"])
 def test_grad_image_bit_exact(amd, ctx, golden, name):
     g = golden(name)
     out = amd.gpet_utils.comp_grad_img(g["in_img"], g["in_kernel"], ctx=ctx)
@@ -136,7 +136,7 @@ def test_normals_stream_odd_count(amd, ctx, golden, z_cols):
     np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
 
 
-@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96"])
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_mat35_96"])
 def test_sample_T2_injected_factor(amd, ctx, golden, name):
     """T2: with the reference's factor sqrt(s)*v injected, samples match the reference."""
     g = golden(name)

@@ -74,7 +74,7 @@ def test_pixel_selection_500_from_reference_kde(amd, ctx, golden):
     assert b.scalars().score_thresh == float(g["ref_score_thresh_out"])
 
 
-@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_rbf500"])
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_mat35_96", "trace_rbf500"])
 def test_full_trace_vs_oracle(amd, ctx, golden, name):
     """Whole trace on the device vs the oracle run with the library's eigenvector sign
     convention: observation sets per iteration, iteration count and edge trace bit-exact."""
@@ -146,7 +146,8 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
     optimum (theta and CI from the reference run, trace_* fixtures, given its observations)."""
     from gaussian_process_edge_trace_amd.gpet import device_final_fits
     for name, stage in [("trace_rbf64", "stage_rbf64"), ("trace_rbf65", "stage_rbf65"),
-                        ("trace_mat128", "stage_mat128"), ("trace_rbf500", "stage_rbf500")]:
+                        ("trace_mat128", "stage_mat128"), ("trace_rbf500", "stage_rbf500"),
+                        ("trace_mat35_96", "stage_mat35_96")]:
         g = golden(name)
         grad = golden(stage)["ref_grad"]
         kw = dict(CTOR[stage])
@@ -155,6 +156,13 @@ def test_final_fit_matches_reference_theta(amd, ctx, golden):
         obs = g["ref_obs_%02d" % n_iter]
         fits, rounds = device_final_fits(tr._batch, [dict(tr._p, seed=tr.seed)], [obs], [n_iter])
         mean, std, theta = fits[0]
+        if name == "trace_mat35_96":
+            # general nu: sklearn's length-scale gradient is a forward difference with step 1e-10 (noise ~1e-6 of the
+            # gradient), the device's is analytic: the optimiser paths part at that level
+            np.testing.assert_allclose(theta[:2], g["ref_final_theta"][:2], rtol=0, atol=5e-3)
+            np.testing.assert_allclose(mean, g["ref_final_mean"], rtol=0, atol=5e-3)
+            assert np.array_equal(np.rint(mean).astype(int), g["ref_edge_trace"][:, 0])
+            continue
         # log c and log l to 1e-4; the noise level enters K as nl * w + 1e-6, so it is compared in linear
         # space (the objective is flat in log nl once nl << 1e-6 and the optimiser's stopping point there
         # is decided by rounding noise in the gradient)

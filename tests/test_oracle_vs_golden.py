@@ -5,7 +5,7 @@ import pytest
 
 from oracle import gpet_oracle as orc
 
-STAGES = ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_rbf500"]
+STAGES = ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_mat35_96", "stage_rbf500"]
 CTOR = {
     "stage_rbf64": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1,
                         N_samples=128, score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, seed=1,
@@ -17,12 +17,16 @@ CTOR = {
                          keep_ratio=0.125, pixel_thresh=4, seed=7, fix_endpoints=False),
     "stage_mat15_96": dict(kernel_options=(2, 2, 2), noise_y=1, N_samples=200, score_thresh=1, delta_x=6,
                            keep_ratio=0.1, pixel_thresh=2, seed=3, fix_endpoints=True),
+    # general-nu Matern (Bessel-K branch of sklearn's kernel; gpet.py:134)
+    "stage_mat35_96": dict(kernel_options={'kernel': 'Matern', 'nu': 3.5, 'sigma_f': 15, 'length_scale': 10}, noise_y=1,
+                           N_samples=200, score_thresh=1, delta_x=6, keep_ratio=0.1, pixel_thresh=3, seed=5,
+                           fix_endpoints=True),
     "stage_rbf500": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1,
                          N_samples=1000, score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1,
                          fix_endpoints=True),
 }
 TRACES = {"trace_rbf64": "stage_rbf64", "trace_rbf65": "stage_rbf65", "trace_mat128": "stage_mat128",
-          "trace_rbf500": "stage_rbf500"}
+          "trace_mat35_96": "stage_mat35_96", "trace_rbf500": "stage_rbf500"}
 
 
 def test_rng_stream_matches_numpy_legacy():
@@ -50,7 +54,7 @@ def test_kernels(golden):
         np.testing.assert_allclose(Kqx, g["ref_Kqx_" + tag], rtol=1e-13, atol=1e-300)
 
 
-@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96"])
+@pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_mat35_96"])
 def test_conv_bit_exact(golden, name):
     g = golden(name)
     assert np.array_equal(orc.kernel_builder((11, 5)), g["in_kernel"])
@@ -140,7 +144,7 @@ def test_pixel_selection(golden, name):
     assert state["score_thresh"] == float(g["ref_score_thresh_out"])
 
 
-@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128"])
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_mat35_96"])
 def test_full_trace_small(golden, name):
     g = golden(name)
     rec = []
@@ -152,8 +156,9 @@ def test_full_trace_small(golden, name):
     assert np.array_equal(et, g["ref_edge_trace"])
     np.testing.assert_allclose(ci[0], g["ref_ci_lower"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ci[1], g["ref_ci_upper"], rtol=1e-6, atol=1e-6)
-    # (theta sits in a flat direction of the likelihood: L-BFGS-B stops within ~1e-4 of it)
-    np.testing.assert_allclose(info["final"]["theta"], g["ref_final_theta"], rtol=1e-4, atol=1e-6)
+    # (theta sits in a flat direction of the likelihood: L-BFGS-B stops within ~1e-4 of it; for a general Matern nu
+    # sklearn's length-scale gradient is a forward difference with step 1e-10, whose rounding noise moves the stop)
+    np.testing.assert_allclose(info["final"]["theta"], g["ref_final_theta"], rtol=2e-3 if "mat35" in name else 1e-4, atol=1e-6)
 
 
 def test_full_trace_readme_500(golden):
