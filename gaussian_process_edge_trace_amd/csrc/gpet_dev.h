@@ -12,7 +12,8 @@ struct EigState {
   double tol;                      // 1e-14 * first pivot: where the pivoted Cholesky stops
   unsigned long long maxrel_bits;  // bits of the largest squared relative row coupling met in the current sweep
   int stopped, rank;               // pivoted Cholesky finished; rows of G
-  int converged, sweeps;           // Jacobi: every pair orthogonal to 1e-11; sweeps done
+  int converged, sweeps;           // Jacobi: every pair orthogonal to the tolerance; sweeps done
+  int cand_half, pad;              // blocked pivoting: which half of pcx_cand holds the candidates of the next block
 };
 
 // One entry per edge, stored in a device array; kernels index it with blockIdx.y.

@@ -244,6 +244,268 @@ __global__ void __launch_bounds__(256) k_pcx_step(PcxArgs args, EdgeDev* edges, 
   }
 }
 
+// ---- the same factorisation, PCB_NB pivots per launch --------------------------------------------------------------
+// One launch per pivot is bound by launch + round-trip latency (~11 us x 1024 pivots).  A block of up to 16 pivots per
+// launch: every 32-column workgroup offers its largest remaining diagonal as a candidate (so candidates are spread over
+// the edge: neighbouring columns of a smooth covariance would knock each other out), the 16 largest are taken; every
+// workgroup computes the 16 panel rows for its own columns AND, redundantly, the 16 x 16 Schur block of the candidates,
+// factors that block with greedy pivoting (identical arithmetic in every workgroup; a candidate whose pivot has fallen
+// under the tolerance is dropped and may come back in a later block), and finishes its columns of the new rows by
+// forward substitution.  Any pivot order gives G^T G = Sigma; NumPy emulation: same Jacobi sweep count as the exact
+// greedy order, no rejected candidates on the Matern frames.
+#define PCB_NB 16
+#define PCB_CH 128
+template <bool ARGS>
+__global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges, int blk, int nw_max) {
+  PcxEdge E;
+  if (ARGS) {
+    E = args.e[blockIdx.y];
+  } else {
+    const EdgeDev& Et = edges[blockIdx.y];
+    E.G = Et.G;
+    E.Gt = Et.Gt;
+    E.pcx_d = Et.pcx_d;
+    E.pcx_cand = Et.pcx_cand;
+    E.cov = Et.cov;
+    E.perm = Et.perm;
+    E.eig = Et.eig;
+    E.sc = Et.sc;
+    E.Lg = Et.Lg;
+    E.r_cap = Et.r_cap;
+    E.factor_injected = Et.factor_injected;
+  }
+  const int Lg = E.Lg, j0 = blockIdx.x * PCX_COLS, tid = threadIdx.x;
+  if (j0 >= Lg) return;
+  const int lane = tid & 63, w = tid >> 6;
+  EigState* st = E.eig;
+  const gpet_scalars* sc = E.sc;
+  const int s_done = sc->done, s_force = sc->force, s_status = sc->status, s_stopped = st->stopped;
+  const int t0 = st->rank, half = st->cand_half;
+  const double tol_prev = st->tol;
+  const int nwe = (Lg + PCX_COLS - 1) / PCX_COLS;  // <= 64 (the launcher takes the one-pivot path for wider edges)
+  const double* cand = E.pcx_cand + (size_t)half * 2 * nw_max;
+  double cv = -2.0;
+  int ci = 0x7FFFFFFF;
+  if (lane < nwe) {
+    cv = cand[2 * lane];
+    ci = (int)cand[2 * lane + 1];
+  }
+  const int cc = tid & 31, kg = tid >> 5;
+  const int j = j0 + cc;
+  double dj = (j < Lg) ? E.pcx_d[j] : -1.0;
+  if ((s_done && !s_force) || s_status != GPET_OK || E.factor_injected || s_stopped) return;
+  __shared__ int s_cand[PCB_NB];
+  __shared__ double s_cval[PCB_NB];
+  __shared__ int s_nc;
+  __shared__ double s_gp[PCB_NB][PCB_CH + 1];
+  __shared__ double s_P[PCB_NB][PCX_COLS + 1];
+  __shared__ double s_S[PCB_NB][PCB_NB + 1];
+  __shared__ double s_l[PCB_NB][PCB_NB + 1];  // s_l[i][a]: coefficient of candidate i on accepted pivot a
+  __shared__ int s_ord[PCB_NB];
+  __shared__ int s_na;
+  __shared__ double s_bv[4];
+  __shared__ int s_bi[4];
+  if (w == 0) {
+    // the PCB_NB largest candidates, ties to the smaller column
+    for (int k = 0; k < PCB_NB; ++k) {
+      double bv = cv;
+      int bi = ci;
+      pcx_argmax_wave(bv, bi);
+      if (lane == 0) {
+        s_cand[k] = bi;
+        s_cval[k] = bv;
+      }
+      if (ci == bi) cv = -2.0;  // taken
+    }
+  }
+  __syncthreads();
+  const double tol = (blk == 0 && t0 == 0) ? s_cval[0] * 1e-14 : tol_prev;
+  int nc = 0;
+  for (int k = 0; k < PCB_NB; ++k) nc += (s_cval[k] > tol && s_cval[k] > 0.0) ? 1 : 0;  // (sorted: the first nc)
+  if (nc > E.r_cap - t0) nc = E.r_cap - t0;
+  if (nc <= 0) {
+    if (blockIdx.x == 0 && tid == 0) st->stopped = 1;
+    return;
+  }
+  if (blk == 0 && t0 == 0 && blockIdx.x == 0 && tid == 0) st->tol = tol;
+  // panel rows of this workgroup's columns and the Schur block of the candidates, previous rows streamed in chunks
+  const int ld = E.r_cap;
+  double accP0 = 0.0, accP1 = 0.0, accS = 0.0;
+  const int sk = tid >> 4, sm = tid & 15;
+  for (int s0 = 0; s0 < t0; s0 += PCB_CH) {
+    const int len = (t0 - s0) < PCB_CH ? (t0 - s0) : PCB_CH;
+    __syncthreads();
+    for (int e = tid; e < PCB_NB * PCB_CH; e += 256) {
+      const int k = e / PCB_CH, s = e - k * PCB_CH;
+      s_gp[k][s] = (k < nc && s < len) ? E.Gt[(size_t)s_cand[k] * ld + s0 + s] : 0.0;
+    }
+    __syncthreads();
+    if (j < Lg) {
+      const double* __restrict__ gcol = E.G + (size_t)s0 * Lg + j;
+      for (int s = 0; s < len; ++s) {
+        const double gv = gcol[(size_t)s * Lg];
+        accP0 += gv * s_gp[2 * kg][s];
+        accP1 += gv * s_gp[2 * kg + 1][s];
+      }
+    }
+    for (int s = 0; s < len; ++s) accS += s_gp[sk][s] * s_gp[sm][s];
+  }
+  if (j < Lg) {
+    s_P[2 * kg][cc] = (2 * kg < nc) ? E.cov[(size_t)s_cand[2 * kg] * Lg + j] - accP0 : 0.0;
+    s_P[2 * kg + 1][cc] = (2 * kg + 1 < nc) ? E.cov[(size_t)s_cand[2 * kg + 1] * Lg + j] - accP1 : 0.0;
+  } else {
+    s_P[2 * kg][cc] = 0.0;
+    s_P[2 * kg + 1][cc] = 0.0;
+  }
+  s_S[sk][sm] = (sk < nc && sm < nc) ? E.cov[(size_t)s_cand[sk] * Lg + s_cand[sm]] - accS : 0.0;
+  __syncthreads();
+  // greedy pivoted Cholesky of the nc x nc Schur block: lanes 0..15 of wave 0 hold one candidate each (its row of the
+  // factor in registers, the pivot's row broadcast by shuffles); every workgroup gets the same result
+  if (w == 0) {
+    const int i = lane & 15;
+    double Sd = s_S[i][i];
+    bool used = i >= nc;
+    double li[PCB_NB];
+#pragma unroll
+    for (int m = 0; m < PCB_NB; ++m) li[m] = 0.0;
+    int na = 0;
+    bool going = true;
+#pragma unroll
+    for (int a = 0; a < PCB_NB; ++a) {
+      if (going && a < nc) {
+        double bv = used ? -1.0 : Sd;
+        int bi = i;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          const double ov = __shfl_xor(bv, o, WAVE);
+          const int oi = __shfl_xor(bi, o, WAVE);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        const int k = bi;
+        if (!(bv > tol) || !(bv > 0.0)) {
+          going = false;
+        } else {
+          const double piv = sqrt(bv);
+          double v = s_S[i][k];
+#pragma unroll
+          for (int m = 0; m < PCB_NB; ++m)
+            if (m < a) v -= li[m] * __shfl(li[m], k, WAVE);
+          const double la = (i == k) ? piv : v / piv;
+          li[a] = la;
+          if (i == k) used = true;
+          else if (!used) Sd -= la * la;
+          if (lane == 0) s_ord[a] = k;
+          na = a + 1;
+        }
+      }
+    }
+    if (lane < PCB_NB) {
+#pragma unroll
+      for (int m = 0; m < PCB_NB; ++m) s_l[i][m] = li[m];
+    }
+    if (lane == 0) s_na = na;
+  }
+  __syncthreads();
+  const int na = s_na;
+  if (na == 0) {  // (cannot happen while the first candidate is above the tolerance; defensive)
+    if (blockIdx.x == 0 && tid == 0) st->stopped = 1;
+    return;
+  }
+  // this workgroup's columns of the new rows: r_a = (P[k_a] - sum_{m<a} l[k_a][m] r_m) / l[k_a][a]
+  double nb_v = -1.0;
+  int nb_i = 0x7FFFFFFF;
+  if (tid < PCX_COLS && j < Lg) {
+    double r[PCB_NB];
+    for (int a = 0; a < na; ++a) {
+      const int k = s_ord[a];
+      double v = s_P[k][cc];
+      for (int m = 0; m < a; ++m) v -= s_l[k][m] * r[m];
+      v = v / s_l[k][a];
+      if (!(dj >= 0.0)) v = 0.0;  // a column pivoted earlier has no entries in later rows
+      r[a] = v;
+      E.G[(size_t)(t0 + a) * Lg + j] = v;
+      E.Gt[(size_t)j * ld + t0 + a] = v;
+      if (j == s_cand[k]) {
+        dj = -1.0;
+        E.perm[t0 + a] = j;
+      } else if (dj >= 0.0) {
+        const double nd = dj - v * v;
+        dj = nd > 0.0 ? nd : 0.0;
+      }
+    }
+    E.pcx_d[j] = dj;
+    nb_v = dj;
+    nb_i = j;
+  }
+  if (tid < WAVE) {
+    pcx_argmax_wave(nb_v, nb_i);
+    if (tid == 0) {
+      double* nxt = E.pcx_cand + (size_t)(1 - half) * 2 * nw_max;
+      nxt[2 * blockIdx.x] = nb_v;
+      nxt[2 * blockIdx.x + 1] = (double)nb_i;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    st->rank = t0 + na;
+    st->cand_half = 1 - half;
+    if (t0 + na >= E.r_cap) st->stopped = 1;
+  }
+}
+
+// per-workgroup candidates for the first block
+__global__ void __launch_bounds__(64) k_pcb_init(EdgeDev* edges, int nw_max) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (eig_skip(E)) return;
+  const int Lg = E.Lg, j0 = blockIdx.x * PCX_COLS, tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) {
+    EigState* st = E.eig;
+    st->tol = 0.0;
+    st->stopped = 0;
+    st->rank = 0;
+    st->maxrel_bits = 0ull;
+    st->converged = 0;
+    st->sweeps = 0;
+    st->cand_half = 0;
+  }
+  if (j0 >= Lg) return;
+  const int j = j0 + tid;
+  double bv = -1.0;
+  int bi = 0x7FFFFFFF;
+  if (tid < PCX_COLS && j < Lg) {
+    const double d = E.cov[(size_t)j * Lg + j];
+    E.pcx_d[j] = d;
+    bv = d;
+    bi = j;
+  }
+  pcx_argmax_wave(bv, bi);
+  if (tid == 0) {
+    E.pcx_cand[2 * blockIdx.x] = bv;
+    E.pcx_cand[2 * blockIdx.x + 1] = (double)bi;
+  }
+  (void)nw_max;
+}
+
+__global__ void __launch_bounds__(64) k_pcb_fin(EdgeDev* edges, int nw_max) {
+  const EdgeDev E = edges[blockIdx.x];
+  if (eig_skip(E)) return;
+  EigState* st = E.eig;
+  gpet_scalars* sc = E.sc;
+  if (threadIdx.x != 0) return;
+  const int rank = st->rank;
+  if (rank < E.Lg) {  // stopped short of full rank: by the tolerance (fine) or by the capacity / launch budget
+    const int nwe = (E.Lg + PCX_COLS - 1) / PCX_COLS;
+    const double* cand = E.pcx_cand + (size_t)st->cand_half * 2 * nw_max;
+    double rem = 0.0;
+    for (int i = 0; i < nwe; ++i) rem = cand[2 * i] > rem ? cand[2 * i] : rem;
+    if (rem > st->tol * 1e4) sc->status = GPET_ERR_RANK_CAP;
+  }
+  st->stopped = 1;
+  sc->rank = rank;
+}
+
 __global__ void __launch_bounds__(64) k_pcx_fin(EdgeDev* edges, int steps, int nw_max) {
   const EdgeDev E = edges[blockIdx.x];
   if (eig_skip(E)) return;
@@ -659,8 +921,8 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
       d.injected = h_edges[e].factor_injected;
     }
   const int nw = cdiv_h(bd.Lg, PCX_COLS);
-  hipLaunchKernelGGL(k_pcx_init, dim3(nw, B), dim3(256), 0, st, d_edges, nw);
   const int steps = bd.r_cap < bd.Lg ? bd.r_cap : bd.Lg;
+  const int nblk = 2 * cdiv_h(steps, 2 * OJ_B);
   PcxArgs px_args;
   memset(&px_args, 0, sizeof px_args);
   if (use_args)
@@ -679,14 +941,29 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
       d.r_cap = h.r_cap;
       d.factor_injected = h.factor_injected;
     }
-  for (int t = 0; t < steps; ++t) {
-    if (use_args) hipLaunchKernelGGL((k_pcx_step<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
-    else hipLaunchKernelGGL((k_pcx_step<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+  if (nw <= 64 && !getenv("GPET_PCX_ONE_PIVOT")) {
+    // blocks of up to PCB_NB pivots; rejected candidates cost extra blocks, so the budget is generous (a block that
+    // finds the factorisation finished returns at once)
+    hipLaunchKernelGGL(k_pcb_init, dim3(nw, B), dim3(64), 0, st, d_edges, nw);
+    const int nblocks = 2 * cdiv_h(steps, PCB_NB) + 8;
+    for (int blk = 0; blk < nblocks; ++blk) {
+      if (use_args) hipLaunchKernelGGL((k_pcb_block<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
+      else hipLaunchKernelGGL((k_pcb_block<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
+    }
+    hipLaunchKernelGGL(k_pcb_fin, dim3(B), dim3(64), 0, st, d_edges, nw);
+  } else {
+    hipLaunchKernelGGL(k_pcx_init, dim3(nw, B), dim3(256), 0, st, d_edges, nw);
+    for (int t = 0; t < steps; ++t) {
+      if (use_args) hipLaunchKernelGGL((k_pcx_step<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+      else hipLaunchKernelGGL((k_pcx_step<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+    }
+    hipLaunchKernelGGL(k_pcx_fin, dim3(B), dim3(64), 0, st, d_edges, steps, nw);
   }
-  hipLaunchKernelGGL(k_pcx_fin, dim3(B), dim3(64), 0, st, d_edges, steps, nw);
-  const int nblk = 2 * cdiv_h(steps, 2 * OJ_B);
   const int max_sweeps = gpet_opt_oj_max_sweeps();
-  const bool staged = bd.Lg <= OJ_STAGE_MAX && !getenv("GPET_OJ_NO_STAGE");
+  // LDS staging costs a workgroup a whole CU (131 KB): worth it while a round's workgroups (pairs x edges) fit the
+  // chip's 256 CUs side by side (one edge: 64 pairs; measured 54 vs 61 ms per factor); a bigger batch runs two
+  // register-fed workgroups per CU instead (8 edges: 85 vs 106 ms)
+  const bool staged = bd.Lg <= OJ_STAGE_MAX && (long long)(nblk / 2) * B <= 256 && !getenv("GPET_OJ_NO_STAGE");
   const size_t stage_lds = (size_t)OJ_M * (((bd.Lg + 31) & ~31) + 2) * sizeof(double);
   if (staged) {
     static int attr_done[64] = {};

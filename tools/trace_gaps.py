@@ -2,8 +2,9 @@ import csv,glob,statistics as st,sys
 d0=sys.argv[1]
 f=glob.glob(d0+"/**/*kernel_trace.csv",recursive=True)[0]
 allrows=list(csv.DictReader(open(f)))
-for name in ("k_oj_round","k_pcx_step"):
+for name in ("k_oj_round","k_pcx_step","k_pcb_block"):
     rows=[r for r in allrows if name in r["Kernel_Name"]]
+    if not rows: continue
     rows.sort(key=lambda r:int(r["Start_Timestamp"]))
     d=[int(r["End_Timestamp"])-int(r["Start_Timestamp"]) for r in rows]
     g=[int(rows[i+1]["Start_Timestamp"])-int(rows[i]["End_Timestamp"]) for i in range(len(rows)-1)]
