@@ -87,6 +87,39 @@ struct gpet_batch {
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
+// Host waits.  hipStreamSynchronize spins on a CPU core; with one process per GPU and a few driver threads per process
+// (device loop + converged fits in flight) eight ranks would keep 32 threads spinning on a node's cores.  In blocking
+// mode (gpet_set_option("blocking_sync", 1); default: on when WORLD_SIZE > 1, i.e. under torch.distributed.run) a wait
+// is an event created with hipEventBlockingSync: the thread sleeps until the GPU signals.
+static int& opt_blocking_sync() {
+  static int v = [] {
+    const char* e = getenv("GPET_BLOCKING_SYNC");
+    if (e) return atoi(e) ? 1 : 0;
+    const char* w = getenv("WORLD_SIZE");
+    return (w && atoi(w) > 1) ? 1 : 0;
+  }();
+  return v;
+}
+static hipError_t gpet_wait(hipStream_t st) {
+  if (!opt_blocking_sync()) return hipStreamSynchronize(st);
+  static thread_local hipEvent_t ev = nullptr;  // (per host thread: waits from different driver threads do not share it)
+  static thread_local int ev_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!ev || ev_dev != dev) {
+    if (ev) (void)hipEventDestroy(ev);
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+    if (e != hipSuccess) {
+      ev = nullptr;
+      return hipStreamSynchronize(st);
+    }
+    ev_dev = dev;
+  }
+  hipError_t e = hipEventRecord(ev, st);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(ev);
+}
+
 static int fail(gpet_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -213,6 +246,12 @@ int gpet_set_option(const char* name, int value) {
     v = value ? 1 : 0;
     return old;
   }
+  if (name && strcmp(name, "blocking_sync") == 0) {
+    int& v = opt_blocking_sync();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "oj_tol_exp") == 0) {
     int& v = gpet_opt_oj_tol_exp();
     const int old = v;
@@ -270,7 +309,7 @@ const char* gpet_last_error(const gpet_ctx* c) { return c ? c->err.c_str() : "nu
 
 int gpet_sync(gpet_ctx* c) {
   if (!c) return GPET_ERR_BAD_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -295,7 +334,7 @@ int gpet_timer_stop_ms(gpet_ctx* c, float* ms) {
 // context -- nothing to leak on an error path and no hipMalloc/hipFree per call.
 static int ctx_scratch(gpet_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_bytes) return GPET_OK;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   if (c->scratch) (void)hipFree(c->scratch);
   c->scratch = nullptr;
   c->scratch_bytes = 0;
@@ -335,7 +374,7 @@ int gpet_grad_image(gpet_ctx* c, const double* img, int M, int N, const double* 
   HIPCHK(c, launch_conv(c->stream, d_img, M, N, d_wf, kh, kw, oy, ox, d_tmp, d_mm));
   HIPCHK(c, launch_normalise(c->stream, d_tmp, px, d_mm, d_out));
   HIPCHK(c, hipMemcpyAsync(out, d_out, px * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -359,7 +398,7 @@ int gpet_normalise_f32(gpet_ctx* c, const float* img, size_t count, float* out) 
   HIPCHK(c, launch_minmax(c->stream, d_in, count, d_mm));
   HIPCHK(c, launch_normalise(c->stream, d_in, count, d_mm, d_out));
   HIPCHK(c, hipMemcpyAsync(out, d_out, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -390,7 +429,7 @@ static int upload_images(gpet_batch* b, const float* const* grad, unsigned int f
     HIPCHK(c, hipMemcpyAsync(b->d_minmax, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_minmax(c->stream, b->d_raw, px, b->d_minmax));
     HIPCHK(c, launch_normalise(c->stream, b->d_raw, px, b->d_minmax, (float*)b->h_edges[g].grad));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host copy of mm0 / a pageable source must stay valid)
+    HIPCHK(c, gpet_wait(c->stream));  // (the host copy of mm0 / a pageable source must stay valid)
   }
   return GPET_OK;
 }
@@ -570,7 +609,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   if (any_gen_nu) HIPCHK(c, launch_rho_tab(c->stream, b->d_edges, B, N));
   // gradient KDE of every distinct image (gpet.py:127)
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : B, b->bd, 1));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   // structured loop path: eigenbasis of the grid's correlation matrix, once per edge.  Usable when the
   // LDS Jacobi applies (capacity <= 96) and every init x lies on the grid; GPET_NO_STRUCT=1 disables it.
   b->structured = false;
@@ -614,7 +653,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
         HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
       }
       HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
       b->structured = ok;
     }
   }
@@ -677,7 +716,7 @@ int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count) {
 static int read_scalars(gpet_batch* b, int e, gpet_scalars* s) {
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipMemcpyAsync(s, b->h_edges[e].sc, sizeof *s, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -685,7 +724,7 @@ static int fetch_all_scalars(gpet_batch* b) {
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipMemcpyAsync(b->h_scalars.data(), b->d_scalars, sizeof(gpet_scalars) * b->B, hipMemcpyDeviceToHost,
                            c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -736,7 +775,7 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   if (n_obs > 0)
     HIPCHK(c, hipMemcpyAsync(E.obs_xy, obs_xy, sizeof(long long) * 2 * n_obs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(E.sc, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -785,7 +824,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
       HIPCHK(c, hipMemcpyAsync((char*)dst, E.fin_x, nc * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync((char*)dst + nc * 8, E.fin_y, nc * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync((char*)dst + 2 * nc * 8, E.fin_w, nc * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
       return GPET_OK;
     }
     case GPET_BUF_CHOL: {
@@ -793,7 +832,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
       if (bytes < n * n * 8) return fail(c, GPET_ERR_BAD_ARG, "CHOL read needs %zu bytes", n * n * 8);
       std::vector<double> full((size_t)E.n_cap * E.n_cap);
       HIPCHK(c, hipMemcpyAsync(full.data(), E.K, full.size() * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
       double* o = (double*)dst;
       for (size_t i = 0; i < n; ++i)
         for (size_t j = 0; j < n; ++j) o[i * n + j] = (j <= i) ? full[i * E.n_cap + j] : 0.0;
@@ -809,7 +848,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
     if (s.rank > 0) {
       HIPCHK(c, hipMemcpyAsync(th.data(), E.theta, (size_t)s.rank * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(ord.data(), E.order, (size_t)s.rank * 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
     }
     double* o = (double*)dst;
     for (size_t k = 0; k < bytes / 8; ++k) o[k] = th[ord[k]];
@@ -817,7 +856,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
   }
   if (bytes) {
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, gpet_wait(c->stream));
   }
   return GPET_OK;
 }
@@ -870,7 +909,7 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
   }
   if (bytes > cap) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cap);
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -880,7 +919,7 @@ int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
   EdgeDev& E = b->h_edges[e];
   E.factor_injected = 0;
   HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -916,7 +955,7 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
   HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, -1, 1));
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   b->have_normals = true;
   return GPET_OK;
 }
@@ -964,7 +1003,7 @@ int gpet_final_cov(gpet_batch* b) {
   for (int e = 0; e < b->B; ++e)
     if (b->h_edges[e].fin_n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_cov before gpet_final_predict_all");
   HIPCHK(c, launch_final_cov(c->stream, b->d_edges, b->B, b->bd));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   b->have_fit = true;  // (mean in the caller's hands, covariance in GPET_BUF_COV: gpet_gp_factor may follow)
   return GPET_OK;
 }
@@ -995,7 +1034,7 @@ int gpet_batch_reset(gpet_batch* b) {
     s0.done = (0 >= b->h_edges[e].algo_thresh) ? 1 : 0;
   }
   HIPCHK(c, hipMemcpyAsync(b->d_scalars, b->h_scalars.data(), sizeof(gpet_scalars) * b->B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -1003,7 +1042,7 @@ int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int 
   if (!b || !grad) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   int rc = upload_images(b, grad, flags);
   if (rc) return rc;
   // gradient KDE of every distinct image (gpet.py:127), then the state of a fresh constructor
@@ -1065,7 +1104,7 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
   HIPCHK(c, hipMemcpyAsync(E.fin_w, w, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   E.fin_n = n;
   HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -1087,7 +1126,7 @@ int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int st
   const int cap = b->bd.obs_cap;
   std::vector<long long> host((size_t)b->B * 2 * cap);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_obs, host.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   for (int e = 0; e < b->B; ++e) {
     const int n = b->h_scalars[e].n_obs;
     counts[e] = n;
@@ -1124,7 +1163,7 @@ int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* y
   HIPCHK(c, hipMemcpyAsync(b->d_fin_stage + 2 * blk, w, sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b->d_fin_n, n, sizeof(int) * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_fin_scatter(c->stream, b->d_edges, b->B, b->d_fin_stage, b->d_fin_n, stride));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
 
@@ -1138,7 +1177,7 @@ int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, d
   HIPCHK(c, launch_final_predict(c->stream, b->d_edges, b->B, b->bd));
   std::vector<double> host((size_t)b->B * 2 * b->bd.Lg);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
   for (int e = 0; e < b->B; ++e) {
     const int Lg = b->h_edges[e].Lg;
     memcpy(mean_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg, sizeof(double) * Lg);
@@ -1188,7 +1227,7 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
   HIPCHK(c, hipEventRecord(b->ev_l1, b->fit));
   HIPCHK(c, hipMemcpyAsync(f_out, b->d_f, sizeof(double) * P, hipMemcpyDeviceToHost, b->fit));
   HIPCHK(c, hipMemcpyAsync(g_out, b->d_g, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, b->fit));
-  HIPCHK(c, hipStreamSynchronize(b->fit));
+  HIPCHK(c, gpet_wait(b->fit));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, b->ev_l0, b->ev_l1) == hipSuccess) b->lml_ms += (double)ms;
   b->lml_evals += P;
@@ -1208,7 +1247,7 @@ static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const
   const int ncap_v = ((n_max + 63) / 64) * 64 + 64;
   if (!b->big_mem || b->big_ncap < ncap_v) {
     if (b->big_mem) {
-      HIPCHK(c, hipStreamSynchronize(st));
+      HIPCHK(c, gpet_wait(st));
       (void)hipFree(b->big_mem);
       b->big_mem = nullptr;
     }
@@ -1321,7 +1360,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
     if (rounds % LB_CHECK == 0) {
       int h_next = 0;
       HIPCHK(c, hipMemcpyAsync(&h_next, cnt_next, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipStreamSynchronize(st));
+      HIPCHK(c, gpet_wait(st));
       n_upper = h_next;
     }
   }
@@ -1334,7 +1373,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
   std::vector<double> host((size_t)B * 2 * b->bd.Lg), th((size_t)B * 4);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(th.data(), b->lb_theta_out, th.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, gpet_wait(st));
   for (int e = 0; e < B; ++e) {
     const int Lg = b->h_edges[e].Lg;
     memcpy(mean_out + (size_t)e * stride, host.data() + (size_t)e * 2 * b->bd.Lg, sizeof(double) * Lg);
@@ -1480,7 +1519,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       b->iters_issued += 1;
     }
     b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = true;
-    HIPCHK(c, hipStreamSynchronize(b->side));  // (its launches read the compacted tables too)
+    HIPCHK(c, gpet_wait(b->side));  // (its launches read the compacted tables too)
     int rc = check_device_status(b);
     if (rc) return rc;
     active = 0;

@@ -128,7 +128,9 @@ int gpet_abi_version(void);
  * default (pivoted Cholesky over the GPU + one-sided block Jacobi on its rows, ~12x faster and closer to LAPACK's
  * factor); kept as an independent cross-check.  name = "oj_tol_exp" (default 8) / "oj_max_sweeps" (default 16): the
  * default solver stops after a sweep in which every pair of rows it met was orthogonal to 10^-x relative, or after
- * that many sweeps.  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
+ * that many sweeps.  name = "blocking_sync": 1 = host waits sleep on a blocking event instead of spinning in
+ * hipStreamSynchronize (default: on when WORLD_SIZE > 1 -- one process per GPU, several driver threads each, on a node's
+ * shared cores; environment GPET_BLOCKING_SYNC).  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
  * run ahead of it (default -1 = by batch size: 8 for batches of up to 64 edges, whose loop is bound by the latency of
  * one sequential stream per edge and iteration, 1 for larger ones, which are bound by the generator's throughput; 0: it
  * starts when the previous iteration's pixel selection is done, so nothing is drawn for finished edges, but it then
