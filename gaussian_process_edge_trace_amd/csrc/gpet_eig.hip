@@ -279,8 +279,10 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
   const int lane = tid & 63, w = tid >> 6;
   EigState* st = E.eig;
   const gpet_scalars* sc = E.sc;
-  const int s_done = sc->done, s_force = sc->force, s_status = sc->status, s_stopped = st->stopped;
-  const int t0 = st->rank, half = st->cand_half;
+  // (state of THIS block lives in slot blk & 1, written by the previous launch; this launch writes the other slot)
+  const int cur = blk & 1, nxt = cur ^ 1, half = cur;
+  const int s_done = sc->done, s_force = sc->force, s_status = sc->status, s_stopped = st->stop_slot[cur];
+  const int t0 = st->t_slot[cur];
   const double tol_prev = st->tol;
   const int nwe = (Lg + PCX_COLS - 1) / PCX_COLS;  // <= 64 (the launcher takes the one-pivot path for wider edges)
   const double* cand = E.pcx_cand + (size_t)half * 2 * nw_max;
@@ -293,7 +295,14 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
   const int cc = tid & 31, kg = tid >> 5;
   const int j = j0 + cc;
   double dj = (j < Lg) ? E.pcx_d[j] : -1.0;
-  if ((s_done && !s_force) || s_status != GPET_OK || E.factor_injected || s_stopped) return;
+  if ((s_done && !s_force) || s_status != GPET_OK || E.factor_injected) return;
+  if (s_stopped) {
+    if (blockIdx.x == 0 && tid == 0) {
+      st->t_slot[nxt] = t0;
+      st->stop_slot[nxt] = 1;
+    }
+    return;
+  }
   __shared__ int s_cand[PCB_NB];
   __shared__ double s_cval[PCB_NB];
   __shared__ int s_nc;
@@ -324,7 +333,10 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
   for (int k = 0; k < PCB_NB; ++k) nc += (s_cval[k] > tol && s_cval[k] > 0.0) ? 1 : 0;  // (sorted: the first nc)
   if (nc > E.r_cap - t0) nc = E.r_cap - t0;
   if (nc <= 0) {
-    if (blockIdx.x == 0 && tid == 0) st->stopped = 1;
+    if (blockIdx.x == 0 && tid == 0) {
+      st->t_slot[nxt] = t0;
+      st->stop_slot[nxt] = 1;
+    }
     return;
   }
   if (blk == 0 && t0 == 0 && blockIdx.x == 0 && tid == 0) st->tol = tol;
@@ -411,7 +423,10 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
   __syncthreads();
   const int na = s_na;
   if (na == 0) {  // (cannot happen while the first candidate is above the tolerance; defensive)
-    if (blockIdx.x == 0 && tid == 0) st->stopped = 1;
+    if (blockIdx.x == 0 && tid == 0) {
+      st->t_slot[nxt] = t0;
+      st->stop_slot[nxt] = 1;
+    }
     return;
   }
   // this workgroup's columns of the new rows: r_a = (P[k_a] - sum_{m<a} l[k_a][m] r_m) / l[k_a][a]
@@ -443,15 +458,16 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
   if (tid < WAVE) {
     pcx_argmax_wave(nb_v, nb_i);
     if (tid == 0) {
-      double* nxt = E.pcx_cand + (size_t)(1 - half) * 2 * nw_max;
-      nxt[2 * blockIdx.x] = nb_v;
-      nxt[2 * blockIdx.x + 1] = (double)nb_i;
+      double* cnx = E.pcx_cand + (size_t)nxt * 2 * nw_max;
+      cnx[2 * blockIdx.x] = nb_v;
+      cnx[2 * blockIdx.x + 1] = (double)nb_i;
     }
   }
   if (blockIdx.x == 0 && tid == 0) {
-    st->rank = t0 + na;
-    st->cand_half = 1 - half;
-    if (t0 + na >= E.r_cap) st->stopped = 1;
+    st->t_slot[nxt] = t0 + na;
+    st->stop_slot[nxt] = (t0 + na >= E.r_cap) ? 1 : 0;
+    st->rank = t0 + na;     // (read by k_pcb_fin and the Jacobi kernels: later launches)
+    st->cand_half = nxt;
   }
 }
 
@@ -469,6 +485,10 @@ __global__ void __launch_bounds__(64) k_pcb_init(EdgeDev* edges, int nw_max) {
     st->converged = 0;
     st->sweeps = 0;
     st->cand_half = 0;
+    st->t_slot[0] = 0;
+    st->stop_slot[0] = 0;
+    st->t_slot[1] = 0;
+    st->stop_slot[1] = 0;
   }
   if (j0 >= Lg) return;
   const int j = j0 + tid;
@@ -945,7 +965,8 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     // blocks of up to PCB_NB pivots; rejected candidates cost extra blocks, so the budget is generous (a block that
     // finds the factorisation finished returns at once)
     hipLaunchKernelGGL(k_pcb_init, dim3(nw, B), dim3(64), 0, st, d_edges, nw);
-    const int nblocks = 2 * cdiv_h(steps, PCB_NB) + 8;
+    const int per_block = nw < PCB_NB ? nw : PCB_NB;  // (one candidate per 32-column workgroup: narrow edges offer fewer)
+    const int nblocks = 2 * cdiv_h(steps, per_block) + 8;
     for (int blk = 0; blk < nblocks; ++blk) {
       if (use_args) hipLaunchKernelGGL((k_pcb_block<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
       else hipLaunchKernelGGL((k_pcb_block<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
