@@ -176,6 +176,44 @@ def test_any_rank_factor_full_rank_matern_vs_lapack(amd, ctx):
     assert d_lapack < 1e-5 and d_scalar < 0.05  # (measured: 2.7e-7 px; the scalar rounds are 4e-3 px from LAPACK)
 
 
+@pytest.mark.parametrize("env", [{}, {"GPET_PCX_ONE_PIVOT": "1"}, {"GPET_OJ_NO_STAGE": "1"}, {"GPET_OJ_NO_ARGS": "1"},
+                                 {"GPET_PCX_ONE_PIVOT": "1", "GPET_OJ_NO_STAGE": "1", "GPET_OJ_NO_ARGS": "1"}])
+def test_any_rank_factor_code_paths_agree(amd, ctx, env, monkeypatch):
+    """Every variant of the any-rank factor -- blocked or one-pivot-per-launch Cholesky, rows staged in LDS or fed from
+    registers, per-edge pointers in the kernel arguments or in the edge table (the forms wide edges and big batches
+    take) -- on a batch of three 320-column Matern edges of different observation sets: valid factors (reconstruction,
+    LAPACK's eigenvalues) whose samples agree with LAPACK's to 1e-5 px."""
+    L = amd._lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N = 320
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 48, 'length_scale': 13}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    obs = [truth[s:-s:s][:, [1, 0]].astype(np.int64) for s in (16, 40, 64)]
+    bt = amd.GP_Edge_Tracing_Batch([init] * 3, grad, [3, 4, 5], obs=obs, **kw, _ctx=ctx)
+    b = bt._batch
+    b.fit_predict(want_cov=True)
+    b.factor()
+    Z = orc.legacy_standard_normal(11, 16 * N).reshape(16, N)
+    for e in range(3):
+        s = b.scalars(e)
+        A, cov, ev = b.read(L.BUF_FACTOR, e), b.read(L.BUF_COV, e), b.read(L.BUF_EIGVALS, e)
+        assert s.rank == N
+        w = np.linalg.eigvalsh(cov)[::-1]
+        assert np.abs(A.T @ A - cov).max() < 2e-12 * np.abs(cov).max()
+        assert np.abs(ev - w).max() < 1e-12 * w[0]
+        F, _, _ = orc.mvn_factor_svd(cov, "harmonic")
+        d = np.abs(Z @ A - Z @ F) * s.y_s
+        # the two pinned end points (noise 1e-7 + 1e-6) are a near-degenerate pair of tiny eigenvalues whose
+        # eigenvectors are arbitrary within their plane in any solver, LAPACK included: ~6 sigma of that amplitude at
+        # the ends, decaying inwards over a few length scales; away from them the samples agree to 1e-5 px
+        assert d[:, N // 4:3 * N // 4].max() < 1e-5
+        assert d.max() < 6 * np.sqrt(1.2e-6) * s.y_s * np.abs(Z).max()
+
+
 def test_any_rank_factor_rank_deficient_rbf(amd, ctx):
     """RBF with a short length scale on 1024 columns: numerical rank ~270 -- above the LDS solver's 96, far below Lg.
     The pivoted Cholesky stops at its tolerance and the Jacobi runs on the rows it produced."""
