@@ -249,7 +249,13 @@ def main():
     share_gpu = os.environ.get("GPET_BENCH_SHARE_GPU", "0") == "1"
     dev_index = 0 if share_gpu else local_rank
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # GPET_BENCH_FORCE_DIST=1: take the N>1 code path (process group, broadcast, device-pointer hand-over, barriers)
+    # with a single rank too -- the only way to run the nccl path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("GPET_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"),
+                              RANK=str(rank), WORLD_SIZE=str(world))
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
@@ -267,7 +273,7 @@ def main():
     init = truth[[0, -1], :][:, [1, 0]]
     t_b = 0.0
     grad_kw = {}
-    if world > 1:
+    if use_dist:
         g = torch.empty((N, N), dtype=torch.float32, device=coll_dev)
         if rank == 0:
             g.copy_(torch.from_numpy(pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)))

@@ -240,3 +240,58 @@ def test_out_of_image_observations_are_rejected(amd, ctx):
         with pytest.raises(amd._lib.GpetError) as ei:
             tr._batch.set_obs(0, np.array(bad, dtype=np.int64))
         assert ei.value.code == amd._lib.ERR_BAD_ARG
+
+
+DEVPTR_WORKER = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch                     # BEFORE the library: one HIP runtime per process (both have soname libamdhip64.so.7,
+torch.cuda.init()                # the first one loaded serves both; torch tensors are then valid device pointers for it)
+import gaussian_process_edge_trace_amd as amd
+L = amd._lib
+ctx = L.Context(0)
+N = 128
+imgs = []
+for t in range(4):
+    img, truth = amd.gpet_utils.construct_test_img((N, N), int(0.4 * N), 4, 0.05, 'sinusoidal', 0.3, gaps=True, seed=30 + t)
+    imgs.append(amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
+init = truth[[0, -1], :][:, [1, 0]]
+kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 20, 'length_scale': 10}, noise_y=1, N_samples=256,
+          score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+dev = [torch.from_numpy(g).to("cuda:0") for g in imgs]
+torch.cuda.synchronize()
+host = amd.GP_Edge_Tracing_Batch([init] * 3, imgs[0], [1, 2, 3], **kw, _ctx=ctx)
+onde = amd.GP_Edge_Tracing_Batch([init] * 3, None, [1, 2, 3], grad_device_ptrs=[dev[0].data_ptr()], grad_shape=(N, N), **kw, _ctx=ctx)
+assert np.array_equal(host._batch.read(L.BUF_GRAD), onde._batch.read(L.BUF_GRAD))
+assert np.array_equal(host._batch.read(L.BUF_GRAD_KDE), onde._batch.read(L.BUF_GRAD_KDE))
+for a, b in zip(host(), onde()):
+    assert np.array_equal(a, b)
+host2 = amd.GP_Edge_Tracing_Batch([init] * 2, imgs[:2], [4, 5], **kw, _ctx=ctx)
+onde2 = amd.GP_Edge_Tracing_Batch([init] * 2, None, [4, 5], grad_device_ptrs=[dev[0].data_ptr(), dev[1].data_ptr()], grad_shape=(N, N), **kw, _ctx=ctx)
+for a, b in zip(host2(), onde2()):
+    assert np.array_equal(a, b)
+host2.set_frame(imgs[2:4], None, [6, 7])
+onde2.set_frame(None, None, [6, 7], grad_device_ptrs=[dev[2].data_ptr(), dev[3].data_ptr()])
+assert np.array_equal(host2._batch.read(L.BUF_GRAD_KDE, 1), onde2._batch.read(L.BUF_GRAD_KDE, 1))
+for a, b in zip(host2(), onde2()):
+    assert np.array_equal(a, b)
+print("device pointers ok")
+'''
+
+
+def test_device_pointer_images_equal_host_images(tmp_path):
+    """gpet_batch_create2 / gpet_batch_set_images with GPET_GRAD_ON_DEVICE: gradient images that already live on the GPU
+    (torch CUDA tensors, the way an RCCL broadcast leaves them; SURVEY 8b/8e) are consumed in place and give what host
+    arrays give -- the normalised image, the gradient KDE, every trace -- for a shared image and for one per edge, at
+    construction and through set_frame.  Runs in a fresh process that imports torch FIRST, the order bench.py and the
+    sharded drivers use: torch ships its own HIP runtime and a process must hold only one (INTEGRATION.md section 4)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "devptr_worker.py"
+    script.write_text(DEVPTR_WORKER % dict(root=root))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "device pointers ok" in r.stdout
