@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpet_hip.so")
+LIB_PATH = os.environ.get("GPET_LIB_PATH") or os.path.join(_HERE, "libgpet_hip.so")  # (override: instrumented builds)
 
 # status codes (gpet_status)
 OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_ITER_CAP, ERR_RANK_CAP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_STATE = range(9)

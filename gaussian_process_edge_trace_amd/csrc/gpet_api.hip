@@ -246,6 +246,12 @@ int gpet_set_option(const char* name, int value) {
     v = value ? 1 : 0;
     return old;
   }
+  if (name && strcmp(name, "jacobi_variant") == 0) {
+    int& v = gpet_opt_jacobi_variant();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "blocking_sync") == 0) {
     int& v = opt_blocking_sync();
     const int old = v;
@@ -923,6 +929,14 @@ int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
   return GPET_OK;
 }
 
+// Normals the loop stores per sample row: a structured batch's factors have at most r0_max rows (the posterior lives in
+// the prior's r0 eigen-directions), so only that many columns of the z_cols-wide block are ever multiplied.  The stage
+// API (gpet_gp_normals) always stores the whole block: its factor may come from the generic path or from the caller.
+static inline int loop_z_store(const gpet_batch* b) {
+  if (!b->structured || b->bd.r0_max < 1 || getenv("GPET_Z_STORE_FULL")) return 0;
+  return (b->bd.r0_max + 3) & ~3;
+}
+
 // ---- stages ---------------------------------------------------------------------------
 int gpet_gp_fit_predict(gpet_batch* b, int want_cov) {
   if (!b) return GPET_ERR_BAD_ARG;
@@ -1068,7 +1082,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         break;
       case 120: case 121: case 122: case 123:  // structured path: fit, (U, H, mean), Jacobi, factor rows
         HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
-      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring)); break;
+      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b))); break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1)); break;  // (the loop form: raw, band only)
@@ -1487,7 +1501,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         int n = ring - (j - cur);
         if (n > look) n = look;
         if (cur - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(cur - 1) % 16], 0));
-        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, n));
+        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, n, loop_z_store(b)));
         for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
         b->norm_issued = j + n;
       }
@@ -1498,7 +1512,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         } else if (j - ring >= first) {
           HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
         }
-        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, 1));
+        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, 1, loop_z_store(b)));
         HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
         b->norm_issued = j + 1;
       }

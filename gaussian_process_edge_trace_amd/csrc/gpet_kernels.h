@@ -24,7 +24,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts = ~0u);
 hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd);
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
-                          int iter_abs, int n_ahead);
+                          int iter_abs, int n_ahead, int z_store = 0);
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u,
                       int raw_band = 0);
 hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
@@ -38,6 +38,7 @@ int& gpet_opt_oj_tol_exp();
 // process-wide switch (gpet_set_option "scalar_jacobi"; initial value from the environment GPET_SCALAR_JACOBI):
 // 1 = factor covariances of rank > 96 with the round-1 whole-GPU scalar Jacobi instead of gpet_eig.hip
 int& gpet_opt_scalar_jacobi();
+int& gpet_opt_jacobi_variant();
 // gpet_set_option "rng_lookahead" (default 1; environment GPET_RNG_LOOKAHEAD): how many iterations the RNG stream of
 // the device loop may run ahead of it (gpet_api.hip, gpet_trace_iterate)
 int& gpet_opt_rng_lookahead();

@@ -1175,6 +1175,281 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
   if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
 }
 
+// step 3, "seated" form of the same cyclic Jacobi (same pairs in the same order: the circle method of rr_pair).  The
+// kernel above addresses the matrix by ROW INDEX, so every round recomputes who meets whom and where their entries
+// live, and it writes every off-diagonal block twice.  Here the matrix is addressed by SEAT: the players of pair k always
+// sit in slots 2k and 2k+1, and after every round each player of the circle moves one seat back (the pivot of pair 0
+// stays; after m - 1 rounds everybody is back where they started).  The 2x2 block (pair a, pair b), a <= b, is then a
+// FIXED record, and each of its four updated entries goes to a fixed place of the next round's layout, computed once
+// per thread before the first sweep.  Only the upper triangle of blocks exists (the matrix is symmetric): no mirrored
+// writes, no per-round index arithmetic, and the matrix takes half the space -- 21 KB + 41 KB of W at m = 72, so that TWO
+// workgroups of 512 threads share a CU and one's barriers and rotation parameters hide behind the other's LDS work.
+//   layout: four planes [r][c] of nblk doubles, block (a <= b) at index b (b + 1) / 2 + a: consecutive threads read and
+//           (mostly) write consecutive doubles -- no bank conflicts; diagonal blocks keep [0][0], [0][1], [1][1].
+//   W:      W2[ip][player] as 16-byte pairs (components 2 ip, 2 ip + 1 of the player's eigenvector): the lanes of a wave
+//           are consecutive pairs, whose players are consecutive -- contiguous, conflict-free 16-byte accesses.
+//   round:  read own block, rotate | barrier | write the four entries to next round's places | barrier |
+//           last wave: rotation parameters of the next round; the other seven: W of this round | barrier.
+__device__ __forceinline__ int seat_player(int slot, int round, int m1) {  // who sits in `slot` in round `round` (< m1)
+  const int k = slot >> 1;
+  if (slot & 1) {
+    if (k == 0) return m1;
+    const int v = m1 - k + round;
+    return v >= m1 ? v - m1 : v;
+  }
+  const int v = k + round;
+  return v >= m1 ? v - m1 : v;
+}
+__device__ __forceinline__ int seat_next_slot(int slot, int m1, int half) {  // where the player of `slot` sits next round
+  const int k = slot >> 1;
+  if (slot == 1) return 1;  // the pivot
+  int seat = (slot & 1) ? m1 - k : k;
+  seat = seat == 0 ? m1 - 1 : seat - 1;
+  if (seat == 0) return 0;
+  return seat < half ? 2 * seat : 2 * (m1 - seat) + 1;
+}
+// offset (in doubles) of entry (slot i, slot j) of the symmetric matrix in the four-plane triangle
+__device__ __forceinline__ int seat_offset(int i, int j, int nblk) {
+  int a = i >> 1, b = j >> 1, ri = i & 1, cj = j & 1;
+  if (a > b || (a == b && ri > cj)) {
+    int t = a; a = b; b = t;
+    t = ri; ri = cj; cj = t;
+  }
+  return (2 * ri + cj) * nblk + b * (b + 1) / 2 + a;
+}
+__device__ __forceinline__ void seat_block_of(int e, int& a_, int& b_) {  // e = b (b + 1) / 2 + a, a <= b
+  b_ = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+  while (b_ * (b_ + 1) / 2 > e) --b_;
+  while ((b_ + 1) * (b_ + 2) / 2 <= e) ++b_;
+  a_ = e - b_ * (b_ + 1) / 2;
+}
+
+#define JS_NT 512
+template <int NU>  // blocks per thread: half (half + 1) / 2 <= 1024 up to m = 88, 1176 at m = 96
+__global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scaled_out) {
+  constexpr int NT = JS_NT;
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  __shared__ double s_red[16];
+  __shared__ __attribute__((aligned(16))) double2 s_cs[2][48];
+  __shared__ int s_pos[96];
+  __shared__ double s_theta[96];
+  const int r = sc->rank, ldg = E.r_cap;
+  const int m = (r + 1) & ~1;
+  const int half = m >> 1, m1 = m - 1;
+  const int nblk = half * (half + 1) / 2;
+  double* A0 = s_mem;                                                       // [4][nblk]
+  double2* W2 = reinterpret_cast<double2*>(s_mem + 4 * ((nblk + 1) & ~1));  // [half][m]
+  const int tid = threadIdx.x;
+  if (nblk > NU * NT) {  // (the launcher picks NU from the batch's capacity)
+    if (tid == 0) sc->status = GPET_ERR_RANK_CAP;
+    return;
+  }
+  for (int e = tid; e < nblk; e += NT) {
+    int a_, b_;
+    seat_block_of(e, a_, b_);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = seat_player(2 * a_ + (q >> 1), 0, m1), j = seat_player(2 * b_ + (q & 1), 0, m1);
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      A0[q * nblk + e] = (hi < r) ? E.C[(size_t)lo * ldg + hi] : 0.0;
+    }
+  }
+  for (int e = tid; e < half * m; e += NT) {
+    const int ip = e / m, pl = e - ip * m;
+    W2[e] = make_double2(pl == 2 * ip ? 1.0 : 0.0, pl == 2 * ip + 1 ? 1.0 : 0.0);
+  }
+  // fixed roles: blocks tid, tid + NT, ... with the places of their four entries in the next round's layout
+  int ba[NU], bb[NU], dst[NU][4];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int e = tid + u * NT;
+    seat_block_of(e, ba[u], bb[u]);
+    if (e >= nblk) ba[u] = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i2 = seat_next_slot(2 * ba[u] + (q >> 1), m1, half), j2 = seat_next_slot(2 * bb[u] + (q & 1), m1, half);
+      dst[u][q] = (ba[u] < 0 || (ba[u] == bb[u] && q == 2)) ? -1 : seat_offset(i2, j2, nblk);
+    }
+  }
+  // W workers: the first seven waves, in groups of `half` consecutive threads (thread = pair); group g takes the
+  // component pairs g, g + ngrp, ...   The last wave owns the rotation parameters.
+  constexpr int WT = NT - 64;
+  const int ngrp = half > 0 ? WT / half : 1;
+  const int wg = half > 0 ? tid / half : 0, wb = tid - wg * half;
+  const bool w_on = tid < WT && wg < ngrp;
+  const int pk = tid - WT;
+  const int dk = pk * (pk + 1) / 2 + pk;  // diagonal block of pair pk
+  auto params = [&](int nxt) {
+    if (pk >= 0 && pk < half) {
+      double c = 1.0, s = 0.0;
+      const double app = A0[dk], apq = A0[nblk + dk], aqq = A0[3 * nblk + dk];
+      if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
+        // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
+        // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
+        // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
+        const double d = aqq - app, hh = 2.0 * apq;
+        const double rho2 = d * d + hh * hh;
+        double y = __builtin_amdgcn_rsq(rho2);
+        y = y * (1.5 - 0.5 * rho2 * y * y);
+        const double den = fabs(d) + rho2 * y;
+        double iv = __builtin_amdgcn_rcp(den);
+        iv = iv * (2.0 - den * iv);
+        const double t = (d >= 0.0 ? hh : -hh) * iv;
+        const double u = 1.0 + t * t;
+        c = __builtin_amdgcn_rsq(u);
+        c = c * (1.5 - 0.5 * u * c * c);
+        c = c * (1.5 - 0.5 * u * c * c);
+        s = t * c;
+      }
+      s_cs[nxt][pk] = make_double2(c, s);
+    }
+  };
+  __syncthreads();
+  int sweeps = 0;
+#ifdef GPET_JAC_PROF  // cycles per phase of a round, as seen by the first wave and by the parameter wave
+  long long pq[7] = {0, 0, 0, 0, 0, 0, 0};
+#define JAC_CLK(v) const long long v = clock64()
+#else
+#define JAC_CLK(v)
+#endif
+  if (r >= 2) {
+    for (int sweep = 0; sweep < 40; ++sweep) {
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < nblk; e += NT) {
+        int a_, b_;
+        seat_block_of(e, a_, b_);
+        const double v00 = A0[e], v01 = A0[nblk + e], v10 = A0[2 * nblk + e], v11 = A0[3 * nblk + e];
+        if (a_ == b_) {
+          dg += v00 * v00 + v11 * v11;
+          off += 2.0 * v01 * v01;
+        } else {
+          off += 2.0 * ((v00 * v00 + v01 * v01) + (v10 * v10 + v11 * v11));
+        }
+      }
+      off = block_sum(off, s_red);
+      dg = block_sum(dg, s_red);
+      // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
+      if (off <= 1e-24 * dg || off == 0.0) break;
+      ++sweeps;
+      params(0);
+      __syncthreads();
+      int pb = wb, qb = wb == 0 ? m1 : m1 - wb;  // players of this thread's W pair in round 0
+      for (int round = 0; round < m1; ++round) {
+        JAC_CLK(q0);
+        const double2* cs = s_cs[round & 1];
+        double nv[NU][4];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (ba[u] < 0) continue;
+          const int e = tid + u * NT;
+          const double2 ra = cs[ba[u]], rb = cs[bb[u]];
+          const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
+          const double b00 = A0[e], b01 = A0[nblk + e], b11 = A0[3 * nblk + e];
+          const double b10 = (ba[u] == bb[u]) ? b01 : A0[2 * nblk + e];
+          const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+          const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+          nv[u][0] = ca * t00 - sa * t10;
+          nv[u][2] = sa * t00 + ca * t10;
+          nv[u][1] = ca * t01 - sa * t11;
+          nv[u][3] = sa * t01 + ca * t11;
+        }
+        JAC_CLK(q1);
+        __syncthreads();  // every block has been read
+        JAC_CLK(q2);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (ba[u] >= 0 && dst[u][q] >= 0) A0[dst[u][q]] = nv[u][q];
+        JAC_CLK(q3);
+        __syncthreads();
+        JAC_CLK(q4);
+        if (w_on) {  // W: rotate the eigenvector entries of players pb, qb (needs only this round's cs)
+          const double2 rb = cs[wb];
+          const double cb = rb.x, sb = rb.y;
+          if (sb != 0.0) {
+            // three component pairs per pass, all loads first: the LDS latency is paid once per pass
+            for (int ip0 = wg; ip0 < half; ip0 += 3 * ngrp) {
+              double2 wp[3], wq[3];
+#pragma unroll
+              for (int t = 0; t < 3; ++t) {
+                const int ip = ip0 + t * ngrp;
+                if (ip < half) {
+                  wp[t] = W2[ip * m + pb];
+                  wq[t] = W2[ip * m + qb];
+                }
+              }
+#pragma unroll
+              for (int t = 0; t < 3; ++t) {
+                const int ip = ip0 + t * ngrp;
+                if (ip < half) {
+                  W2[ip * m + pb] = make_double2(cb * wp[t].x - sb * wq[t].x, cb * wp[t].y - sb * wq[t].y);
+                  W2[ip * m + qb] = make_double2(sb * wp[t].x + cb * wq[t].x, sb * wp[t].y + cb * wq[t].y);
+                }
+              }
+            }
+          }
+        }
+        if (round + 1 < m1) params((round + 1) & 1);
+        JAC_CLK(q5);
+        __syncthreads();
+#ifdef GPET_JAC_PROF
+        const long long q6 = clock64();
+        pq[0] += q1 - q0; pq[1] += q2 - q1; pq[2] += q3 - q2; pq[3] += q4 - q3; pq[4] += q5 - q4; pq[5] += q6 - q5; pq[6] += q6 - q0;
+#endif
+        // next round: everybody on the circle is one player further
+        pb = pb + 1 >= m1 ? 0 : pb + 1;
+        if (wb != 0) qb = qb + 1 >= m1 ? 0 : qb + 1;
+      }
+    }
+  }
+  // back in the initial seats: slot -> player of round 0
+  for (int k = tid; k < half; k += NT) {
+    const int d = k * (k + 1) / 2 + k;
+    s_theta[seat_player(2 * k, 0, m1)] = A0[d];
+    s_theta[seat_player(2 * k + 1, 0, m1)] = A0[3 * nblk + d];
+  }
+  __syncthreads();
+  for (int k = tid; k < r; k += NT) E.theta[k] = s_theta[k];
+  const double* Wd = reinterpret_cast<const double*>(W2);  // W[j][i] = Wd[((i >> 1) * m + j) * 2 + (i & 1)]
+  for (int e = tid; e < r * r; e += NT) {
+    const int i = e / r, j = e - i * r;
+    E.W[(size_t)i * ldg + j] = Wd[((i >> 1) * m + j) * 2 + (i & 1)];
+  }
+  for (int k = tid; k < r; k += NT) {
+    const double v = s_theta[k];
+    int pos = 0;
+    for (int j = 0; j < r; ++j) {
+      const double u = s_theta[j];
+      pos += (u > v) || (u == v && j < k);
+    }
+    E.order[pos] = k;
+    s_pos[k] = pos;
+  }
+  __syncthreads();
+  // structured path (scaled_out): G (unused there) <- eigenvectors in descending eigenvalue order, scaled by
+  // y_std sqrt(theta): column pos of row t is the coefficient of basis vector t in factor row pos
+  if (scaled_out) {
+    for (int e = tid; e < r * r; e += NT) {
+      const int i = e / r, j = e - i * r;
+      const double th = s_theta[j];
+      E.G[(size_t)i * ldg + s_pos[j]] = Wd[((i >> 1) * m + j) * 2 + (i & 1)] * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+    }
+  }
+  if (tid == 0) sc->lml = (double)sweeps;  // diagnostics: Jacobi sweeps of this factorisation
+#ifdef GPET_JAC_PROF
+  if ((tid == 0 || tid == NT - 64) && (blockIdx.y == 0 || blockIdx.y == 700) && sweeps > 0) {
+    const double n = (double)sweeps * m1;
+    printf("jac prof blk %d tid %d: per round: read+rotate %.0f | wait %.0f | write %.0f | wait %.0f | W / params %.0f | wait %.0f | total %.0f cycles\n",
+           (int)blockIdx.y, tid, pq[0] / n, pq[1] / n, pq[2] / n, pq[3] / n, pq[4] / n, pq[5] / n, pq[6] / n);
+  }
+#endif
+#undef JAC_CLK
+}
+
 // ---- structured loop path (training points on the pixel grid, rank(rho) <= 96) ---------------
 // The prior covariance on the unit-spaced grid is c * rho with rho Toeplitz and FIXED for the whole
 // trace: rho = Q Lam Q^T (rank r0 ~ 2.6 Lg / l for RBF) is factored once per edge at construction.
@@ -1761,7 +2036,7 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
 // generated by one launch, one workgroup per (iteration, edge).
 #define MTQ_CAP 512  // ring of pending (r2, x1, x2, destinations) records: < 64 left over + 156 per block + slack
 __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
-                                                    int iter_abs) {
+                                                    int iter_abs, int z_store) {
 #pragma clang fp contract(off)
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
@@ -1787,7 +2062,9 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     }
   }
   __syncthreads();
-  const int Lg = E.Lg, zc = E.z_cols;
+  // zc: row stride of the stored block; zs: how many leading normals of a row are stored (the structured loop knows
+  // its factors have at most r0 rows, so the host asks for r0 rounded up to 4 instead of the whole capacity)
+  const int Lg = E.Lg, zc = E.z_cols, zs = (z_store > 0 && z_store < zc) ? z_store : zc;
   const long long total = (long long)E.S * Lg;
   const long long need_pairs = (total + 1) / 2;
   // Only the first z_cols normals of every sample row are stored, but every attempt's accept/reject decision is
@@ -1795,7 +2072,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   // ~1 in 7) the log/sqrt of the stored ones would still run in every wave of every block, so those pairs are queued
   // in LDS and the fourth wave -- idle during the attempts -- evaluates them 64 at a time; when most are stored
   // they are evaluated in place.
-  const bool queued = 2 * zc <= Lg;
+  const bool queued = 2 * zs <= Lg;
   long long done_pairs = 0;
   int row0 = 0, col0 = 0;  // (row, column) of the normal at stream position 2 * done_pairs
   int q_popped = 0;  // records evaluated so far (same value in every thread)
@@ -1870,8 +2147,8 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
           row1 = row + 1;
         }
         const bool last_odd = odd_total && (k == rem - 1) && rem64 <= 1024;  // the stream ends on the first normal of the pair
-        if (col < zc) d0 = row * zc + col;
-        if (!last_odd && col1 < zc) d1 = row1 * zc + col1;
+        if (col < zs) d0 = row * zc + col;
+        if (!last_odd && col1 < zs) d1 = row1 * zc + col1;
         need = (d0 >= 0) || (d1 >= 0);
       }
     }
@@ -3682,6 +3959,30 @@ int& gpet_opt_rng_lookahead() {
   return v;
 }
 
+// LDS Jacobi of ranks <= 96: 1 (default) = seated (k_jacobi_seat), 0 = by row index (k_jacobi_lds, the round-1 form)
+int& gpet_opt_jacobi_variant() {
+  static int v = getenv("GPET_JACOBI_VARIANT") ? atoi(getenv("GPET_JACOBI_VARIANT")) : 1;
+  return v;
+}
+static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int rank_max, int scaled_out) {
+  const int mm = (rank_max + 1) & ~1;
+  static PerDeviceOnce once;
+  if (once.first()) {
+    (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  }
+  if (gpet_opt_jacobi_variant() == 0) {
+    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double), st,
+                       d_edges, scaled_out);
+  } else {
+    const size_t nblk = (size_t)(mm / 2) * (mm / 2 + 1) / 2;
+    const size_t lds = (4 * ((nblk + 1) & ~(size_t)1) + (size_t)mm * mm) * sizeof(double);
+    if (nblk <= 2 * JS_NT) hipLaunchKernelGGL(k_jacobi_seat<2>, dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+    else hipLaunchKernelGGL(k_jacobi_seat<3>, dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+  }
+}
+
 int& gpet_opt_scalar_jacobi() {
   static int v = getenv("GPET_SCALAR_JACOBI") != nullptr ? 1 : 0;
   return v;
@@ -3722,14 +4023,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   }
   const int t = cdiv(bd.r_cap, 16);
   if (parts & 2u) hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
-  if (parts & 4u) {
-    const int mm = (bd.r_cap + 1) & ~1;
-    const size_t lds = ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double);
-    static PerDeviceOnce once;
-    if (once.first())
-      (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), lds, st, d_edges, 0);
-  }
+  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r_cap, 0);
   if (parts & 8u)
     hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
@@ -3767,11 +4061,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     const int l_in_lds = full <= (size_t)STRUCT_H_LDS_MAX ? 1 : 0;  // (gpet_batch_create checked that `rowm` fits)
     hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), l_in_lds ? full : rowm, st, d_edges, l_in_lds);
   }
-  if (parts & 4u) {
-    const int mm = (bd.r_cap + 1) & ~1;
-    hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double), st,
-                       d_edges, 1);
-  }
+  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r0_max > 0 ? bd.r0_max : bd.r_cap, 1);
   if (parts & 8u) {
     // the variant k_struct_rows picks for r0_max: [4 KS][16 MT + 1] eigenvector tile, reused as [r][64] products
     const int rm = bd.r0_max;
@@ -3799,9 +4089,9 @@ hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const Ba
 }
 
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
-                          int iter_abs, int n_ahead) {
+                          int iter_abs, int n_ahead, int z_store) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs);
+  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store);
   return hipGetLastError();
 }
 
