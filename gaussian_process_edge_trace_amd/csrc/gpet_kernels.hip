@@ -1190,6 +1190,11 @@ __global__ void __launch_bounds__(1024) k_jacobi_lds(EdgeDev* edges, int scaled_
 //           are consecutive pairs, whose players are consecutive -- contiguous, conflict-free 16-byte accesses.
 //   round:  read own block, rotate | barrier | write the four entries to next round's places | barrier |
 //           last wave: rotation parameters of the next round; the other seven: W of this round | barrier.
+// What bounds it: LDS STORES (VGPR -> LDS transfer, ~80 B/clk per CU: 13 cycles per ds_write_b128, 6 per ds_write_b64),
+// 62 KB of them per round, two thirds for W.  Tried and measured slower: two copies of the
+// triangle with 2 barriers (85 KB: one workgroup per CU); 768 threads; W in registers moved along the wave with DPP
+// shifts, inside the rounds or as a separate pass over logged rotations (tools/ubench/wpass.hip: VALU-bound at the
+// same ~0.8 ms per 1 024 factorisations the LDS form of W costs).
 __device__ __forceinline__ int seat_player(int slot, int round, int m1) {  // who sits in `slot` in round `round` (< m1)
   const int k = slot >> 1;
   if (slot & 1) {
@@ -2248,6 +2253,17 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
   }
 }
 
+// Workgroup id -> (edge, part) such that the parts of one edge share an XCD.  The dispatcher deals consecutive workgroup
+// ids round the 8 XCDs (cdna_hip_programming.md T1), so with the plain (part, edge) grid the parts of an edge sit on
+// different XCDs and each pulls the edge's shared operand through its own L2.  Bijective for any grid size.
+__device__ __forceinline__ void xcd_edge_part(int nparts, int& edge, int& part) {
+  const int nwg = (int)(gridDim.x * gridDim.y), bid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  edge = wg / nparts;
+  part = wg - edge * nparts;
+}
+
 // K6, rank <= 96 (the production case): each wave keeps its 16 rows of Z -- the whole K extent,
 // 24 f64 per lane -- in registers for the entire sweep over the columns, so Z is read exactly
 // once.  A workgroup is 8 waves = 128 sample rows; the K x 64 chunk of the factor for the
@@ -2256,12 +2272,17 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // The MFMA loop only runs over the actual rank (rounded up to 4).
 // The K extent is a template parameter (KS steps of 4, rank rounded up): a run-time bound inside the
 // unrolled MFMA chain makes the compiler copy the accumulators around every step and drain the pipe.
+// What bounds it: the 4.1 GB of samples it has to STORE per launch of 1 024 edges.  tools/ubench/gemm_pipe.hip rebuilds
+// the loop piece by piece: matrix pipe + LDS operand + barriers + staging run at 68-70 TFLOP/s (1.13 ms); with the
+// stores 1.56 ms, and the stores with 1/18 of the MFMAs still 1.51 ms (2.7 TB/s; 2.85 TB/s with 512-byte runs per
+// instruction).  Measured slower or equal, and dropped: streaming (nontemporal) stores (+35 %), the chunk by LDS-DMA
+// with four 4-wave workgroups per CU (+8 %), a half-tile phase offset between the workgroups of a CU (+-0).
 #define GEMM_KMAX 96
 template <int KS>
-__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa) {
+__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part) {
   constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
-  const int s0 = blockIdx.x * 128;
+  const int s0 = part * 128;
   const int rows = sc->rank;
   const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2274,6 +2295,10 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
     areg[q] = (k < rows && srow < S) ? Zs[(size_t)srow * zc + k] : 0.0;
   }
   const double y_s = sc->y_s;
+  // the posterior mean sits in LDS behind the chunk: a global load in the epilogue would make every 16-column group
+  // wait (vmcnt counts in order) for ALL the stores issued before it
+  double* s_mu = s_fa + 4 * KS * 65;
+  for (int j = tid; j < Lg; j += 512) s_mu[j] = E.mean[j];
   double pf[PF];
   // element e = tid + 512 * u of the [4 KS][64] chunk: row kk = e >> 6, column jj = e & 63 (zero beyond the rank)
 #pragma unroll
@@ -2298,25 +2323,26 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
         pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
       }
     }
-    v4f64 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < KS; ++q) {
-      const double a = areg[q];
-      const double* brow = s_fa + (4 * q + lq) * 65 + li;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, brow[16 * t], acc[t], 0, 0, 0);
-    }
+    // one 16-column group at a time: its 4 stores go out while the matrix pipe works on the next group (and the
+    // accumulators take 8 registers instead of 32)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (j0 + 16 * t >= Lg) continue;  // (an empty group: uniform over the workgroup)
+      v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 16 * t], acc, 0, 0, 0);
       const int j = j0 + 16 * t + li;
       if (j >= Lg) continue;
-      const double mu = E.mean[j];
+      const double mu = s_mu[j];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int sidx = s0 + 16 * w + lq + 4 * g;
-        if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[t][g] + mu) * y_s;
+#if defined(GPET_GEMM_EXP) && GPET_GEMM_EXP == 1  // experiment: no stores (the condition is never true)
+        if (sidx < S && acc[g] == 1.2345e300) E.Y[(size_t)sidx * Lg + j] = (acc[g] + mu) * y_s;
+#else  // (streaming stores, __builtin_nontemporal_store, were measured 35 % slower here)
+        if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[g] + mu) * y_s;
+#endif
       }
     }
   }
@@ -2327,21 +2353,25 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 // 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
 template <int KS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
+  int edge, part;  // the row blocks of an edge on one XCD: its factor comes out of HBM once, not once per row block
+  xcd_edge_part((int)gridDim.x, edge, part);
+  const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  if ((int)blockIdx.x * 128 >= E.S) return;
+  if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];  // [4 KS][65]
-  sample_gemm_body<KS>(E, sc, s_fa);
+  sample_gemm_body<KS>(E, sc, s_fa, part);
 }
 template <int KS>
 __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  // (K > 72: one workgroup per CU)
-  const EdgeDev E = edges[blockIdx.y];
+  int edge, part;
+  xcd_edge_part((int)gridDim.x, edge, part);
+  const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  if ((int)blockIdx.x * 128 >= E.S) return;
+  if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];
-  sample_gemm_body<KS>(E, sc, s_fa);
+  sample_gemm_body<KS>(E, sc, s_fa, part);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -4191,7 +4221,7 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     const int rm = rank_max > 0 && rank_max <= bd.r_cap ? rank_max : (bd.r_cap > bd.a_rows_cap ? bd.r_cap : bd.a_rows_cap);
     const int ks = (rm + 3) >> 2;
     const dim3 grid(cdiv(bd.S, 128), B), block(512);
-#define GPET_GEMM_LAUNCH(KERNEL, KS_) hipLaunchKernelGGL((KERNEL<KS_>), grid, block, (size_t)4 * KS_ * 65 * sizeof(double), st, d_edges)
+#define GPET_GEMM_LAUNCH(KERNEL, KS_) hipLaunchKernelGGL((KERNEL<KS_>), grid, block, ((size_t)4 * KS_ * 65 + bd.Lg) * sizeof(double), st, d_edges)
     if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
     else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
     else if (ks <= 16) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 16);

@@ -10,7 +10,7 @@ N = 500
 img, truth = synth_image(N, 3)
 init = truth[[0, -1], :][:, [1, 0]]
 grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
-for variant in [0, 1]:
+for variant in [int(a) for a in sys.argv[1:]] or [0, 1]:
     L.set_option("jacobi_variant", variant)
     for E in [64, 256, 512, 768, 1024, 2048]:
         seeds = list(range(1, E + 1))
