@@ -28,11 +28,11 @@ STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "
 # gpet_profile_stage ids of the single kernels of one iteration (include/gpet_hip.h)
 # structured loop path (prior eigenbasis; what gpet_trace_iterate runs for on-grid batches): 120-123;
 # generic path (per-stage API, off-grid observations, GPET_NO_STRUCT=1): 100-113
-KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_lds", 123: "k_struct_rows"}
+KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_seat", 123: "k_struct_rows"}
 KERNEL_IDS_GENERIC = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram",
-                      112: "k_jacobi_lds", 113: "k_factor_rows"}
+                      112: "k_jacobi_seat", 113: "k_factor_rows"}
 KERNEL_IDS_COMMON = {130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
-                     151: "k_kde_fused"}  # (152 k_kde_normalise: stage API only; the loop normalises inside the pixel kernels)
+                     151: "k_kde_fused", 160: "k_pix_columns"}  # (152 k_kde_normalise: stage API only; the loop normalises inside the pixel kernels)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector/matrix peak (spec)
 
@@ -455,16 +455,20 @@ def main():
         "k_gram": dict(flops=1.0 * r * r * Lg, bytes=8.0 * (r * Lg + r * r)),
         "k_factor_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
         "k_struct_H": dict(flops=1.0 * n_ * n_ * r + 2.0 * r * r * n_ + 2.0 * r * Lg, bytes=8.0 * (n_ * n_ / 2 + r * r + r * Lg)),
-        "k_jacobi_lds": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
+        "k_jacobi_seat": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
         "k_struct_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
         "k_sample_gemm_mfma_r": dict(flops=2.0 * S * Lg * r, bytes=8.0 * (S * r + r * Lg + S * Lg)),
         "k_score": dict(flops=60.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * M_ * N),
         "k_topk": dict(flops=2.0 * S * S, bytes=16.0 * S),
         "k_kde_prep": dict(flops=2.0 * nk * Lg, bytes=8.0 * nk * Lg),
         "k_kde_fused": dict(flops=36.0 * M_ * N + 10.0 * nk * Lg, bytes=8.0 * nk * Lg + 4.0 * M_ * N),
+        # column scan of the pixel selection: the raw density of the band rows (4 B, ~1/3 of the rows at this state) and,
+        # where it exceeds the threshold, the gradient KDE (4 B); ~30 flops per scanned pixel
+        "k_pix_columns": dict(flops=30.0 * M_ * N / 3.0, bytes=2 * 4.0 * M_ * N / 3.0),
     }
     # the normals kernel fills a ring of `ring` iterations per launch on a side stream: per-iteration share
-    zc = info0["z_cols"]
+    # (a structured batch stores only the r0 leading normals of a row, rounded up to 4: its factors have no more rows)
+    zc = ((info0["r0"] + 3) & ~3) if structured and info0.get("r0", 0) > 0 else info0["z_cols"]
     kernel_ms["k_mt_normals"] = stage_ms["normals"] * ring
     alg["k_mt_normals"] = dict(flops=40.0 * S * zc * ring, bytes=8.0 * S * zc * ring)
     per_iter = {k: (v / ring if k == "k_mt_normals" else v) for k, v in kernel_ms.items()}
@@ -500,10 +504,12 @@ def main():
                     launches_per_step=(lml["launches"] if dom == "k_lml" else iters_per_trace),
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                     note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
-                          "bound is LDS bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_lds" else
+                          "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_seat" else
+                          ("bound by the samples it stores (8 S Lg bytes per edge: 2.7-2.85 TB/s is what a store-only kernel of this "
+                           "shape reaches, tools/ubench/gemm_pipe.hip), see DESIGN.md section 6" if dom == "k_sample_gemm_mfma_r" else
                           ("objective of the converged fits: %d evaluations of ~%.0f-point problems in %d launches per step; "
                            "f64 vector peak; latency-bound (one barrier per pivot), DESIGN.md section 6"
-                           % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None)),
+                           % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None))),
                     state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
                                loop_path="structured" if structured else "generic", iterations_per_trace=iters_per_trace,
                                n_train_final_fit=n_fit),

@@ -1096,6 +1096,9 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
       case 150: case 151: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150), 1)); break;
       case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 4u, 0)); break;  // (stage-API form only)
+      // 160: the column scan of the pixel selection, loop form (reads the raw KDE band of stage 151; it only raises
+      // per-bin maxima to values they already hold, so repeating it leaves the loop state as it was)
+      case 160: HIPCHK(c, launch_pixels(c->stream, b->d_edges, b->B, b->bd, 1, 1u)); break;
       default: return fail(c, GPET_ERR_BAD_ARG, "gpet_profile_stage: unknown stage %d", stage);
     }
   }

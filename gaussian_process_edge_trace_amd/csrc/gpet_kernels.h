@@ -27,7 +27,7 @@ hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigne
                           int iter_abs, int n_ahead, int z_store = 0);
 hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int mode, unsigned parts = ~0u,
                       int raw_band = 0);
-hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0);
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band = 0, unsigned parts = ~0u);
 // any-rank factor (gpet_eig.hip): pivoted Cholesky over the whole GPU + one-sided block Jacobi on its rows
 hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const EdgeDev* h_edges = nullptr);
 // gpet_set_option "oj_max_sweeps" (default 16; environment GPET_OJ_MAX_SWEEPS): sweep budget of that Jacobi

@@ -3079,30 +3079,32 @@ __device__ __forceinline__ int bin_of(const EdgeDev& E, int x) {
 }
 
 // best new candidate of every admissible column (first in row-major order among equals).
-// 16 columns x 16 row-lanes per workgroup: each thread scans every 16th row of its column
-// (independent, column-coalesced loads), then the 16 lanes of a column reduce in LDS.
+// 32 columns x 8 row-lanes per workgroup: each thread scans every 8th row of its column (independent loads; a wave reads
+// two rows of 128 contiguous bytes per instruction: whole cache lines), then the 8 lanes of a column reduce in LDS.
+#define PIX_CX 32
+#define PIX_RY 8
 __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges, int raw_band) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  __shared__ double s_best[16][17];
-  __shared__ int s_by[16][17];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const int x = blockIdx.x * 16 + cx;
+  __shared__ double s_best[PIX_RY][PIX_CX + 1];
+  __shared__ int s_by[PIX_RY][PIX_CX + 1];
+  const int cx = threadIdx.x & (PIX_CX - 1), ry = threadIdx.x / PIX_CX;
+  const int x = blockIdx.x * PIX_CX + cx;
   double best = -1.0;
   int by = -1;
   const bool admissible = (x < E.N) && (E.fix_endpoints ? (x > E.x_st && x < E.x_en) : true);  // gpet.py:655-657
   const float mn = f32_from_key(E.mm[0]);
   const float span = f32_from_key(E.mm[1]) - mn;
-  // raw_band: rows outside the tile's band hold density 0 -> normalised 0 <= 1e-3 unless the minimum of the
-  // whole image is negative (it is not: densities are sums of non-negative terms), so only the band is scanned
+  // raw_band: rows outside the band of the column's KDE tile hold density 0 -> normalised 0 <= 1e-3 unless the minimum
+  // of the whole image is negative (it is not: densities are sums of non-negative terms), so only the band is scanned
   int y_first = 0, y_last = E.M - 1;
-  if (raw_band) {
-    y_first = E.kde_band[2 * blockIdx.x];
-    y_last = E.kde_band[2 * blockIdx.x + 1];
+  if (raw_band && x < E.N) {
+    y_first = E.kde_band[2 * (x / KDE_TX)];
+    y_last = E.kde_band[2 * (x / KDE_TX) + 1];
   }
   if (admissible) {
-    for (int y = y_first + ry; y <= y_last; y += 16) {
+    for (int y = y_first + ry; y <= y_last; y += PIX_RY) {
       const double iv = raw_band ? (double)((E.kde[(size_t)y * E.N + x] - mn) / span) : (double)E.kde[(size_t)y * E.N + x];
       if (iv > 1e-3) {  // gpet.py:651
         const double sv = pixel_score(iv, (double)E.grad_kde[(size_t)y * E.N + x]);
@@ -3117,7 +3119,7 @@ __global__ void __launch_bounds__(256) k_pix_columns(EdgeDev* edges, int raw_ban
   s_by[ry][cx] = by;
   __syncthreads();
   if (ry == 0 && x < E.N) {
-    for (int q = 1; q < 16; ++q) {
+    for (int q = 1; q < PIX_RY; ++q) {
       const double v = s_best[q][cx];
       const int yy = s_by[q][cx];
       if (yy >= 0 && (v > best || (v == best && yy < by))) {
@@ -4202,13 +4204,13 @@ hipError_t launch_pixels_reset(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   return hipGetLastError();
 }
 
-hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band) {
+hipError_t launch_pixels(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int raw_band, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, 16), B), dim3(256), 0, st, d_edges, raw_band);
+  if (parts & 1u) hipLaunchKernelGGL(k_pix_columns, dim3(cdiv(bd.N, PIX_CX), B), dim3(256), 0, st, d_edges, raw_band);
   const int nt = bd.N > bd.obs_cap ? bd.N : bd.obs_cap;
-  hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges, raw_band);
-  hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges, raw_band);
-  hipLaunchKernelGGL(k_pix_select, dim3(1, B), dim3(64), 0, st, d_edges);
+  if (parts & 2u) hipLaunchKernelGGL(k_pix_old, dim3(cdiv(bd.obs_cap, 256), B), dim3(256), 0, st, d_edges, raw_band);
+  if (parts & 4u) hipLaunchKernelGGL(k_pix_argbest, dim3(cdiv(nt, 256), B), dim3(256), 0, st, d_edges, raw_band);
+  if (parts & 8u) hipLaunchKernelGGL(k_pix_select, dim3(1, B), dim3(64), 0, st, d_edges);
   return hipGetLastError();
 }
 

@@ -276,7 +276,8 @@ int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluat
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample
  * GEMM, 4 scoring+top-k, 5 curve KDE; single kernels: 100 fit, 101 predict, 102 covariance, 110 pivoted
  * Cholesky, 111 Gram, 112 Jacobi, 113 factor rows, 130 sample GEMM, 140 scoring, 141 top-k, 150 KDE prep,
- * 151 fused KDE (5, 150, 151: the loop form -- raw density, band rows only), 152 KDE normalise (stage-API form);
+ * 151 fused KDE (5, 150, 151: the loop form -- raw density, band rows only), 152 KDE normalise (stage-API form),
+ * 160 column scan of the pixel selection (loop form);
  * structured loop path: 120 fit, 121 U/H/mean, 122 Jacobi, 123 factor rows + sign pass.
  * (bench.py's roofline leg; leaves the loop state as-is.) */
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep);
