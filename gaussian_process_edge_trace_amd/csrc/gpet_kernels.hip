@@ -32,6 +32,23 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return t;
 }
 
+// Workgroup id -> (edge, part) such that the parts of one edge share an XCD.  The dispatcher deals consecutive workgroup
+// ids round the 8 XCDs (cdna_hip_programming.md T1), so with the plain (part, edge) grid the parts of an edge sit on
+// different XCDs and each pulls the edge's shared operand -- or the cache lines it shares with its neighbours -- through
+// its own L2.  Bijective for any grid size.  Grid: parts along x (and y), edges along the last used dimension.
+__device__ __forceinline__ void xcd_edge_part(int nparts, int& edge, int& part) {
+  const int nwg = (int)(gridDim.x * gridDim.y * gridDim.z);
+  const int bid = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+#ifdef GPET_NO_XCD_REMAP  // (A/B builds)
+  const int wg = bid;
+#else
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#endif
+  edge = wg / nparts;
+  part = wg - edge * nparts;
+}
+
 // General-nu Matern correlation (sklearn kernels.py Matern.__call__, the Bessel-K branch the reference reaches with
 // kernel_options = {'kernel': 'Matern', 'nu': ...}, gpet.py:134):
 //   rho(r) = 2^(1-nu) / Gamma(nu) (sqrt(2 nu) r)^nu K_nu(sqrt(2 nu) r)  =  1 / Gamma(nu) int exp(nu s - e^s - q e^-s) ds,
@@ -2253,17 +2270,6 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
   }
 }
 
-// Workgroup id -> (edge, part) such that the parts of one edge share an XCD.  The dispatcher deals consecutive workgroup
-// ids round the 8 XCDs (cdna_hip_programming.md T1), so with the plain (part, edge) grid the parts of an edge sit on
-// different XCDs and each pulls the edge's shared operand through its own L2.  Bijective for any grid size.
-__device__ __forceinline__ void xcd_edge_part(int nparts, int& edge, int& part) {
-  const int nwg = (int)(gridDim.x * gridDim.y), bid = (int)(blockIdx.x + gridDim.x * blockIdx.y);
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  edge = wg / nparts;
-  part = wg - edge * nparts;
-}
-
 // K6, rank <= 96 (the production case): each wave keeps its 16 rows of Z -- the whole K extent,
 // 24 f64 per lane -- in registers for the entire sweep over the columns, so Z is read exactly
 // once.  A workgroup is 8 waves = 128 sample rows; the K x 64 chunk of the factor for the
@@ -2564,13 +2570,18 @@ __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M,
 }
 
 __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.z];
+  // the tiles of an edge on one XCD: neighbouring tiles split cache lines of the sample rows (a tile's 256-byte runs
+  // start on 32-byte boundaries), which then come out of HBM once instead of once per L2
+  int edge, part;
+  xcd_edge_part((int)(gridDim.x * gridDim.y), edge, part);
+  const int bx = part % (int)gridDim.x, byy = part / (int)gridDim.x;
+  const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ float s_img[];  // [2*SC_PAIRS + 1][ldm]
   const int M = E.M, N = E.N, Lg = E.Lg, S = E.S;
   const int npair = (Lg - 2) / 2;
-  const int p0 = blockIdx.x * SC_PAIRS;
+  const int p0 = bx * SC_PAIRS;
   if (p0 >= npair) return;
   const int c0 = E.x_st + 2 * p0;   // first image column of the slab
   const int ncol = 2 * SC_PAIRS + 1;
@@ -2585,9 +2596,9 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const int pl = tid & 15;  // pair within the tile
   const int i = p0 + pl;
   const int k = 2 * i;
-  const int s_lo = blockIdx.y * SC_CURVES;
+  const int s_lo = byy * SC_CURVES;
   const int s_hi = (s_lo + SC_CURVES < S) ? (s_lo + SC_CURVES) : S;
-  double* __restrict__ part = E.cost_part + ((size_t)blockIdx.x * S) * 2;
+  double* __restrict__ cpart = E.cost_part + ((size_t)bx * S) * 2;
   for (int s0 = s_lo; s0 < s_hi; s0 += SC_THREADS / 16) {
     const int s = s0 + (tid >> 4);
     const bool live = s < s_hi;
@@ -2629,8 +2640,8 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
       li += __shfl_xor(li, o, 16);
     }
     if (pl == 0 && live) {
-      part[2 * s] = al;
-      part[2 * s + 1] = li;
+      cpart[2 * s] = al;
+      cpart[2 * s + 1] = li;
     }
   }
 }
