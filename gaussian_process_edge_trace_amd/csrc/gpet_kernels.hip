@@ -1737,9 +1737,9 @@ __global__ void __launch_bounds__(256) k_struct_mean(EdgeDev* edges) {
 #define SR_TJ 64
 typedef double v4f64_ __attribute__((ext_vector_type(4)));
 template <int MT, int KS>
-__device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w) {
+__device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, int tile) {
   const int r = E.r0, Lg = E.Lg;
-  const int j0 = blockIdx.x * SR_TJ;
+  const int j0 = tile * SR_TJ;
   constexpr int kpad = 4 * KS;
   constexpr int ldw = 16 * MT + 1;  // [kpad][ldw]: s_w[t][k] = scaled coefficient of basis vector t in row k
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1796,23 +1796,25 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w) 
       d2 += row[(c + 2 + k) & 63];
       d3 += row[(c + 3 + k) & 63];
     }
-    E.row_part[(size_t)k * ntile + blockIdx.x] = (d0 + d1) + (d2 + d3);
+    E.row_part[(size_t)k * ntile + tile] = (d0 + d1) + (d2 + d3);
   }
 }
 
 __global__ void __launch_bounds__(256) k_struct_rows(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
+  int edge, tile;  // the column tiles of an edge on one XCD: its r x r coefficient matrix comes out of HBM once
+  xcd_edge_part((int)gridDim.x, edge, tile);
+  const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK || !E.structured) return;
-  if ((int)blockIdx.x * SR_TJ >= E.Lg || E.r0 < 1) return;
+  if (tile * SR_TJ >= E.Lg || E.r0 < 1) return;
   extern __shared__ __attribute__((aligned(16))) double s_rows[];
   const int r = E.r0;  // uniform over the workgroup
-  if (r <= 32) struct_rows_body<2, 8>(E, s_rows);
-  else if (r <= 48) struct_rows_body<3, 12>(E, s_rows);
-  else if (r <= 64) struct_rows_body<4, 16>(E, s_rows);
-  else if (r <= 72) struct_rows_body<5, 18>(E, s_rows);
-  else if (r <= 80) struct_rows_body<5, 20>(E, s_rows);
-  else struct_rows_body<6, 24>(E, s_rows);
+  if (r <= 32) struct_rows_body<2, 8>(E, s_rows, tile);
+  else if (r <= 48) struct_rows_body<3, 12>(E, s_rows, tile);
+  else if (r <= 64) struct_rows_body<4, 16>(E, s_rows, tile);
+  else if (r <= 72) struct_rows_body<5, 18>(E, s_rows, tile);
+  else if (r <= 80) struct_rows_body<5, 20>(E, s_rows, tile);
+  else struct_rows_body<6, 24>(E, s_rows, tile);
 }
 
 // sign convention sum_j A[k][j] / (j + 1) >= 0 from the per-tile partials
