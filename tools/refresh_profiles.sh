@@ -36,7 +36,7 @@ grep "^N=" $O/eig.log >> gpurun_out/profiles_new/r02_matern_factor_launches.txt
 DOM=$(grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel'])")
 echo "dominant kernel: $DOM"
 if [ "$DOM" = "k_lml" ]; then
-  NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//4)")
+  NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//3)")
   python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r02_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
 else
   python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/r02_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
