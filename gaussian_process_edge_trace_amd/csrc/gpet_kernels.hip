@@ -1304,10 +1304,20 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
   const bool w_on = tid < WT && wg < ngrp;
   const int pk = tid - WT;
   const int dk = pk * (pk + 1) / 2 + pk;  // diagonal block of pair pk
+#ifdef GPET_JAC_TRACE
+  double trace_rel = 0.0;
+#endif
   auto params = [&](int nxt) {
     if (pk >= 0 && pk < half) {
       double c = 1.0, s = 0.0;
       const double app = A0[dk], apq = A0[nblk + dk], aqq = A0[3 * nblk + dk];
+#ifdef GPET_JAC_TRACE
+      {
+        const double den = fabs(app * aqq);
+        const double rel2 = den > 0.0 ? apq * apq / den : 0.0;
+        trace_rel = rel2 > trace_rel ? rel2 : trace_rel;
+      }
+#endif
       if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
         // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
         // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
@@ -1353,6 +1363,18 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
       }
       off = block_sum(off, s_red);
       dg = block_sum(dg, s_red);
+#ifdef GPET_JAC_TRACE
+      {
+        double tr = trace_rel;
+        for (int o = 32; o > 0; o >>= 1) {
+          const double ov = __shfl_xor(tr, o, 64);
+          tr = ov > tr ? ov : tr;
+        }
+        if (tid == NT - 64 && (blockIdx.y == 0 || blockIdx.y == 517))
+          printf("jac trace blk %d sweep %d: off2/diag2 = %.3e   largest rel2 rotated in the previous sweep = %.3e\n", (int)blockIdx.y, sweep, off / dg, tr);
+        trace_rel = 0.0;
+      }
+#endif
       // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
       if (off <= 1e-24 * dg || off == 0.0) break;
       ++sweeps;
@@ -2601,15 +2623,29 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const int s_lo = byy * SC_CURVES;
   const int s_hi = (s_lo + SC_CURVES < S) ? (s_lo + SC_CURVES) : S;
   double* __restrict__ cpart = E.cost_part + ((size_t)bx * S) * 2;
+  // the samples of the NEXT group of curves are requested before this group is worked on: the loop is bound by the
+  // latency of these loads (8 waves per SIMD do not cover an HBM round trip per 600 cycles of work on their own)
+  const bool edge_lane = (pl == 15);  // its successor pair belongs to the next tile
+  auto fetch = [&](int s0, double& a0, double& a1, double& a2, double& a3) {
+    const int s = s0 + (tid >> 4);
+    const double* __restrict__ row = E.Y + (size_t)(s < s_hi ? s : s_lo) * Lg;
+    a0 = a1 = a2 = a3 = 0.0;
+    if (k + 1 < Lg) {
+      a0 = row[k];
+      a1 = row[k + 1];
+    }
+    if (edge_lane && i < npair) {
+      a2 = row[k + 2];
+      a3 = row[k + 3];
+    }
+  };
+  double y0, y1, ye2, ye3;
+  fetch(s_lo, y0, y1, ye2, ye3);
   for (int s0 = s_lo; s0 < s_hi; s0 += SC_THREADS / 16) {
     const int s = s0 + (tid >> 4);
     const bool live = s < s_hi;
-    const double* __restrict__ row = E.Y + (size_t)(live ? s : s_lo) * Lg;
-    double y0 = 0.0, y1 = 0.0;
-    if (k + 1 < Lg) {
-      y0 = row[k];
-      y1 = row[k + 1];
-    }
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+    if (s0 + SC_THREADS / 16 < s_hi) fetch(s0 + SC_THREADS / 16, n0, n1, n2, n3);
     const double d0 = y1 - y0;
     const double q0 = 1.0 + d0 * d0;
     const double r0 = rsqrt(q0), l0 = q0 * r0;
@@ -2619,10 +2655,9 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     double g2 = __shfl_down(g0, 1, 16);
     double al = 0.0, li = 0.0;
     if (i < npair) {
-      if (pl == 15) {  // successor pair belongs to the next tile
-        y2 = row[k + 2];
-        const double y3 = row[k + 3];
-        const double d2 = y3 - y2;
+      if (edge_lane) {
+        y2 = ye2;
+        const double d2 = ye3 - y2;
         const double q2 = 1.0 + d2 * d2;
         r2 = rsqrt(q2);
         l2 = q2 * r2;
@@ -2645,6 +2680,10 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
       cpart[2 * s] = al;
       cpart[2 * s + 1] = li;
     }
+    y0 = n0;
+    y1 = n1;
+    ye2 = n2;
+    ye3 = n3;
   }
 }
 
@@ -2877,13 +2916,15 @@ __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
 // columns outside the padded grid never receive weight.
 __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band) {
-  const EdgeDev E = edges[blockIdx.y];
+  int edge, tile;  // the column tiles of an edge on one XCD: neighbours share 8 of their 24 staged columns of every curve
+  xcd_edge_part((int)gridDim.x, edge, tile);
+  const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ double s_a[];
   __shared__ int s_band[2];
   const int M = E.M, N = E.N;
-  const int x0 = blockIdx.x * KDE_TX;
+  const int x0 = tile * KDE_TX;
   if (x0 >= N) return;
   const int NC = KDE_TX + 8;
   const int ld = (KDE_H + 8) | 1;
@@ -3039,8 +3080,8 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
   bool wrote_zero = false;
   if (raw_band) {
     if (tid == 0) {
-      E.kde_band[2 * blockIdx.x] = y_lo;
-      E.kde_band[2 * blockIdx.x + 1] = y_hi;
+      E.kde_band[2 * tile] = y_lo;
+      E.kde_band[2 * tile + 1] = y_hi;
     }
     wrote_zero = (tid == 0) && (y_hi - y_lo + 1 < M);
   } else {
