@@ -2308,8 +2308,9 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // instruction).  Measured slower or equal, and dropped: streaming (nontemporal) stores (+35 %), the chunk by LDS-DMA
 // with four 4-wave workgroups per CU (+8 %), a half-tile phase offset between the workgroups of a CU (+-0).
 #define GEMM_KMAX 96
+#define GEMM_LDS_MAX (150 * 1024)
 template <int KS>
-__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part) {
+__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part, bool mu_lds) {
   constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = part * 128;
@@ -2328,7 +2329,8 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
   // the posterior mean sits in LDS behind the chunk: a global load in the epilogue would make every 16-column group
   // wait (vmcnt counts in order) for ALL the stores issued before it
   double* s_mu = s_fa + 4 * KS * 65;
-  for (int j = tid; j < Lg; j += 512) s_mu[j] = E.mean[j];
+  if (mu_lds)
+    for (int j = tid; j < Lg; j += 512) s_mu[j] = E.mean[j];
   double pf[PF];
   // element e = tid + 512 * u of the [4 KS][64] chunk: row kk = e >> 6, column jj = e & 63 (zero beyond the rank)
 #pragma unroll
@@ -2364,7 +2366,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 16 * t], acc, 0, 0, 0);
       const int j = j0 + 16 * t + li;
       if (j >= Lg) continue;
-      const double mu = s_mu[j];
+      const double mu = mu_lds ? s_mu[j] : E.mean[j];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int sidx = s0 + 16 * w + lq + 4 * g;
@@ -2382,7 +2384,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 // rank multiplies a few zero rows): register allocation is per kernel, and the variants up to K = 72 fit the
 // 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
 template <int KS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges, int mu_in_lds) {
   int edge, part;  // the row blocks of an edge on one XCD: its factor comes out of HBM once, not once per row block
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
@@ -2390,10 +2392,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];  // [4 KS][65]
-  sample_gemm_body<KS>(E, sc, s_fa, part);
+  sample_gemm_body<KS>(E, sc, s_fa, part, mu_in_lds != 0);
 }
 template <int KS>
-__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  // (K > 72: one workgroup per CU)
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int mu_in_lds) {  // (K > 72: one workgroup per CU)
   int edge, part;
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
@@ -2401,7 +2403,7 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];
-  sample_gemm_body<KS>(E, sc, s_fa, part);
+  sample_gemm_body<KS>(E, sc, s_fa, part, mu_in_lds != 0);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -4277,7 +4279,22 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     const int rm = rank_max > 0 && rank_max <= bd.r_cap ? rank_max : (bd.r_cap > bd.a_rows_cap ? bd.r_cap : bd.a_rows_cap);
     const int ks = (rm + 3) >> 2;
     const dim3 grid(cdiv(bd.S, 128), B), block(512);
-#define GPET_GEMM_LAUNCH(KERNEL, KS_) hipLaunchKernelGGL((KERNEL<KS_>), grid, block, ((size_t)4 * KS_ * 65 + bd.Lg) * sizeof(double), st, d_edges)
+    {  // (the chunk plus the posterior mean of a wide edge exceed the 64 KB a kernel gets without asking: 66 KB at K = 96, Lg = 2048)
+      static PerDeviceOnce once;
+      if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX);
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<18>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_rl<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_rl<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      }
+    }
+    // (an edge too wide for its posterior mean to sit behind the chunk reads it from global memory in the epilogue)
+    const int mu_in_lds = ((size_t)4 * 24 * 65 + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
+#define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                          \
+  hipLaunchKernelGGL((KERNEL<KS_>), grid, block, ((size_t)4 * KS_ * 65 + (mu_in_lds ? bd.Lg : 0)) * sizeof(double), st, d_edges, \
+                     mu_in_lds)
     if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
     else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
     else if (ks <= 16) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 16);
