@@ -1547,6 +1547,10 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
   double* s_b = Lp + (l_in_lds ? (size_t)E.n_cap * (E.n_cap + 1) / 2 : (size_t)E.n_cap);  // [r_cap] beta
   const int tid = threadIdx.x, bs = blockDim.x;
   const double c = sc->amp;
+#ifdef GPET_SH_PROF
+  const long long p0 = clock64();
+  const long long w0 = wall_clock64();
+#endif
   // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once if it fits
   for (int e = tid; e < n * r0; e += bs) {
     const int i = e / r0, a = e - i * r0;
@@ -1560,6 +1564,9 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
     }
   }
   __syncthreads();
+#ifdef GPET_SH_PROF
+  const long long p1 = clock64();
+#endif
   // beta_a = sum_i Bo[i][a] alpha_i
   for (int a = tid; a < r0; a += bs) {
     double acc = 0.0;
@@ -1567,15 +1574,51 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
     s_b[a] = acc;
     E.beta[a] = acc;
   }
+#ifdef GPET_SH_PROF
+  const long long p1b = clock64();
+#endif
   if (l_in_lds) {
-    // U = L^-1 Bo: thread a owns column a entirely (its own entries of U, read-only L) -- no barriers inside
-    if (tid < r0) {
-      for (int i = 0; i < n; ++i) {
-        const double* li = Lp + i * (i + 1) / 2;
-        double acc = U[i * ldu + tid];
-        for (int t = 0; t < i; ++t) acc -= li[t] * U[t * ldu + tid];
-        U[i * ldu + tid] = acc / li[i];
+    // U = L^-1 Bo in blocks of 16 rows: (a) every thread takes one (row of the block, column) entry and subtracts the
+    // rows ABOVE the block -- independent inner products, all 16 waves busy; (b) one thread per column finishes the
+    // block's 16 rows (<= 120 dependent steps).  The terms of an entry are subtracted in ascending row order, as by
+    // the one-thread-per-column loop of round 1 (which left 14 of the 16 waves idle for n^2 / 2 dependent steps: 65 %
+    // of this kernel at n = 90), so the result is the same to the bit.
+    for (int i0 = 0; i0 < n; i0 += 16) {
+      const int nb = (n - i0) < 16 ? (n - i0) : 16;
+      if (i0 > 0) {
+        for (int o = tid; o < nb * r0; o += bs) {
+          const int ri = o / r0, ca = o - ri * r0;
+          const int i = i0 + ri;
+          const double* li = Lp + i * (i + 1) / 2;
+          double acc = U[i * ldu + ca];
+#pragma unroll 8
+          for (int t = 0; t < i0; ++t) acc -= li[t] * U[t * ldu + ca];
+          U[i * ldu + ca] = acc;
+        }
+        __syncthreads();
       }
+      if (tid < r0) {
+        // (the block's 16 entries of the column in registers, the triangle fully unrolled: the reads of L carry no
+        //  dependence and are issued ahead of the chain instead of costing one LDS round trip per step)
+        double u[16];
+#pragma unroll
+        for (int ri = 0; ri < 16; ++ri) u[ri] = (ri < nb) ? U[(i0 + ri) * ldu + tid] : 0.0;
+#pragma unroll
+        for (int ri = 0; ri < 16; ++ri) {
+          if (ri < nb) {
+            const int i = i0 + ri;
+            const double* li = Lp + i * (i + 1) / 2 + i0;
+            double acc = u[ri];
+#pragma unroll
+            for (int t = 0; t < ri; ++t) acc -= li[t] * u[t];
+            u[ri] = acc / li[ri];
+          }
+        }
+#pragma unroll
+        for (int ri = 0; ri < 16; ++ri)
+          if (ri < nb) U[(i0 + ri) * ldu + tid] = u[ri];
+      }
+      __syncthreads();
     }
   } else {
     // (many training points: L does not fit next to U; its rows are streamed through LDS one at a time)
@@ -1592,6 +1635,9 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
     }
   }
   __syncthreads();
+#ifdef GPET_SH_PROF
+  const long long p2 = clock64();
+#endif
   // H[a][b] = c lam0[a] delta_ab - sum_i U[i][a] U[i][b]
   for (int e = tid; e < r0 * r0; e += bs) {
     const int a = e / r0, b = e - a * r0;
@@ -1602,13 +1648,25 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
     E.C[(size_t)a * ldc + b] = v;
     E.C[(size_t)b * ldc + a] = v;
   }
+#ifdef GPET_SH_PROF
+  const long long p3 = clock64();
+#endif
   // posterior mean on the grid: y_std * (Q beta) + y_mean        sklearn_gpr.py:382-385
-  for (int j = tid; j < Lg; j += bs) {
-    double acc = 0.0;
-    for (int a = 0; a < r0; ++a) acc += E.Q0[(size_t)a * Lg + j] * s_b[a];
-    E.mean[j] = sc->y_std * acc + sc->y_mean;
+  {  // (two threads per grid point, even and odd basis vectors, loads unrolled: the 72 reads of a thread were one chain)
+    const int hh = tid & 1;
+    const double y_std = sc->y_std, y_mean = sc->y_mean;
+    for (int j = tid >> 1; j < Lg; j += bs >> 1) {
+      double acc = 0.0;
+#pragma unroll 6
+      for (int a = hh; a < r0; a += 2) acc += E.Q0[(size_t)a * Lg + j] * s_b[a];
+      acc += __shfl_xor(acc, 1, 2);
+      if (hh == 0) E.mean[j] = y_std * acc + y_mean;
+    }
   }
   if (tid == 0) sc->rank = r0;
+#ifdef GPET_SH_PROF
+  if (tid == 0 && blockIdx.y == 5) printf("k_struct_H n=%d: build+L %lld | beta %lld | substitution %lld | H %lld | mean %lld ticks; whole kernel %lld ticks = %lld wall ticks of 10 ns\n", n, p1 - p0, p1b - p1, p2 - p1b, p3 - p2, clock64() - p3, clock64() - p0, wall_clock64() - w0);
+#endif
 }
 
 // ---- structured path with MANY training points (n_cap > 128): U lives in HBM (the V buffer, row stride r_cap) ----
