@@ -1551,17 +1551,26 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
   const long long p0 = clock64();
   const long long w0 = wall_clock64();
 #endif
-  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once if it fits
-  for (int e = tid; e < n * r0; e += bs) {
-    const int i = e / r0, a = e - i * r0;
-    const int idx = (int)E.xt[i] - E.x_st;
-    U[i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
-  }
+  // right-hand sides  Bo[i][a] = c * lam0[a] * Q0[a][idx_i];  the Cholesky factor comes into LDS once if it fits.
+  // The grid indices of the training points go to LDS first (s_b is free until beta is formed): the gathers of Q0 then
+  // depend on nothing and overlap with each other and with the copy of L -- two global round trips for the phase
+  // instead of two per gathered element
+  int* s_idx = reinterpret_cast<int*>(s_b);  // (n <= n_cap <= 128 ints in r_cap >= 4 doubles ... sized below)
+  const bool idx_in_lds = (size_t)n * sizeof(int) <= (size_t)E.r_cap * sizeof(double);
+  if (idx_in_lds)
+    for (int i = tid; i < n; i += bs) s_idx[i] = (int)E.xt[i] - E.x_st;
   if (l_in_lds) {
     for (int e = tid; e < n * n; e += bs) {
       const int i = e / n, t = e - i * n;
       if (t <= i) Lp[i * (i + 1) / 2 + t] = E.K[(size_t)i * ldk + t];
     }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int e = tid; e < n * r0; e += bs) {
+    const int i = e / r0, a = e - i * r0;
+    const int idx = idx_in_lds ? s_idx[i] : (int)E.xt[i] - E.x_st;
+    U[i * ldu + a] = c * E.lam0[a] * E.Q0[(size_t)a * Lg + idx];
   }
   __syncthreads();
 #ifdef GPET_SH_PROF
@@ -1638,15 +1647,36 @@ __global__ void __launch_bounds__(1024) k_struct_H(EdgeDev* edges, int l_in_lds)
 #ifdef GPET_SH_PROF
   const long long p2 = clock64();
 #endif
-  // H[a][b] = c lam0[a] delta_ab - sum_i U[i][a] U[i][b]
-  for (int e = tid; e < r0 * r0; e += bs) {
-    const int a = e / r0, b = e - a * r0;
-    if (b > a) continue;
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += U[i * ldu + a] * U[i * ldu + b];
-    const double v = ((a == b) ? c * E.lam0[a] : 0.0) - acc;
-    E.C[(size_t)a * ldc + b] = v;
-    E.C[(size_t)b * ldc + a] = v;
+  // H[a][b] = c lam0[a] delta_ab - sum_i U[i][a] U[i][b]: U^T U on the matrix cores, one 16 x 16 tile of the upper
+  // triangle per wave (v_mfma_f64_16x16x4: A lane l <- U[4 q + (l >> 4)][16 ta + (l & 15)], B the same with tb; both
+  // operands straight from the LDS copy of U), mirrored on the way out
+  {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int nt = (r0 + 15) >> 4, ntile = nt * (nt + 1) / 2, nwave = bs >> 6;
+    for (int tile = wv; tile < ntile; tile += nwave) {
+      int tb = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+      while (tb * (tb + 1) / 2 > tile) --tb;
+      while ((tb + 1) * (tb + 2) / 2 <= tile) ++tb;
+      const int ta = tile - tb * (tb + 1) / 2;  // ta <= tb
+      const int ca = 16 * ta + li, cb = 16 * tb + li;
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int i0 = 0; i0 < n; i0 += 4) {
+        const int i = i0 + lq;
+        const double av = (i < n && ca < r0) ? U[i * ldu + ca] : 0.0;
+        const double bv = (i < n && cb < r0) ? U[i * ldu + cb] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int a = 16 * ta + lq + 4 * g, b = cb;
+        if (a < r0 && b < r0 && b >= a) {
+          const double v = ((a == b) ? c * E.lam0[a] : 0.0) - acc[g];
+          E.C[(size_t)a * ldc + b] = v;
+          E.C[(size_t)b * ldc + a] = v;
+        }
+      }
+    }
   }
 #ifdef GPET_SH_PROF
   const long long p3 = clock64();
