@@ -197,8 +197,9 @@ __global__ void k_normalise_f32(const float* __restrict__ in, size_t count, cons
 // factor is written to HBM; otherwise it is factored in place in HBM (large n, config 3).
 // FINAL: the converged fit at the optimum found by L-BFGS-B (gpet.py:232-266): training set,
 // amplitude, length scale and noise come from fin_x/fin_y/fin_w/fin_par instead of the loop state.
+#define FIT_MAXD 136  // 4 * ceil((128 + 1) / 4) + slack
 template <bool K_IN_LDS, bool FINAL>
-__global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
+__global__ void __launch_bounds__(576) k_fit(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if (!FINAL && ((sc->done && !sc->force) || sc->status != GPET_OK)) return;
@@ -206,6 +207,10 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
   __shared__ double s_red[16];
   __shared__ double s_diag;
   const int tid = threadIdx.x, bs = blockDim.x;
+#ifdef GPET_FIT_PROF
+  const long long f0 = clock64();
+  long long f1 = f0;
+#endif
   const int n_obs = sc->n_obs;
   const int n = FINAL ? E.fin_n : (E.n_init + n_obs);
   const int ld = K_IN_LDS ? (E.n_cap | 1) : E.n_cap;
@@ -232,13 +237,29 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
 
   // 1. gather + stable rank sort by x (np.argsort, gpet.py:212)
   const double w_init = E.fix_endpoints ? 1e-7 : 0.5;  // gpet.py:161
+  // (the x values go through LDS -- the solve vector is free until step 5 -- when they fit: the rank count then reads
+  //  them as broadcasts instead of paying one global round trip per comparison)
+  long long* s_xs = reinterpret_cast<long long*>(s_dyn);
+  const bool x_in_lds = n <= E.n_cap;
+  if (x_in_lds) {
+    for (int j = tid; j < n; j += bs) s_xs[j] = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+    __syncthreads();
+  }
   for (int i = tid; i < n; i += bs) {
     const long long* pi = (i < E.n_init) ? (E.init_xy + 2 * i) : (E.obs_xy + 2 * (i - E.n_init));
     const long long xi = pi[0], yi = pi[1];
     int r = 0;
-    for (int j = 0; j < n; ++j) {
-      const long long xj = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
-      r += (xj < xi) || (xj == xi && j < i);
+    if (x_in_lds) {
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) {
+        const long long xj = s_xs[j];
+        r += (xj < xi) || (xj == xi && j < i);
+      }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        const long long xj = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+        r += (xj < xi) || (xj == xi && j < i);
+      }
     }
     E.xt[r] = (double)xi;
     E.yt[r] = (double)yi;
@@ -246,6 +267,9 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
   }
   __syncthreads();
 
+#ifdef GPET_FIT_PROF
+  f1 = clock64();
+#endif
   // 2. y scaling (gpet.py:228-230) then centring (sklearn_gpr.py:222-227)
   double part = 0.0;
   for (int i = tid; i < n; i += bs) part += E.yt[i];
@@ -285,6 +309,9 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
   __syncthreads();
   }  // !FINAL
 
+#ifdef GPET_FIT_PROF
+  const long long f2 = clock64();
+#endif
   // 3. K = amp * rho + diag(noise_y * w) + jitter     (lower triangle only)
   //    inputs are divided by l exactly as sklearn does (X / length_scale)
   const bool zero_noise = (n == E.Lg);  // sklearn_gpr.py:673-677
@@ -303,32 +330,115 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
   }
   __syncthreads();
 
+#ifdef GPET_FIT_PROF
+  const long long f3 = clock64();
+#endif
   // 4. Cholesky, in place.  K in LDS: right-looking -- per step the pivot column is scaled, then every trailing
   //    entry takes its rank-1 update independently (flat loop over the lower triangle of the trailing block):
   //    two barriers and no serial dot products per step.  K in HBM (n > 128): left-looking (read-mostly).
   bool bad = false;
+  bool fwd_done = false;  // the forward solve z = L^-1 y came out of the factorisation (K_IN_LDS)
   if (K_IN_LDS) {
-    for (int k = 0; k < n; ++k) {
-      const double d = K[(size_t)k * ld + k];
-      if (!(d > 0.0)) {  // (same value for every thread: read before anyone rewrites it)
-        bad = true;
-        break;
+    // Right-looking Cholesky of the BORDERED matrix [K; y^T] in registers: thread t owns the 4 x 4 tile (ti, tj),
+    // tj <= ti, of the lower triangle (diagonal tiles keep both halves); row n is y^T and is never a pivot, so when
+    // the n pivots are done it holds z^T = (L^-1 y)^T -- the forward solve comes for free.  Per pivot: the owners of
+    // column k publish it to LDS (double-buffered), ONE barrier, everyone scales its 4 + 4 column entries by
+    // 1 / sqrt(d) and takes its rank-1 update (the structure of k_lml's sweep).  The LDS-resident form it replaces
+    // needed three barriers, a column pass and a sqrt-indexed sweep over the trailing triangle per pivot: 2 700 cycles
+    // a pivot against ~500 (238 k -> 45 k cycles at n = 89, -DGPET_FIT_PROF).
+    __shared__ __attribute__((aligned(16))) double s_col[2][FIT_MAXD];
+    const int nbt = (n + 1 + 3) >> 2;
+    const int ntile = nbt * (nbt + 1) / 2;
+    const bool active = tid < ntile;
+    int ti = (int)((sqrt(8.0 * (double)tid + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tid) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tid) ++ti;
+    const int tj = tid - ti * (ti + 1) / 2;
+    if (ntile > bs) {  // (cannot happen: n_cap <= 128 and 576 threads)
+      if (tid == 0) sc->status = GPET_ERR_RANK_CAP;
+      return;
+    }
+    double T[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int i = 4 * ti + a, j = 4 * tj + b;
+        double v = 0.0;
+        if (active && i <= n && j < n) {
+          if (i == n) v = E.yt[j];
+          else v = (j <= i) ? K[(size_t)i * ld + j] : K[(size_t)j * ld + i];
+        }
+        T[a][b] = v;
       }
-      const double dk = sqrt(d);
+    bool stop = false;
+    for (int kb = 0; kb < nbt && !stop; ++kb) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = 4 * kb + kk;
+        const int buf = kk & 1;
+        if (k >= n) {
+          stop = true;
+          break;
+        }
+        if (active && tj == kb) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) s_col[buf][4 * ti + a] = T[a][kk];
+        }
+        __syncthreads();
+        const double d = s_col[buf][k];
+        if (!(d > 0.0)) {  // not positive definite (the same value in every thread)
+          bad = true;
+          stop = true;
+          break;
+        }
+        if (active && ti >= kb) {
+          // 1 / sqrt(d) from the hardware seed + two Newton steps (full precision), sqrt(d) = d / sqrt(d): a sqrt and
+          // a division per pivot would sit on every thread's critical path in front of the next barrier
+          double inv = __builtin_amdgcn_rsq(d);
+          inv = inv * (1.5 - 0.5 * d * inv * inv);
+          inv = inv * (1.5 - 0.5 * d * inv * inv);
+          const double dk = d * inv;
+          double ci[4], cj[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            ci[a] = s_col[buf][4 * ti + a] * inv;
+            cj[a] = s_col[buf][4 * tj + a] * inv;
+          }
+          if (tj > kb) {  // strictly below and right of the pivot's tile row / column: no masks
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+              for (int b = 0; b < 4; ++b) T[a][b] = fma(-ci[a], cj[b], T[a][b]);
+          } else if (tj == kb) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const int i = 4 * ti + a;
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                if (i > k && b > kk) T[a][b] = fma(-ci[a], cj[b], T[a][b]);
+              if (i > k) T[a][kk] = ci[a];       // column k of L
+              else if (i == k) T[a][kk] = dk;
+            }
+          }
+        }
+      }
+    }
+    if (!bad) {
+      // the factor back to LDS (lower triangle) for the backward solve, k_struct_H and the readers; z to the solve vector
       __syncthreads();
-      for (int i = k + tid; i < n; i += bs) K[(size_t)i * ld + k] = (i == k) ? dk : K[(size_t)i * ld + k] / dk;
-      __syncthreads();
-      const int m = n - k - 1;
-      // trailing entry e of the packed lower triangle of the m x m block: row ii = floor((sqrt(8e+1)-1)/2)
-      for (int e = tid; e < m * (m + 1) / 2; e += bs) {
-        int ii = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-        while (ii * (ii + 1) / 2 > e) --ii;
-        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-        const int jj = e - ii * (ii + 1) / 2;
-        const int i = k + 1 + ii, j = k + 1 + jj;
-        K[(size_t)i * ld + j] -= K[(size_t)i * ld + k] * K[(size_t)j * ld + k];
+      if (active) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int i = 4 * ti + a, j = 4 * tj + b;
+            if (i < n && j <= i) K[(size_t)i * ld + j] = T[a][b];
+            else if (i == n && j < n) s_dyn[j] = T[a][b];
+          }
       }
       __syncthreads();
+      fwd_done = true;
     }
   } else {
     for (int j = 0; j < n; ++j) {
@@ -357,14 +467,18 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
     return;
   }
 
+#ifdef GPET_FIT_PROF
+  const long long f4 = clock64();
+#endif
   // 5. alpha = L^-T L^-1 y by one wave in column (axpy) form: the solution vector lives in registers
   //    (rows lane, lane + 64), each step broadcasts one solved component -- no reductions, no barriers
   if (tid < WAVE) {
     const int lane = tid;
-    double z0 = (lane < n) ? E.yt[lane] : 0.0, z1 = (lane + WAVE < n) ? E.yt[lane + WAVE] : 0.0;
+    double z0 = (lane < n) ? (fwd_done ? s_dyn[lane] : E.yt[lane]) : 0.0;
+    double z1 = (lane + WAVE < n) ? (fwd_done ? s_dyn[lane + WAVE] : E.yt[lane + WAVE]) : 0.0;
     // (n <= 2 * WAVE on this path: n_cap <= 128 whenever K fits LDS; larger n takes the generic loop below)
     if (n <= 2 * WAVE) {
-      for (int j = 0; j < n; ++j) {  // forward: z_j = y_j / l_jj, then y_i -= l_ij z_j for i > j
+      for (int j = 0; j < n && !fwd_done; ++j) {  // forward: z_j = y_j / l_jj, then y_i -= l_ij z_j for i > j
         const double ljj = K[(size_t)j * ld + j];
         const double zj = __shfl((j < WAVE) ? z0 : z1, j & (WAVE - 1), WAVE) / ljj;
         if (lane == (j & (WAVE - 1))) {
@@ -373,9 +487,14 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
         if (lane > j && lane < n) z0 -= K[(size_t)lane * ld + j] * zj;
         if (lane + WAVE > j && lane + WAVE < n) z1 -= K[(size_t)(lane + WAVE) * ld + j] * zj;
       }
-      for (int j = n - 1; j >= 0; --j) {  // backward: a_j = z_j / l_jj, then z_i -= l_ji a_j for i < j
+      // backward: a_j = z_j / l_jj, then z_i -= l_ji a_j for i < j.  The reciprocals of the diagonal are formed once,
+      // before the chain: a step is multiply + shuffle + fused multiply-add instead of carrying a division
+      const double ri0 = (lane < n) ? 1.0 / K[(size_t)lane * ld + lane] : 0.0;
+      const double ri1 = (lane + WAVE < n) ? 1.0 / K[(size_t)(lane + WAVE) * ld + lane + WAVE] : 0.0;
+#pragma unroll 4
+      for (int j = n - 1; j >= 0; --j) {
         const double* rj = K + (size_t)j * ld;
-        const double aj = __shfl((j < WAVE) ? z0 : z1, j & (WAVE - 1), WAVE) / rj[j];
+        const double aj = __shfl((j < WAVE) ? z0 * ri0 : z1 * ri1, j & (WAVE - 1), WAVE);
         if (lane == (j & (WAVE - 1))) {
           if (j < WAVE) z0 = aj; else z1 = aj;
         }
@@ -402,12 +521,20 @@ __global__ void __launch_bounds__(512) k_fit(EdgeDev* edges) {
       for (int i = lane; i < n; i += WAVE) E.alpha[i] = z[i];
     }
   }
+#ifdef GPET_FIT_PROF
+  const long long f5 = clock64();
+#endif
   if (K_IN_LDS) {  // publish the factor for k_predict / readers (row stride n_cap in HBM)
     for (int idx = tid; idx < n * n; idx += bs) {
       const int i = idx / n, j = idx - i * n;
       if (j <= i) E.K[(size_t)i * E.n_cap + j] = K[(size_t)i * ld + j];
     }
   }
+#ifdef GPET_FIT_PROF
+  if (!FINAL && tid == 0 && blockIdx.y == 5)
+    printf("k_fit n=%d: sort %lld | scaling %lld | K %lld | cholesky %lld | solves %lld | publish %lld cycles\n", n, f1 - f0, f2 - f1, f3 - f2,
+           f4 - f3, f5 - f4, clock64() - f5);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -4076,7 +4203,7 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
   fit_predict_attrs();
   if (!(parts & 1u)) {
   } else if (bd.n_cap <= 128)
-    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(512),
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(576),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else
     launch_fit_blocked(st, d_edges, B, bd);
@@ -4113,7 +4240,7 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
   (void)hipGetLastError();
   fit_predict_attrs();
   if (bd.n_cap <= 128)
-    hipLaunchKernelGGL((k_fit<true, true>), dim3(1, B), dim3(256),
+    hipLaunchKernelGGL((k_fit<true, true>), dim3(1, B), dim3(576),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else
     hipLaunchKernelGGL((k_fit<false, true>), dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
@@ -4217,7 +4344,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
   }
   if (!(parts & 1u)) {
   } else if (bd.n_cap <= 128)
-    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(512),
+    hipLaunchKernelGGL((k_fit<true, false>), dim3(1, B), dim3(576),
                        ((size_t)bd.n_cap * (bd.n_cap | 1) + bd.n_cap) * sizeof(double), st, d_edges);
   else  // (more possible training points than K fits LDS for: blocked factorisation in HBM)
     launch_fit_blocked(st, d_edges, B, bd);
