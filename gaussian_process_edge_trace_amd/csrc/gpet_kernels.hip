@@ -3077,40 +3077,72 @@ __global__ void __launch_bounds__(256) k_kde_normalise(EdgeDev* edges, int mode)
 // ---- fused curve KDE (per-iteration path) ----------------------------------------------
 // k_kde_prep: total kept weight W (KDEpy normalises the weights by their sum), points removed
 // for lying outside the image (gpet.py:498-500), and the per-iteration resets.
+#define KDE_PREP_MAXB 1024
 __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   __shared__ double s_red[16];
   __shared__ double s_inv;
-  if (threadIdx.x == 0) {
-    double inv_sum = 0.0;
-    for (int b = 0; b < E.n_keep; ++b) inv_sum += 1.0 / E.best_costs[b];
-    s_inv = inv_sum;
-    E.mm[0] = 0xFFFFFFFFu;
-    E.mm[1] = 0u;
-  }
-  for (int i = threadIdx.x; i < E.n_bins; i += blockDim.x) {
+  __shared__ double s_ic[KDE_PREP_MAXB];   // 1 / cost of the kept curves, then their weights
+  __shared__ int s_row[KDE_PREP_MAXB];     // their sample rows
+  const int tid = threadIdx.x, nk = E.n_keep;
+  const bool staged = nk <= KDE_PREP_MAXB;
+  // the reciprocals in parallel, their sum by one thread in index order (the order of the sequential loop this
+  // replaces, which paid one global round trip and one division per curve on a single thread)
+  if (staged)
+    for (int b = tid; b < nk; b += blockDim.x) {
+      s_ic[b] = 1.0 / E.best_costs[b];
+      s_row[b] = E.best_idx[b];
+    }
+  for (int i = tid; i < E.n_bins; i += blockDim.x) {
     E.binbest[i] = 0ull;
     E.binarg[i] = 0x7FFFFFFFFFFFFFFFll;
   }
   __syncthreads();
+  if (tid == 0) {
+    double inv_sum = 0.0;
+    if (staged)
+      for (int b = 0; b < nk; ++b) inv_sum += s_ic[b];
+    else
+      for (int b = 0; b < nk; ++b) inv_sum += 1.0 / E.best_costs[b];
+    s_inv = inv_sum;
+    E.mm[0] = 0xFFFFFFFFu;
+    E.mm[1] = 0u;
+  }
+  __syncthreads();
   const double inv_sum = s_inv, ymax = (double)(E.M - 1);
+  if (staged) {
+    for (int b = tid; b < nk; b += blockDim.x) s_ic[b] = s_ic[b] / inv_sum;  // weight of curve b
+    __syncthreads();
+  }
   double wsum = 0.0;
   int removed = 0;
-  // all (curve, column) points as one flat index space: every load is independent of the previous one, so
-  // many are in flight per thread (per-thread sums in a fixed order -> deterministic block sum)
-  const int total = E.n_keep * E.Lg;
+  if (staged) {
+    // wave w takes curves w, w + 16, ...; its lanes walk the columns: coalesced rows, no division per point
+    const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    for (int b = wv; b < nk; b += nw) {
+      const double* __restrict__ row = E.Y + (size_t)s_row[b] * E.Lg;
+      const double wb = s_ic[b];
 #pragma unroll 4
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int b = e / E.Lg, k = e - b * E.Lg;
-    const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
-    const double wb = (1.0 / E.best_costs[b]) / inv_sum;
-    if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
+      for (int k = lane; k < E.Lg; k += 64) {
+        const double y = row[k];
+        if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
+      }
+    }
+  } else {
+    const int total = nk * E.Lg;
+#pragma unroll 4
+    for (int e = tid; e < total; e += blockDim.x) {
+      const int b = e / E.Lg, k = e - b * E.Lg;
+      const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
+      const double wb = (1.0 / E.best_costs[b]) / inv_sum;
+      if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
+    }
   }
   wsum = block_sum(wsum, s_red);
   const double rem = block_sum((double)removed, s_red);
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     E.colsum[0] = wsum;     // W
     E.colsum[1] = inv_sum;  // sum of 1/cost over the kept curves
     sc->n_removed = (int)rem;
