@@ -1338,7 +1338,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
   }
   hipStream_t st = b->fit;
   HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride));
+  HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride, b->bd.n_cap));
   HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0]));
   // Rounds.  The number of running problems lives on the device (lb_count[round & 1]); the host reads it only every
   // LB_CHECK rounds and sizes the launches by its last known value in between -- workgroups beyond the true count

@@ -55,7 +55,7 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
 // converged fit on the device (gpet_lbfgsb.hip): training sets + start points, L-BFGS-B state machines, best restart
 size_t lb_prob_bytes();
 hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, double* d_starts,
-                              double* d_scratch, int scratch_stride);
+                              double* d_scratch, int scratch_stride, int n_cap);
 hipError_t launch_lb_init(hipStream_t st, void* d_probs, int P, const double* d_starts, int* slot_edge, double* slot_theta,
                           int* slot_src);
 hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_upper, const int* cur_count, const int* slot_src,

@@ -741,13 +741,138 @@ __global__ void __launch_bounds__(64) k_lb_pick(EdgeDev* edges, int B, const LbP
   theta_out[(size_t)e * 4 + 3] = fb;
 }
 
+// The same with one WAVE per edge: the points in LDS, ranks and the element-wise transforms by all lanes, the sums by
+// lane 0 in numpy's order (the same arithmetic on the same operands: bit-identical to the kernel above, which spends
+// 2.3 ms per batch on n^2 global loads per thread with 16 waves on the whole GPU -- a tenth of a single edge's trace).
+__global__ void __launch_bounds__(64) k_fin_prepare_wave(EdgeDev* edges, int B, const unsigned int* seeds, double* starts,
+                                                         int n_cap) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x;
+  if (e >= B) return;
+  EdgeDev& Eg = edges[e];
+  const EdgeDev E = Eg;
+  extern __shared__ double s_fp[];  // [4][n_cap]: raw x (as integers), sorted x, sorted y, squares
+  long long* rx = reinterpret_cast<long long*>(s_fp);
+  double* sx = s_fp + n_cap;
+  double* sy = sx + n_cap;
+  double* tmp = sy + n_cap;
+  __shared__ double s_par[6];
+  __shared__ unsigned int s_key[470];
+  const int lane = threadIdx.x;
+  const int n_obs = E.sc->n_obs, n = E.n_init + n_obs;
+  for (int j = lane; j < n; j += 64) rx[j] = j < E.n_init ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const long long xi = rx[i];
+    const long long yi = i < E.n_init ? E.init_xy[2 * i + 1] : E.obs_xy[2 * (i - E.n_init) + 1];
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < n; ++j) {
+      const long long xj = rx[j];
+      rank += (xj < xi) || (xj == xi && j < i);
+    }
+    sx[rank] = (double)xi;
+    sy[rank] = (double)yi;
+    E.fin_w[rank] = (n == E.Lg) ? 0.0 : (i < E.n_init ? (E.fix_endpoints ? 1e-7 : 0.5) : 1.0);  // sklearn_gpr.py:673-677
+  }
+  __syncthreads();
+  const double dn = (double)n;
+  if (lane == 0) s_par[0] = np_pairwise_sum(sy, n) / dn;  // y_m
+  __syncthreads();
+  const double y_m = s_par[0];
+  for (int i = lane; i < n; i += 64) {
+    const double v = sy[i] - y_m;
+    tmp[i] = v * v;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    s_par[1] = sqrt(np_pairwise_sum(tmp, n) / dn);  // y_s
+    s_par[2] = np_pairwise_sum(sx, n) / dn;         // X_m
+  }
+  __syncthreads();
+  const double y_s = s_par[1], X_m = s_par[2];
+  for (int i = lane; i < n; i += 64) {
+    const double v = sx[i] - X_m;
+    tmp[i] = v * v;
+  }
+  __syncthreads();
+  if (lane == 0) s_par[3] = sqrt(np_pairwise_sum(tmp, n) / dn);  // X_s
+  __syncthreads();
+  const double X_s = s_par[3];
+  for (int i = lane; i < n; i += 64) {
+    sy[i] = (sy[i] - y_m) / y_s;
+    E.fin_x[i] = (sx[i] - X_m) / X_s;
+  }
+  __syncthreads();
+  if (lane == 0) s_par[4] = np_pairwise_sum(sy, n) / dn;  // m2
+  __syncthreads();
+  const double m2 = s_par[4];
+  for (int i = lane; i < n; i += 64) {
+    const double v = sy[i] - m2;
+    tmp[i] = v * v;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double s2 = sqrt(np_pairwise_sum(tmp, n) / dn);
+    if (s2 == 0.0) s2 = 1.0;
+    s_par[5] = s2;
+  }
+  __syncthreads();
+  const double s2 = s_par[5];
+  for (int i = lane; i < n; i += 64) E.fin_y[i] = (sy[i] - m2) / s2;
+  if (lane == 0) {
+    double* par = E.fin_par;
+    par[3] = X_m;
+    par[4] = X_s;
+    par[5] = y_m;
+    par[6] = y_s;
+    par[7] = m2;
+    par[8] = s2;
+    Eg.fin_n = n;
+    // MT19937 init_genrand(seed); the first 72 outputs need state words 0..72 and 397..468 of the first twist only
+    s_key[0] = seeds[e];
+    for (int i = 1; i < 470; ++i) s_key[i] = 1812433253u * (s_key[i - 1] ^ (s_key[i - 1] >> 30)) + (unsigned int)i;
+  }
+  __syncthreads();
+  // start points: theta of the kernel (gpet.py:244-245), then lo + (hi - lo) * RandomState(seed).uniform(size=(12, 3))
+  double lo[3], hi[3];
+  lb_bounds(lo, hi);
+  double* st = starts + (size_t)e * 13 * 3;
+  if (lane == 0) {
+    st[0] = log(5.0);
+    st[1] = log(5.0);
+    st[2] = log(E.noise_y);
+  }
+  if (lane < 36) {
+    const int k = lane;
+    unsigned int wv[2];
+    for (int h = 0; h < 2; ++h) {
+      const int q = 2 * k + h;
+      const unsigned int yv = (s_key[q] & 0x80000000u) | (s_key[q + 1] & 0x7FFFFFFFu);
+      unsigned int v = s_key[q + 397] ^ (yv >> 1) ^ ((yv & 1u) ? 0x9908B0DFu : 0u);
+      v ^= v >> 11;
+      v ^= (v << 7) & 0x9D2C5680u;
+      v ^= (v << 15) & 0xEFC60000u;
+      v ^= v >> 18;
+      wv[h] = v;
+    }
+    const double uu = ((double)(wv[0] >> 5) * 67108864.0 + (double)(wv[1] >> 6)) / 9007199254740992.0;
+    const int c = k % 3;
+    st[3 + k] = lo[c] + (hi[c] - lo[c]) * uu;
+  }
+}
+
 size_t lb_prob_bytes() { return sizeof(LbProb); }
 
 hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, double* d_starts,
-                              double* d_scratch, int scratch_stride) {
+                              double* d_scratch, int scratch_stride, int n_cap) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(k_fin_prepare, dim3((B + 63) / 64), dim3(64), 0, st, d_edges, B, d_seeds, d_starts, d_scratch,
-                     scratch_stride);
+  const size_t lds = (size_t)4 * n_cap * sizeof(double);
+  if (n_cap > 0 && lds <= 60 * 1024 && !getenv("GPET_FIN_PREPARE_SERIAL"))
+    hipLaunchKernelGGL(k_fin_prepare_wave, dim3(B), dim3(64), lds, st, d_edges, B, d_seeds, d_starts, n_cap);
+  else
+    hipLaunchKernelGGL(k_fin_prepare, dim3((B + 63) / 64), dim3(64), 0, st, d_edges, B, d_seeds, d_starts, d_scratch,
+                       scratch_stride);
   return hipGetLastError();
 }
 
