@@ -2292,6 +2292,8 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
 }
 
+// (Tried and dropped, bit-identical but no faster: software-pipelining the blocks so that a third of the next block's
+// twist shares each barrier phase with the attempts of the current one.)
 // blockIdx.x = how many iterations ahead of the edge's current one this stream belongs to: the
 // seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
 // generated by one launch, one workgroup per (iteration, edge).
@@ -2353,18 +2355,35 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
     if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
     __syncthreads();
-    // 156 polar attempts on waves 0-2; wave 3 drains the queue of the previous blocks meanwhile
-    bool ok = false;
+    // 156 polar attempts on waves 0-2; wave 3 drains the queue of the previous blocks meanwhile.
+    // Accept / reject needs r2 = x1^2 + x2^2 against 1 -- in double, as numpy decides it -- but only 1 pair in 7 is
+    // stored and needs the doubles themselves.  x1 = (a - 2^26) / 2^26 + b / 2^52 with a the 27 high bits: a float32
+    // estimate from a and c alone is within 4e-7 of r2, so an estimate farther than 1e-5 from the boundary (and from 0)
+    // decides exactly what the double comparison decides; the others (1 attempt in ~1e5) and the stored pairs take the
+    // double path (two more words tempered, the arithmetic of legacy_gauss).
+    bool ok = false, exact = false;
     double x1 = 0.0, x2 = 0.0, r2 = 1.0;
-    if (tid < 156) {
-      const unsigned int a = mt_temper(nw[4 * tid]) >> 5, b = mt_temper(nw[4 * tid + 1]) >> 6;
-      const unsigned int c = mt_temper(nw[4 * tid + 2]) >> 5, d = mt_temper(nw[4 * tid + 3]) >> 6;
-      const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-      const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
+    unsigned int wa = 0u, wc = 0u;
+    auto exact_pair = [&]() {
+      const unsigned int b = mt_temper(nw[4 * tid + 1]) >> 6, d = mt_temper(nw[4 * tid + 3]) >> 6;
+      const double u1 = ((double)wa * 67108864.0 + (double)b) / 9007199254740992.0;
+      const double u2 = ((double)wc * 67108864.0 + (double)d) / 9007199254740992.0;
       x1 = 2.0 * u1 - 1.0;
       x2 = 2.0 * u2 - 1.0;
       r2 = x1 * x1 + x2 * x2;
-      ok = !(r2 >= 1.0 || r2 == 0.0);
+      exact = true;
+    };
+    if (tid < 156) {
+      wa = mt_temper(nw[4 * tid]) >> 5;
+      wc = mt_temper(nw[4 * tid + 2]) >> 5;
+      const float xf = (float)((int)wa - 67108864) * 1.4901161193847656e-08f;  // 2^-26
+      const float yf = (float)((int)wc - 67108864) * 1.4901161193847656e-08f;
+      const float rf = xf * xf + yf * yf;
+      ok = rf < 1.0f;
+      if (!(fabsf(rf - 1.0f) > 1e-5f && rf > 1e-5f)) {
+        exact_pair();
+        ok = !(r2 >= 1.0 || r2 == 0.0);
+      }
     }
     if (queued) {
       // (s_qtail is only written after the barrier below, so every thread reads the same value here)
@@ -2394,7 +2413,9 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     const long long rem64 = need_pairs - done_pairs;
     const int rem = rem64 > 1024 ? 1024 : (int)rem64;
     const bool odd_total = (total & 1LL) != 0;
-    if (ok) {
+    // a block whose normals all fall between the stored columns of one row (uniform test) stores nothing: no positions
+    const bool none_stored = (col0 >= zs) && (col0 + 2 * (tot < rem ? tot : rem) <= Lg);
+    if (ok && !none_stored) {
       const int k = base + before;  // k-th accepted pair of this block
       if (k < rem) {
         int col = col0 + 2 * k, row = row0;
@@ -2413,6 +2434,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
         need = (d0 >= 0) || (d1 >= 0);
       }
     }
+    if (need && !exact) exact_pair();
     if (!queued) {
       if (need) emit(r2, x1, x2, d0, d1);
     } else {
