@@ -136,7 +136,10 @@ int gpet_abi_version(void);
  * starts when the previous iteration's pixel selection is done, so nothing is drawn for finished edges, but it then
  * delays the start of every iteration; larger n only adds draws for edges that finish meanwhile; results are identical).  name = "lml_two_tiles_from": launches of gpet_lml_batch with at least this many
  * problems use the two-tiles-per-thread objective kernel also below 129 training points (default 600; same pivots and
- * element updates, the final sums are added in a different order).  Returns the previous value, or -1 for an unknown name. */
+ * element updates, the final sums are added in a different order).  name = "jacobi_variant": the LDS-resident Jacobi
+ * of factors of rank <= 96: 1 (default) = seated form (blocks addressed by seat, upper triangle, in place, two workgroups
+ * per CU), 0 = by row index (round 1's kernel; the same rotations in the same order, results equal to rounding; kept as
+ * the cross-check).  Returns the previous value, or -1 for an unknown name. */
 int gpet_set_option(const char* name, int value);
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
  * to let the library create its own. */
