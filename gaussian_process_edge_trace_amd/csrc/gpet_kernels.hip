@@ -1982,6 +1982,9 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int j = j0 + 16 * w + li;
+#ifdef GPET_SR_PROF
+  const long long c0 = clock64();
+#endif
   // B operand (Q0[t][j], this wave's 16 columns) straight into registers; A operand (E.G, written by the Jacobi
   // kernel) through LDS, shared by the four waves
   double breg[KS];
@@ -1990,12 +1993,28 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, 
     const int t = 4 * q + lq;
     breg[q] = (t < r && j < Lg) ? E.Q0[(size_t)t * Lg + j] : 0.0;
   }
-#pragma unroll 4
-  for (int e = tid; e < kpad * 16 * MT; e += 256) {
-    const int t = e / (16 * MT), k = e - t * (16 * MT);
-    s_w[t * ldw + k] = (t < r && k < r) ? E.G[(size_t)t * E.r_cap + k] : 0.0;
+  // (all the loads of the coefficient matrix in flight at once -- the trip count is a compile-time constant --
+  //  instead of six dependent batches of four: the staging was two thirds of this kernel's time)
+  {
+    constexpr int NE = kpad * 16 * MT, NL = (NE + 255) / 256;
+    double gv[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u;
+      const int t = e / (16 * MT), k = e - t * (16 * MT);
+      gv[u] = (e < NE && t < r && k < r) ? E.G[(size_t)t * E.r_cap + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u;
+      const int t = e / (16 * MT), k = e - t * (16 * MT);
+      if (e < NE) s_w[t * ldw + k] = gv[u];
+    }
   }
   __syncthreads();
+#ifdef GPET_SR_PROF
+  const long long c1 = clock64();
+#endif
   v4f64_ acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f64_){0.0, 0.0, 0.0, 0.0};
@@ -2006,6 +2025,9 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, 
     for (int mt = 0; mt < MT; ++mt)
       acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[16 * mt], breg[q], acc[mt], 0, 0, 0);
   }
+#ifdef GPET_SR_PROF
+  const long long c2 = clock64();
+#endif
   __syncthreads();  // s_w is reused, as [r][64], for the products A[k][j] / (j + 1)
   double* s_p = s_w;
   const double inv_j = 1.0 / (double)(j + 1);
@@ -2021,6 +2043,9 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, 
       }
     }
   __syncthreads();
+#ifdef GPET_SR_PROF
+  const long long c3 = clock64();
+#endif
   const int ntile = (Lg + SR_TJ - 1) / SR_TJ;
   // row sums of the tile: 4 independent accumulators per row (fixed order), rows strided over the threads
   for (int k = tid; k < r; k += 256) {
@@ -2035,6 +2060,10 @@ __device__ __forceinline__ void struct_rows_body(const EdgeDev& E, double* s_w, 
     }
     E.row_part[(size_t)k * ntile + tile] = (d0 + d1) + (d2 + d3);
   }
+#ifdef GPET_SR_PROF
+  if (tid == 0 && blockIdx.y == 3 && blockIdx.x == 2)
+    printf("k_struct_rows: loads + staging %lld | mfma %lld | stores + products %lld | row sums %lld cycles\n", c1 - c0, c2 - c1, c3 - c2, clock64() - c3);
+#endif
 }
 
 __global__ void __launch_bounds__(256) k_struct_rows(EdgeDev* edges) {
