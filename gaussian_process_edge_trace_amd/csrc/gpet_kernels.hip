@@ -3223,6 +3223,7 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   extern __shared__ double s_a[];
   __shared__ int s_band[2];
+  __shared__ int s_brow[KDE_NB];
   const int M = E.M, N = E.N;
   const int x0 = tile * KDE_TX;
   if (x0 >= N) return;
@@ -3247,11 +3248,16 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
     const double fscale = ldexp(1.0, kexp), finv = ldexp(1.0, -kexp);
     // stage curves [b0, b0+nb) of this tile's columns; returns the rows they touch through (lo, hi)
     auto stage = [&](int b0, int nb, int& lo, int& hi) {
+      // (the sample rows of the curves of this pass through LDS first: the loads of the points then depend on nothing
+      //  and are all in flight together, instead of one index load + one dependent sample load per point)
+      for (int e = tid; e < nb; e += KDE_THREADS) s_brow[e] = E.best_idx[b0 + e];
+      __syncthreads();
+#pragma unroll 6
       for (int e = tid; e < nb * NC; e += KDE_THREADS) {
         const int bb = e / NC, c = e - bb * NC;
         const int xc = x0 + c - 4;
         double y = -1.0;
-        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)E.best_idx[b0 + bb] * E.Lg + (xc - E.x_st)];
+        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)s_brow[bb] * E.Lg + (xc - E.x_st)];
         if (y < 0.0 || y > ymax) y = -1.0;  // gpet.py:498-500
         s_y[e] = y;
         if (y >= 0.0) {
