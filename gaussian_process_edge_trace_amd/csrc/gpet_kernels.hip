@@ -2972,6 +2972,42 @@ __global__ void __launch_bounds__(256) k_score_combine(EdgeDev* edges, int n_til
   E.costs[s] = al / li;
 }
 
+// argsort(costs)[:n_keep] for S <= 1024 by a bitonic sort of (cost, index) in LDS: 55 compare-exchange steps of 512
+// pairs instead of S^2 comparisons (rank counting, below: 0.20 ms per 1 024 edges).  Equal costs keep index order (the
+// index is the second key); -0.0 and +0.0 compare equal, as `<` on doubles has it.
+__global__ void __launch_bounds__(512) k_topk_sort(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  __shared__ double s_k[1024];
+  __shared__ int s_i[1024];
+  const int tid = threadIdx.x, S = E.S;
+  for (int e = tid; e < 1024; e += 512) {
+    s_k[e] = (e < S) ? E.costs[e] : INFINITY;  // (the padding sorts behind every finite cost, and behind +inf by index)
+    s_i[e] = e;
+  }
+  __syncthreads();
+  for (int k = 2; k <= 1024; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), l = i | j;
+      const double a = s_k[i], b = s_k[l];
+      const int ia = s_i[i], ib = s_i[l];
+      const bool a_first = (a < b) || (a == b && ia < ib);
+      const bool up = (i & k) == 0;
+      if (a_first != up) {
+        s_k[i] = b;
+        s_k[l] = a;
+        s_i[i] = ib;
+        s_i[l] = ia;
+      }
+      __syncthreads();
+    }
+  for (int b = tid; b < E.n_keep; b += 512) {
+    E.best_idx[b] = s_i[b];
+    E.best_costs[b] = s_k[b];
+  }
+}
+
 // argsort(costs)[:n_keep] by rank counting (ties -> lower index first)       gpet.py:443
 __global__ void __launch_bounds__(256) k_topk(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
@@ -4645,7 +4681,10 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
       hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
     }
   }
-  if (parts & 2u) hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  if (parts & 2u) {
+    if (bd.S <= 1024 && !getenv("GPET_TOPK_RANK")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
+    else hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  }
   return hipGetLastError();
 }
 
