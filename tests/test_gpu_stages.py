@@ -306,3 +306,38 @@ def test_gaussian_process_regressor_mirror_many_points(amd, ctx):
     pred = orc.gp_predict(fit, xq, want_cov=False)
     np.testing.assert_allclose(mean, pred["mean"], rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(std, pred["std"], rtol=1e-5, atol=1e-7)
+
+
+def test_topk_sort_and_rank_counting_agree_with_stable_argsort(amd, ctx, monkeypatch):
+    """Top-k of the curve costs (gpet.py:443): the bitonic sort of (cost, index) in LDS and the rank-counting kernel give
+    the indices and costs of numpy's stable argsort -- on costs with heavy ties, negative zeros and infinities, for sample
+    counts that are and are not powers of two."""
+    L = amd._lib
+    rng = np.random.default_rng(7)
+    for S in (64, 100, 1000):
+        img, truth = orc.synth_sinusoid_image(64, 1)
+        grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+        init = truth[[0, -1], :][:, [1, 0]]
+        tr = amd.GP_Edge_Tracing(init, grad, kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 8}, noise_y=1,
+                                 N_samples=S, score_thresh=1, delta_x=5, keep_ratio=0.25, pixel_thresh=3, seed=1,
+                                 fix_endpoints=True, _ctx=ctx)
+        b = tr._batch
+        b.fit_predict(want_cov=True); b.factor(); b.normals([3]); b.sample(); b.score()
+        n_keep = b.info()["n_keep"]
+        costs = np.round(rng.uniform(0.0, 4.0, size=S), 1)          # ~40 distinct values: ties everywhere
+        costs[rng.integers(0, S, size=3)] = np.inf
+        costs[rng.integers(0, S, size=3)] = 0.0
+        costs[rng.integers(0, S, size=2)] = -0.0
+        want = np.argsort(costs, kind="stable")[:n_keep]
+        for env in ("", "1"):
+            if env:
+                monkeypatch.setenv("GPET_TOPK_RANK", env)
+            else:
+                monkeypatch.delenv("GPET_TOPK_RANK", raising=False)
+            b.write(L.BUF_COSTS, costs)
+            b.profile_stage(141, 1)
+            got_idx = b.read(L.BUF_BEST_IDX)[:n_keep]
+            got_cost = b.read(L.BUF_BEST_COSTS)[:n_keep]
+            assert np.array_equal(got_idx, want), (S, env)
+            assert np.array_equal(got_cost, costs[want])
+        monkeypatch.delenv("GPET_TOPK_RANK", raising=False)
