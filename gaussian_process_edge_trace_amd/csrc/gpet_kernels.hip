@@ -2851,14 +2851,33 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
 #define SC_PAIRS 16
 #define SC_CURVES 1024
 #define SC_THREADS 1024
+// cross-lane moves of a double inside rows of 16 lanes by DPP (two v_mov_b32_dpp; __shfl_xor / __shfl_down with width 16
+// go through ds_bpermute and recompute the lane index every time): CTRL = row_ror:8 / row_ror:4 / quad_perm for the
+// butterfly, row_shl:1 for "the lane above" (lane 15 of a row keeps its own value, as __shfl_down does)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 16 lanes of a row, in every lane; the operands of every addition are those of the xor-8, 4, 2, 1 butterfly
+// (after the first step lanes i and i ^ 8 hold the same value, so a rotation by 4 brings what xor 4 would)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_row<0x128>(v);  // row_ror:8
+  v += dpp_row<0x124>(v);  // row_ror:4
+  v += dpp_row<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_row<0xB1>(v);   // quad_perm:[1,0,3,2]
+  return v;
+}
 __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
   y = y < 0.0 ? 0.0 : (y > (double)(M - 1) ? (double)(M - 1) : y);
-  int iy = (int)floor(y);
-  if (iy > M - 2) iy = M - 2;
-  if (iy < 0) iy = 0;
+  // (0 <= y <= M - 1 from here on, M >= 2: the row below is min(floor(y), M - 2) >= 0 and the row above is always inside
+  //  the column -- no further clamps; the kernel is bound by vector-ALU issue and this runs 2-3 times per curve pair)
+  int iy = (int)y;  // = floor(y) for y >= 0
+  iy = iy > M - 2 ? M - 2 : iy;
   const double w1 = y - (double)iy, w0 = ((double)iy + 1.0) - y;
-  const int iy1 = (iy + 1 < M) ? iy + 1 : M - 1;
-  return (double)col[iy] * w0 + (double)col[iy1] * w1;
+  return (double)col[iy] * w0 + (double)col[iy + 1] * w1;
 }
 
 __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
@@ -2919,8 +2938,8 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     const double r0 = rsqrt(q0), l0 = q0 * r0;
     const double g0 = grad_lds(s_img + (2 * pl) * ldm, M, y0) + 1e-3;
     const double g1 = grad_lds(s_img + (2 * pl + 1) * ldm, M, y1) + 1e-3;
-    double y2 = __shfl_down(y0, 1, 16), l2 = __shfl_down(l0, 1, 16), r2 = __shfl_down(r0, 1, 16);
-    double g2 = __shfl_down(g0, 1, 16);
+    double y2 = dpp_row<0x101>(y0), l2 = dpp_row<0x101>(l0), r2 = dpp_row<0x101>(r0);  // row_shl:1: the pair above
+    double g2 = dpp_row<0x101>(g0);
     double al = 0.0, li = 0.0;
     if (i < npair) {
       if (edge_lane) {
@@ -2939,11 +2958,8 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
       const double hsum = h0 + h1;
       li = hsum * (1.0 / 6.0) * (g0 * (2.0 - h1 * ih0) + g1 * (hsum * hsum * (ih0 * ih1)) + g2 * (2.0 - h0 * ih1));
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      al += __shfl_xor(al, o, 16);
-      li += __shfl_xor(li, o, 16);
-    }
+    al = row16_sum(al);
+    li = row16_sum(li);
     if (pl == 0 && live) {
       cpart[2 * s] = al;
       cpart[2 * s + 1] = li;
