@@ -20,6 +20,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// value of one lane (the same for the whole wave) in every lane: two v_readlane_b32 into scalar registers
+__device__ __forceinline__ double wave_bcast(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Sum over the whole workgroup; result returned to every thread.  sh: >= 16 doubles.
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -494,7 +502,7 @@ __global__ void __launch_bounds__(576) k_fit(EdgeDev* edges) {
 #pragma unroll 4
       for (int j = n - 1; j >= 0; --j) {
         const double* rj = K + (size_t)j * ld;
-        const double aj = __shfl((j < WAVE) ? z0 * ri0 : z1 * ri1, j & (WAVE - 1), WAVE);
+        const double aj = wave_bcast((j < WAVE) ? z0 * ri0 : z1 * ri1, j & (WAVE - 1));  // (uniform lane: v_readlane, no LDS permute)
         if (lane == (j & (WAVE - 1))) {
           if (j < WAVE) z0 = aj; else z1 = aj;
         }
