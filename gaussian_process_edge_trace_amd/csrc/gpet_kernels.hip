@@ -2334,7 +2334,7 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
 // blockIdx.x = how many iterations ahead of the edge's current one this stream belongs to: the
 // seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
 // generated by one launch, one workgroup per (iteration, edge).
-#define MTQ_CAP 512  // ring of pending (r2, x1, x2, destinations) records: < 64 left over + 156 per block + slack
+#define MTQ_CAP 256  // ring of pending (r2, x1, x2, destinations) records: < 64 left over + 156 per block = 219 at most
 __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
                                                     int iter_abs, int z_store) {
 #pragma clang fp contract(off)
