@@ -9,6 +9,7 @@
 
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "gpet_kernels.h"
@@ -84,6 +85,9 @@ struct gpet_batch {
   int big_chunk = 0, big_ncap = 0;
   void *big_vedges = nullptr, *big_vsc = nullptr;
   double *big_scratch = nullptr, *big_part = nullptr;  // pairs around every objective launch of a converged fit (gpet_lml_stats)
+  // largest lattice lag of every edge's converged-fit training set as the HOST knows it (fin_par[9..10] on the device):
+  // -1 = no lattice (caller-supplied x off any grid) -> the vector objective kernels; see fin_lattice()
+  std::vector<int> fin_lag;
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
 };
 
@@ -219,9 +223,38 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
 }
 }  // namespace
 
+// Lattice of a caller-supplied training set: h with x_i = x_min + m_i h (the smallest positive gap, refined over the
+// whole span), accepted when every point sits on it to 1e-6 of a step.  hinv = 1 / h; returns the largest lag or -1.
+static int fin_lattice(const double* x, int n, double* hinv) {
+  *hinv = 0.0;
+  if (n < 2) return -1;
+  double lo = x[0], hi = x[0];
+  for (int i = 1; i < n; ++i) {
+    lo = x[i] < lo ? x[i] : lo;
+    hi = x[i] > hi ? x[i] : hi;
+  }
+  std::vector<double> srt(x, x + n);
+  std::sort(srt.begin(), srt.end());
+  double gap = INFINITY;
+  for (int i = 1; i < n; ++i) {
+    const double d = srt[i] - srt[i - 1];
+    if (d > 0.0 && d < gap) gap = d;
+  }
+  if (!(gap < INFINITY) || !(hi > lo)) return -1;
+  const double span = hi - lo, mr = rint(span / gap);
+  if (!(mr >= 1.0 && mr < 1048576.0) || fabs(span / gap - mr) > 1e-6) return -1;
+  const double hi_ = mr / span;
+  for (int i = 0; i < n; ++i) {
+    const double t = (x[i] - x[0]) * hi_;
+    if (fabs(t - rint(t)) > 1e-6) return -1;
+  }
+  *hinv = hi_;
+  return (int)mr;
+}
+
 static int fetch_all_scalars(gpet_batch* b);
 static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const int* d_edge_of, const double* d_theta,
-                          double* d_f, double* d_g);
+                          double* d_f, double* d_g, const int* d_count = nullptr, int lag_cap = 0);
 
 extern "C" {
 
@@ -233,6 +266,12 @@ int gpet_set_option(const char* name, int value) {
     const int old = v;
     v = value < 1 ? 1 : value;
     return old > 0x3fffffff ? 0x3fffffff : old;
+  }
+  if (name && strcmp(name, "lml_mfma") == 0) {
+    int& v = gpet_opt_lml_mfma();
+    const int old = v;
+    v = value;
+    return old;
   }
   if (name && strcmp(name, "rng_lookahead") == 0) {
     int& v = gpet_opt_rng_lookahead();
@@ -1121,6 +1160,11 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
   HIPCHK(c, hipMemcpyAsync(E.fin_w, w, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   E.fin_n = n;
   HIPCHK(c, hipMemcpyAsync(b->d_edges + e, &E, sizeof E, hipMemcpyHostToDevice, c->stream));
+  double lat[2] = {0.0, 0.0};
+  b->fin_lag.resize(b->B, -1);
+  b->fin_lag[e] = fin_lattice(xs, n, &lat[0]);
+  lat[1] = (double)b->fin_lag[e];
+  HIPCHK(c, hipMemcpyAsync(E.fin_par + 9, lat, sizeof lat, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
@@ -1180,6 +1224,14 @@ int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* y
   HIPCHK(c, hipMemcpyAsync(b->d_fin_stage + 2 * blk, w, sizeof(double) * blk, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b->d_fin_n, n, sizeof(int) * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_fin_scatter(c->stream, b->d_edges, b->B, b->d_fin_stage, b->d_fin_n, stride));
+  std::vector<double> lat((size_t)2 * b->B);
+  b->fin_lag.resize(b->B, -1);
+  for (int e = 0; e < b->B; ++e) {
+    b->fin_lag[e] = fin_lattice(xs + (size_t)e * stride, n[e], &lat[2 * (size_t)e]);
+    lat[2 * (size_t)e + 1] = (double)b->fin_lag[e];
+  }
+  HIPCHK(c, hipMemcpy2DAsync(b->d_fin_par + 9, 12 * sizeof(double), lat.data(), 2 * sizeof(double), 2 * sizeof(double), b->B,
+                             hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }
@@ -1190,7 +1242,9 @@ int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, d
   HIPCHK(c, hipSetDevice(c->device));
   for (int e = 0; e < b->B; ++e)
     if (b->h_edges[e].fin_n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_predict_all before the training sets are set");
-  HIPCHK(c, hipMemcpyAsync(b->d_fin_par, par, sizeof(double) * 12 * b->B, hipMemcpyHostToDevice, c->stream));
+  // (slots 9..11 of every edge stay: the lattice of its training set)
+  HIPCHK(c, hipMemcpy2DAsync(b->d_fin_par, 12 * sizeof(double), par, 12 * sizeof(double), 9 * sizeof(double), b->B,
+                             hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_final_predict(c->stream, b->d_edges, b->B, b->bd));
   std::vector<double> host((size_t)b->B * 2 * b->bd.Lg);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1238,7 +1292,13 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
   }
   HIPCHK(c, hipEventRecord(b->ev_l0, b->fit));
   {
-    int rco = eval_objective(b, b->fit, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g);
+    // every training set of this call on a lattice the host knows -> tables of (largest lag + 1) entries
+    int lag_cap = 1;
+    for (int i = 0; i < P && lag_cap > 0; ++i) {
+      const int lg = (size_t)edge_of[i] < b->fin_lag.size() ? b->fin_lag[edge_of[i]] : -1;
+      lag_cap = lg < 0 ? 0 : (lg + 1 > lag_cap ? lg + 1 : lag_cap);
+    }
+    int rco = eval_objective(b, b->fit, P, n_max, b->d_edge_of, b->d_theta, b->d_f, b->d_g, nullptr, lag_cap);
     if (rco) return rco;
   }
   HIPCHK(c, hipEventRecord(b->ev_l1, b->fit));
@@ -1255,10 +1315,10 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
 // -log marginal likelihood + gradient of P problems on stream st: the register-tile kernels up to 250 training points,
 // the blocked HBM path (virtual edges, per-problem scratch, evaluated in chunks that fit a 6 GB budget) above.
 static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const int* d_edge_of, const double* d_theta,
-                          double* d_f, double* d_g) {
+                          double* d_f, double* d_g, const int* d_count, int lag_cap) {
   gpet_ctx* c = b->ctx;
   if (n_max <= 250) {
-    HIPCHK(c, launch_lml(st, b->d_edges, P, n_max, d_edge_of, d_theta, d_f, d_g));
+    HIPCHK(c, launch_lml(st, b->d_edges, P, n_max, d_edge_of, d_theta, d_f, d_g, d_count, lag_cap));
     return GPET_OK;
   }
   const int ncap_v = ((n_max + 63) / 64) * 64 + 64;
@@ -1333,10 +1393,23 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
       }
       b->lb_count = cv.take<int>(4);
       b->lb_seeds = cv.take<unsigned int>((size_t)B);
-      if (!pass) HIPCHK(c, hipMalloc(&b->lb_mem, cv.off + 256));
+      if (!pass) {
+        HIPCHK(c, hipMalloc(&b->lb_mem, cv.off + 256));
+        // slots beyond the true count of a round are never evaluated (the objective kernels read the count), but the
+        // blocked path above 250 points sizes its work by the host's bound: every slot must name a valid edge
+        HIPCHK(c, hipMemsetAsync(b->lb_mem, 0, cv.off + 256, b->fit));
+      }
     }
   }
   hipStream_t st = b->fit;
+  // the training x are pixel columns of the image: a lattice of fewer than N points (k_fin_prepare leaves the step and
+  // the largest lag in fin_par[9..10])
+  int lag_cap = b->bd.N > b->bd.Lg ? b->bd.N : b->bd.Lg;
+  for (int e = 0; e < B; ++e) {
+    const EdgeDev& E = b->h_edges[e];
+    if (E.x_st < 0 || E.x_en >= lag_cap) lag_cap = 0;  // (end points outside the image: no bound on the lags)
+  }
+  b->fin_lag.assign(B, lag_cap > 0 ? lag_cap - 1 : -1);
   HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
   HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride, b->bd.n_cap));
   HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0]));
@@ -1363,7 +1436,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
     }
     HIPCHK(c, hipEventRecord(b->lb_events[ev_used], st));
     {
-      int rco = eval_objective(b, st, n_upper, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g);
+      int rco = eval_objective(b, st, n_upper, n_max, b->lb_slot_edge[cur], b->lb_slot_theta[cur], b->lb_f, b->lb_g, cnt_cur, lag_cap);
       if (rco) return rco;
     }
     HIPCHK(c, hipEventRecord(b->lb_events[ev_used + 1], st));

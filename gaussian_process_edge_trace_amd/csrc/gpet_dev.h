@@ -79,7 +79,9 @@ struct EdgeDev {
   long long* binarg;     // [n_bins] order key of the best candidate per bin
   int bin_lo, fin_n;     // fin_n: training points of the converged fit
   double *fin_x, *fin_y, *fin_w;  // [n_cap] standardised training set of the converged fit (gpet.py:235-238)
-  // optimum + transforms of the converged fit: c, l, noise, X_m, X_s, y_m, y_s, m2, s2 (values, not logs)
+  // optimum + transforms of the converged fit: c, l, noise, X_m, X_s, y_m, y_s, m2, s2 (values, not logs);
+  // [9], [10]: lattice of fin_x (x_i = x_0 + m_i / hinv, m_i integer): hinv (0: none known) and the largest |m_i - m_j| --
+  // the matrix-core objective k_lml16 tabulates the correlation at the lags 0..lagmax
   double* fin_par;       // [12]
   double* fin_out;       // [2 * Lg_max] mean (pixels) then std, in the batch's contiguous output block      // bin index of the first slot (np.round((x - x_st)/delta_x) can be < 0)
 };

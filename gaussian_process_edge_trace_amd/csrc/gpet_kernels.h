@@ -68,7 +68,13 @@ size_t lmlbig_scratch_doubles(int ncap_v);
 hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
                           double* d_f, double* d_g, void* d_vedges, void* d_vsc, double* d_scratch, double* d_part,
                           int ncap_v);
+// d_count (may be null): device word with the true number of problems (workgroups beyond it return at once);
+// lag_cap > 0: every training set of the launch sits on a lattice (fin_par[9..10]) with fewer than lag_cap points -- the
+// matrix-core kernel k_lml16 and its correlation tables apply (n_max <= 108); 0: the vector kernels
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
-                      double* d_f, double* d_g);
+                      double* d_f, double* d_g, const int* d_count, int lag_cap);
+// gpet_set_option "lml_mfma" (default 1; environment GPET_LML_MFMA): 0 = objective of the converged fits on the
+// round-2 vector kernels (k_lml / k_lml2) also below 109 training points
+int& gpet_opt_lml_mfma();
 
 }  // namespace gpet

@@ -3731,8 +3731,9 @@ __device__ __forceinline__ void corr_and_dlog(const EdgeDev& E, double a, double
 // workgroup per CU) of a Cholesky + triangular inverse; LDS use is ~3 KB so several problems share a CU.
 #define LML_MAXD 136  // 4 * ceil((128 + 1) / 4) + slack
 __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
-                                             double* g_out) {
+                                             double* g_out, const int* count) {
   const int pb = blockIdx.x;
+  if (count != nullptr && pb >= *count) return;  // (launches are sized by the host's last KNOWN number of running problems)
   const EdgeDev E = edges[edge_of[pb]];
   const int n = E.fin_n;
   const int nb = (n + 1 + 3) >> 2;  // 4x4 tiles per side of the bordered matrix
@@ -3891,9 +3892,10 @@ __global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))
 // 63 x 64 / 2 = 2016 tiles on 1024 threads.  Kept separate so that the common sizes keep their lean single-tile code.
 #define LML2_MAXD 260
 __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
-                                               double* g_out) {
+                                               double* g_out, const int* count) {
   constexpr int SLOTS = 2;  // (three and four tiles per thread were measured: 163 / 203 VGPRs, 6-40 % slower)
   const int pb = blockIdx.x;
+  if (count != nullptr && pb >= *count) return;
   const EdgeDev E = edges[edge_of[pb]];
   const int n = E.fin_n;
   const int nb = (n + 1 + 3) >> 2;
@@ -4064,10 +4066,495 @@ __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_o
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// f2 on the matrix cores (round 3; n <= 108 training points on a lattice): the same symmetric sweep of the bordered
+// matrix, FOUR pivots at a time, on 16x16 tiles of v_mfma_f64_16x16x4_f64.
+//
+// Layout of the bordered matrix (size n4 + 1 <= 112, n4 = n rounded up to a multiple of 4): indices 0..n-1 = K,
+// n..n4-1 = identity padding (pivots 1: log 1 = 0, no coupling), n4 = the y border (never a pivot), the rest zero.
+// The lower triangle of 16x16 tiles (diagonal tiles whole) lives in the accumulator registers of TWO waves: wave
+// `role` owns the tile rows I_g = 6 - 2 g - role, g = 0..3, i.e. {6, 4, 2, 0} and {5, 3, 1} (16 and 12 tiles).  ONE
+// instruction stream serves both: 16 static accumulator slots (g, J), J < 7 - 2 g, whose tile row is a scalar of the
+// wave; slot (g, J) is in use when J <= I_g.  (Two streams with exactly 14 tiles each were built first: the register
+// allocator kept both sets of accumulators apart -- 224 + 165 registers, one wave per SIMD.)
+// f64 C/D layout: lane (q = l >> 4, col = l & 15), register r holds element (row q + 4 r, column col) of its tile;
+// A operand: lane holds A[row = col][k = q], B operand: B[k = q][column = col].
+//
+// A block step for the pivots k0..k0+3 (tile Jp, sub-block B; W = columns k0..k0+3 of the matrix = the PANEL, in LDS
+// k-major, copied out of the tiles at the end of the previous step; P = its rows k0..k0+3):
+//   P = L D L^T in every lane (the four pivots d are the squared Cholesky diagonal in the scalar order); lane group q
+//   solves P z = e_q, i.e. owns column q of P^-1;
+//   the sweep  T <- T - (W P^-1) W^T  is one MFMA per tile with A = -(W P^-1) rows of the tile row, B = W rows of the
+//   tile column;
+//   the pivot rows must become (W P^-1)^T: in the tile row of the pivots the A operand of the four pivot rows is
+//   (P^-1 - I) instead, so the MFMA yields  T_pj - W_jp + (W P^-1)_jp  and the first two cancel exactly (W_jp was copied
+//   from that very register);
+//   the pivot columns (tile column Jp below the diagonal tile) get the same treatment through the TRANSPOSED product,
+//   A = W rows, B = that modified operand;
+//   only the diagonal tile needs registers touched: its pivot columns are the transpose of its (now exact) pivot rows
+//   (cross-lane permute), the 4x4 block itself becomes -P^-1;
+//   the next panel is copied into the other panel buffer; ONE workgroup barrier per step.
+// n^3 / 2 FMAs of the scalar sweep become 25 x 28 MFMAs (1024 FMAs each, 68 % useful at n = 98).  The training x sit on
+// a lattice (pixel columns), so the correlation and its length-scale derivative are tabulated at the integer lags once
+// per problem: lagmax + 1 transcendentals instead of n^2 for the set-up and n^2 more for the gradient.
+// ---------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define L16_WS 112    // row stride of the panel planes in doubles: = 16 mod 32, so the four k-planes of an operand read fall on disjoint banks
+#define L16_MAXN 108  // 4 * ceil(n / 4) + 1 <= 112
+#define L16_NT 7
+#define L16_LAG_MAX 4096  // longest correlation table (2 x 32 KB of LDS per problem)
+#define L16_NG 4
+#define L16_NS 16
+__host__ __device__ constexpr int l16_sg(int t) { return t < 7 ? 0 : (t < 12 ? 1 : (t < 15 ? 2 : 3)); }  // slot -> group
+__host__ __device__ constexpr int l16_sj(int t) { return t < 7 ? t : (t < 12 ? t - 7 : (t < 15 ? t - 12 : 0)); }  // slot -> tile column
+
+struct L16Shared {
+  double Wt[2][4][L16_WS];  // panel of the current / next block step, k-major
+  double Wm[2][4][L16_WS];  // per wave: W P^-1 of the pivot tile row (16 entries per plane), for the transpose inside the diagonal tile
+  double al[L16_WS];        // alpha (row n4 of the swept matrix)
+  double y[L16_WS], w[L16_WS];
+  double piv[L16_WS];
+  int m[L16_WS];            // lattice coordinate of training point i
+  double red[8];
+};
+
+__device__ __forceinline__ double l16_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = r * (2.0 - d * r);
+  r = r * (2.0 - d * r);
+  return r;
+}
+
+__device__ __forceinline__ double l16_sel(const v4d& a, int r) {
+  return r == 0 ? a[0] : (r == 1 ? a[1] : (r == 2 ? a[2] : a[3]));
+}
+
+struct L16Acc {
+  v4d v[L16_NS];
+};
+
+// copy the panel of pivot block (Jn, BN) out of the tiles: W[row][a] = A[row][16 Jn + 4 BN + a].  Per tile row of the wave at
+// most ONE tile has the panel's columns (tile column Jn: a scalar jump picks its slot) and at most one tile row has its
+// rows (the tile row Jn itself, whose register BN holds the panel rows of the tile columns left of it, by symmetry).
+#define L16_COLPART(vt)                \
+  if (pcn) {                           \
+    wc[0] = (vt)[0];                   \
+    wc[4] = (vt)[1];                   \
+    wc[8] = (vt)[2];                   \
+    wc[12] = (vt)[3];                  \
+  }
+template <int BN, int G>
+__device__ __forceinline__ void l16_extract_group(const L16Acc& A, double* Wn, int Jn, int role, int q, int col) {
+  constexpr int base = G == 0 ? 0 : (G == 1 ? 7 : (G == 2 ? 12 : 15)), cap = 7 - 2 * G;
+  const int I = 6 - 2 * G - role;
+  if (I < Jn) return;  // (tile row above the pivots: its panel rows come out of tile row Jn)
+  const bool pcn = (col >> 2) == BN;
+  double* wc = Wn + (col & 3) * L16_WS + 16 * I + q;
+  switch (Jn) {
+    case 0: L16_COLPART(A.v[base]) break;
+    case 1: if (cap > 1) L16_COLPART(A.v[base + (cap > 1 ? 1 : 0)]) break;
+    case 2: if (cap > 2) L16_COLPART(A.v[base + (cap > 2 ? 2 : 0)]) break;
+    case 3: if (cap > 3) L16_COLPART(A.v[base + (cap > 3 ? 3 : 0)]) break;
+    case 4: if (cap > 4) L16_COLPART(A.v[base + (cap > 4 ? 4 : 0)]) break;
+    case 5: if (cap > 5) L16_COLPART(A.v[base + (cap > 5 ? 5 : 0)]) break;
+    default: if (cap > 6) L16_COLPART(A.v[base + (cap > 6 ? 6 : 0)]) break;
+  }
+  if (I == Jn) {
+    double* wr = Wn + q * L16_WS + col;
+#pragma unroll
+    for (int J = 0; J + 1 < cap; ++J)
+      if (J < Jn) wr[16 * J] = A.v[base + J][BN];
+  }
+}
+template <int BN>
+__device__ __forceinline__ void l16_extract(const L16Acc& A, double* Wn, int Jn, int role, int q, int col) {
+  l16_extract_group<BN, 0>(A, Wn, Jn, role, q, col);
+  l16_extract_group<BN, 1>(A, Wn, Jn, role, q, col);
+  l16_extract_group<BN, 2>(A, Wn, Jn, role, q, col);
+  l16_extract_group<BN, 3>(A, Wn, Jn, role, q, col);
+}
+
+#ifdef GPET_L16_PROF  // cycles per phase of a block step (wave 0 of workgroup 0 prints them)
+#define L16_STAMP(i) { const long long t_ = clock64(); prof[i] += t_ - tl; tl = t_; }
+#else
+#define L16_STAMP(i)
+#endif
+// one block step (pivots 16 Jp + 4 B ..); false: a pivot was not positive
+template <int B>
+__device__ __forceinline__ bool l16_step(L16Acc& A, L16Shared& S, int Jp, int n4, int role, int q, int col
+#ifdef GPET_L16_PROF
+                                         , long long* prof, long long& tl
+#endif
+) {
+  constexpr int buf = B & 1;  // (four steps per tile: the parity of the step is the parity of B)
+  const int k0 = 16 * Jp + 4 * B;
+  const double* W = &S.Wt[buf][0][0];
+  // P = [[Pa, Pb^T], [Pb, Pc]] in 2x2 blocks (uniform: every lane reads the same ten entries); block elimination:
+  // Pa^-1 by its adjugate, X = Pb Pa^-1, S = Pc - X Pb^T, S^-1 by its adjugate.  Half the dependent chain of four scalar
+  // pivots; det Pa and det S are the products of the scalar pivots (d0 d1 and d2 d3), their signs with those of p00 and
+  // s22 the leading minors.
+  const double p00 = W[k0], p10 = W[k0 + 1], p20 = W[k0 + 2], p30 = W[k0 + 3];
+  const double p11 = W[L16_WS + k0 + 1], p21 = W[L16_WS + k0 + 2], p31 = W[L16_WS + k0 + 3];
+  const double p22 = W[2 * L16_WS + k0 + 2], p32 = W[2 * L16_WS + k0 + 3];
+  const double p33 = W[3 * L16_WS + k0 + 3];
+  const double detA = fma(p00, p11, -(p10 * p10));
+  const double rA = l16_rcp(detA);
+  const double x20 = fma(p20, p11, -(p21 * p10)) * rA, x21 = fma(p21, p00, -(p20 * p10)) * rA;
+  const double x30 = fma(p30, p11, -(p31 * p10)) * rA, x31 = fma(p31, p00, -(p30 * p10)) * rA;
+  const double s22 = fma(-x21, p21, fma(-x20, p20, p22));
+  const double s32 = fma(-x31, p21, fma(-x30, p20, p32));
+  const double s33 = fma(-x31, p31, fma(-x30, p30, p33));
+  const double detS = fma(s22, s33, -(s32 * s32));
+  const double rS = l16_rcp(detS);
+  const bool ok = p00 > 0.0 && detA > 0.0 && s22 > 0.0 && detS > 0.0;  // (the same in every lane of both waves)
+  if (role == 0 && (q | col) == 0) {  // log|K| = sum log sqrt(piv): the pivots pairwise
+    S.piv[k0] = detA;
+    S.piv[k0 + 1] = 1.0;
+    S.piv[k0 + 2] = detS;
+    S.piv[k0 + 3] = 1.0;
+  }
+  // column q of P^-1:  y_l = e_l - X e_u,  z_l = S^-1 y_l,  z_u = Pa^-1 e_u - X^T z_l
+  const double eu0 = (q == 0) ? 1.0 : 0.0, eu1 = (q == 1) ? 1.0 : 0.0;
+  const double yl0 = fma(-x21, eu1, fma(-x20, eu0, (q == 2) ? 1.0 : 0.0));
+  const double yl1 = fma(-x31, eu1, fma(-x30, eu0, (q == 3) ? 1.0 : 0.0));
+  const double z2 = fma(s33, yl0, -(s32 * yl1)) * rS;
+  const double z3 = fma(s22, yl1, -(s32 * yl0)) * rS;
+  const double au0 = fma(p11, eu0, -(p10 * eu1)) * rA, au1 = fma(p00, eu1, -(p10 * eu0)) * rA;
+  const double z0 = fma(-x30, z3, fma(-x20, z2, au0));
+  const double z1 = fma(-x31, z3, fma(-x21, z2, au1));
+  const bool pc = (col >> 2) == B;  // this lane's row (A operand) / column (tile) index is one of the pivots
+  const int kc = col & 3;
+  const double zs = kc == 0 ? z0 : (kc == 1 ? z1 : (kc == 2 ? z2 : z3));  // P^-1[kc][q]
+  const int lb = q * L16_WS + col;
+  L16_STAMP(0)
+  // B operands: W rows of every tile column (plain); A operands: -(W P^-1) rows of the wave's own tile rows, and W rows
+  // of those tile rows for the transposed product.  No branches: tile rows beyond the matrix hold zeros or stale values
+  // that only ever reach tiles nobody reads.
+  double bop[L16_NT], aop[L16_NG], wpl[L16_NG];
+#pragma unroll
+  for (int J = 0; J < L16_NT; ++J) bop[J] = W[lb + 16 * J];
+#pragma unroll
+  for (int g = 0; g < L16_NG; ++g) {
+    const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);  // (role 1 has no fourth tile row: a harmless duplicate of row 0)
+    const double* wr = W + 16 * I + col;
+    double s = wr[0] * z0;
+    s = fma(wr[L16_WS], z1, s);
+    s = fma(wr[2 * L16_WS], z2, s);
+    s = fma(wr[3 * L16_WS], z3, s);
+    aop[g] = -s;
+    wpl[g] = W[lb + 16 * I];
+  }
+  // the operand of the pivot tile row: (P^-1 - I) in the pivot rows (both waves need it: as A in tile row Jp, as B in
+  // tile column Jp); its plain form W P^-1 goes through LDS to the lanes that own the pivot columns of the diagonal tile
+  double am;
+  {
+    const double* wr = W + 16 * Jp + col;
+    double s = wr[0] * z0;
+    s = fma(wr[L16_WS], z1, s);
+    s = fma(wr[2 * L16_WS], z2, s);
+    s = fma(wr[3 * L16_WS], z3, s);
+    S.Wm[role][0][lb] = s;
+    am = pc ? (zs - ((kc == q) ? 1.0 : 0.0)) : -s;
+  }
+  const double* wp = &S.Wm[role][kc][q];
+  const double d0 = wp[0], d1 = wp[4], d2 = wp[8], d3 = wp[12];  // (W P^-1)[16 Jp + q + 4 r][kc]
+  L16_STAMP(1)
+  // one MFMA per tile
+#pragma unroll
+  for (int t = 0; t < L16_NS; ++t) {
+    const int g = l16_sg(t), J = l16_sj(t);
+    if (J + 2 * g == 6) continue;  // (the last slot of each group belongs to role 0 only: below)
+    const int I = 6 - 2 * g - role;
+    const bool tr = (J == Jp) && (I != Jp);  // tile column of the pivots, below the diagonal tile: transposed product
+    const double a = tr ? wpl[g] : ((I == Jp) ? am : aop[g]);
+    const double b = tr ? am : bop[J];
+    A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, A.v[t], 0, 0, 0);
+  }
+  if (role == 0) {
+#pragma unroll
+    for (int t = 0; t < L16_NS; ++t) {
+      const int g = l16_sg(t), J = l16_sj(t);
+      if (J + 2 * g != 6) continue;
+      const int I = 6 - 2 * g;  // (= J: the diagonal tiles of role 0)
+      const double a = (I == Jp) ? am : aop[g];
+      A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[J], A.v[t], 0, 0, 0);
+    }
+  }
+  L16_STAMP(2)
+  // diagonal tile of the pivots (slot (g, 6 - 2 g - role) of the group whose tile row is Jp): columns <- W P^-1 rows of the
+  // tile row, block <- -P^-1
+#define L16_DIAGFIX(vt)                     \
+  if (pc) {                                 \
+    (vt)[0] = (B == 0) ? -zs : d0;          \
+    (vt)[1] = (B == 1) ? -zs : d1;          \
+    (vt)[2] = (B == 2) ? -zs : d2;          \
+    (vt)[3] = (B == 3) ? -zs : d3;          \
+  }
+  {
+    const int gs2 = 6 - role - Jp;  // = 2 g of that group, if this wave has it
+    if (role == 0) {
+      if (gs2 == 0) L16_DIAGFIX(A.v[6])
+      else if (gs2 == 2) L16_DIAGFIX(A.v[11])
+      else if (gs2 == 4) L16_DIAGFIX(A.v[14])
+      else if (gs2 == 6) L16_DIAGFIX(A.v[15])
+    } else {
+      if (gs2 == 0) L16_DIAGFIX(A.v[5])
+      else if (gs2 == 2) L16_DIAGFIX(A.v[10])
+      else if (gs2 == 4) L16_DIAGFIX(A.v[13])
+    }
+  }
+  L16_STAMP(3)
+  // next panel
+  if (k0 + 4 < n4) l16_extract<(B + 1) & 3>(A, &S.Wt[buf ^ 1][0][0], B == 3 ? Jp + 1 : Jp, role, q, col);
+  L16_STAMP(4)
+  return ok;
+}
+
+__device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n, int n4, int nt, double c, double nl, int pb,
+                                        double* f_out, double* g_out) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, col = lane & 15;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  L16Acc A;
+#ifdef GPET_L16_PROF
+  const long long t_entry = clock64();
+#endif
+  // tiles.  First every slot as if it were an off-diagonal tile of training points: correlation from the table only, all
+  // loads independent of each other (the lattice coordinates are zero beyond the training set: any lag is inside the
+  // table).  Then the special tiles again, properly: diagonal tiles and the tile row with the padding and the border.
+  {
+    int mi[L16_NG][4], mjv[L16_NT];
+#pragma unroll
+    for (int g = 0; g < L16_NG; ++g) {
+      const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mi[g][r] = S.m[16 * I + q + 4 * r];
+    }
+#pragma unroll
+    for (int J = 0; J < L16_NT; ++J) mjv[J] = S.m[16 * J + col];
+#pragma unroll
+    for (int t = 0; t < L16_NS; ++t) {
+      const int g = l16_sg(t), J = l16_sj(t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) A.v[t][r] = c * tab[abs(mi[g][r] - mjv[J])].x;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < L16_NS; ++t) {
+    const int I = 6 - 2 * l16_sg(t) - role, J = l16_sj(t);
+    const int j = 16 * J + col;
+    if (!(J < I && 16 * I + 16 <= n)) {
+      // every candidate value is loaded (the arrays are zero beyond the training set) and the right one selected -- no
+      // divergent branches
+      const double yj = S.y[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * I + q + 4 * r;
+        const int ic = (ii >= 0 && ii < L16_WS) ? ii : 0;
+        const double dg = (c + nl * S.w[ic]) + 1e-6;
+        const double yi = S.y[ic];
+        const bool in = ii < n && j < n;
+        double v = in ? (ii == j ? dg : A.v[t][r]) : 0.0;
+        v = (!in && ii == j && ii < n4) ? 1.0 : v;
+        v = (ii == n4 && j < n) ? yj : v;
+        v = (j == n4 && ii < n) ? yi : v;
+        A.v[t][r] = (J <= I) ? v : 0.0;
+      }
+    }
+  }
+  l16_extract<0>(A, &S.Wt[0][0][0], 0, role, q, col);
+  __syncthreads();
+  bool ok = true;
+#ifdef GPET_L16_PROF
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tl = clock64();
+  const long long t_begin = tl;
+#define L16_PROF_ARGS , prof, tl
+#else
+#define L16_PROF_ARGS
+#endif
+  for (int Jp = 0; 16 * Jp < n4; ++Jp) {
+    ok = l16_step<0>(A, S, Jp, n4, role, q, col L16_PROF_ARGS) && ok;
+    __syncthreads();
+    L16_STAMP(5)
+    if (16 * Jp + 4 < n4) ok = l16_step<1>(A, S, Jp, n4, role, q, col L16_PROF_ARGS) && ok;
+    __syncthreads();
+    L16_STAMP(5)
+    if (16 * Jp + 8 < n4) ok = l16_step<2>(A, S, Jp, n4, role, q, col L16_PROF_ARGS) && ok;
+    __syncthreads();
+    L16_STAMP(5)
+    if (16 * Jp + 12 < n4) ok = l16_step<3>(A, S, Jp, n4, role, q, col L16_PROF_ARGS) && ok;
+    __syncthreads();
+    L16_STAMP(5)
+  }
+#ifdef GPET_L16_PROF
+  const long long t_loop_end = clock64();
+#endif
+  if (!ok) {  // sklearn returns (-inf, 0) -> objective (+inf, -0)
+    if (threadIdx.x == 0) {
+      f_out[pb] = INFINITY;
+      g_out[3 * pb] = g_out[3 * pb + 1] = g_out[3 * pb + 2] = 0.0;
+    }
+    return;
+  }
+  // alpha = row n4 of the swept matrix, its corner = -y^T alpha
+  const int It = n4 >> 4, rq = n4 & 15, qs = rq & 3, rs = rq >> 2;
+#pragma unroll
+  for (int t = 0; t < L16_NS; ++t) {
+    const int I = 6 - 2 * l16_sg(t) - role, J = l16_sj(t);
+    if (I == It && J <= I) {
+      const double v = l16_sel(A.v[t], rs);
+      if (q == qs) S.al[16 * J + col] = v;
+    }
+  }
+  __syncthreads();
+  const double* al = S.al;
+  double ld = 0.0;
+  if (role == 0)
+    for (int k = lane; k < n; k += 64) ld += log(sqrt(S.piv[k]));
+  // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij; off-diagonal tiles stand for both triangles.
+  // sR, sD: sums of inner_ij R_ij and inner_ij dR_ij over i != j (c applied at the end); gd, gn: the diagonal terms.
+  // Same two passes as the set-up: every slot that is an off-diagonal tile of training points without a branch inside,
+  // then the special tiles element by element with selects.
+  double sR = 0.0, sD = 0.0, gd = 0.0, gn = 0.0;
+  double ai[L16_NG][4];
+  int mi[L16_NG][4], mjv[L16_NT];
+#pragma unroll
+  for (int g = 0; g < L16_NG; ++g) {
+    const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ai[g][r] = al[16 * I + q + 4 * r];
+      mi[g][r] = S.m[16 * I + q + 4 * r];
+    }
+  }
+#pragma unroll
+  for (int J = 0; J < L16_NT; ++J) mjv[J] = S.m[16 * J + col];
+#pragma unroll
+  for (int t = 0; t < L16_NS; ++t) {
+    const int g = l16_sg(t), J = l16_sj(t);
+    const int I = 6 - 2 * g - role;
+    const int j = 16 * J + col;
+    const double aj = al[j];
+    if (J < I && 16 * I + 16 <= n) {  // (all rows and columns are training points, none on the diagonal)
+      double tR = 0.0, tD = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double inner = fma(ai[g][r], aj, A.v[t][r]);  // T = -Kinv
+        const double2 rd = tab[abs(mi[g][r] - mjv[J])];
+        tR = fma(inner, rd.x, tR);
+        tD = fma(inner, rd.y, tD);
+      }
+      sR = fma(2.0, tR, sR);
+      sD = fma(2.0, tD, sD);
+    } else if (J <= I) {
+      const double wt = (I == J) ? 1.0 : 2.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * I + q + 4 * r;
+        const int ic = (ii >= 0 && ii < L16_WS) ? ii : 0;
+        const double inner = fma(ai[g][r], aj, A.v[t][r]);
+        const double2 rd = tab[abs(mi[g][r] - mjv[J])];
+        const bool in = ii < n && j < n;
+        const bool dg = in && ii == j, od = in && ii != j;
+        gd += dg ? inner : 0.0;
+        gn += dg ? inner * (nl * S.w[ic]) : 0.0;
+        sR += od ? wt * inner * rd.x : 0.0;
+        sD += od ? wt * inner * rd.y : 0.0;
+      }
+    }
+  }
+  double gc = c * (sR + gd), gl = c * sD;
+  ld = wave_sum(ld);
+  gc = wave_sum(gc);
+  gl = wave_sum(gl);
+  gn = wave_sum(gn);
+  if (role == 1 && lane == 0) {
+    S.red[0] = gc;
+    S.red[1] = gl;
+    S.red[2] = gn;
+  }
+  __syncthreads();
+#ifdef GPET_L16_PROF
+  if (blockIdx.x == 0 && lane == 0)
+    printf("l16 role %d: set-up %lld, loop %lld (solve %lld, operands %lld, mfma %lld, diag %lld, extract %lld, barrier %lld), epilogue %lld cycles\n",
+           role, (long long)(t_begin - t_entry), (long long)(t_loop_end - t_begin), prof[0], prof[1], prof[2], prof[3], prof[4], prof[5],
+           (long long)(clock64() - t_loop_end));
+#endif
+  if (threadIdx.x == 0) {
+    gc += S.red[0];
+    gl += S.red[1];
+    gn += S.red[2];
+    const double yta = -al[n4];
+    const double lml = -0.5 * yta - ld - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    f_out[pb] = -lml;
+    g_out[3 * pb] = -0.5 * gc;
+    g_out[3 * pb + 1] = -0.5 * gl;
+    g_out[3 * pb + 2] = -0.5 * gn;
+  }
+}
+
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lml16(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+                                               double* g_out, const int* count, int lag_cap) {
+  const int pb = blockIdx.x;
+#ifdef GPET_L16_PROF
+  const long long t_kernel = clock64();
+#endif
+  if (count != nullptr && pb >= *count) return;  // (launches are sized by the host's last KNOWN number of running problems)
+  const EdgeDev E = edges[edge_of[pb]];
+  const int n = E.fin_n;
+  const int n4 = (n + 3) & ~3;
+  const int nt = (n4 + 1 + 15) >> 4;
+  __shared__ L16Shared S;
+  extern __shared__ double2 l16_tab[];  // [lag_cap]: (correlation, d/dlog(length scale)) at the lattice lags
+  const int tid = threadIdx.x;
+  const double c = exp(theta[3 * pb]), ell = exp(theta[3 * pb + 1]), nl = exp(theta[3 * pb + 2]);
+  const double hinv = E.fin_par[9];
+  const int lagmax = (int)E.fin_par[10];
+  if (!(hinv > 0.0) || lagmax < 0 || lagmax >= lag_cap || n > L16_MAXN) {  // the host routes such sets to k_lml / k_lml2: fail loudly
+    if (tid == 0) {
+      f_out[pb] = NAN;
+      g_out[3 * pb] = g_out[3 * pb + 1] = g_out[3 * pb + 2] = 0.0;
+      E.sc->status = GPET_ERR_STATE;
+    }
+    return;
+  }
+  const double x0 = E.fin_x[0];
+  for (int i = tid; i < L16_WS; i += 128) {
+    const bool in = i < n;
+    S.y[i] = in ? E.fin_y[i] : 0.0;
+    S.w[i] = in ? E.fin_w[i] : 0.0;
+    S.m[i] = in ? (int)rint((E.fin_x[i] - x0) * hinv) : 0;
+    S.piv[i] = 1.0;
+    S.al[i] = 0.0;
+  }
+  // the zero fill of both panel buffers: rows beyond the matrix are never written but are read as operands of tiles
+  // nobody uses
+  for (int i = tid; i < 2 * 4 * L16_WS; i += 128) (&S.Wt[0][0][0])[i] = 0.0;
+  // the correlation as sklearn evaluates it for two inputs a lag apart: a = x_i / l, b = x_j / l, d = a - b
+  for (int m = tid; m <= lagmax; m += 128) {
+    double R, dR;
+    corr_and_dlog(E, ((double)m / hinv) / ell, 0.0, R, dR);
+    l16_tab[m] = make_double2(R, dR);
+  }
+  __syncthreads();
+#ifdef GPET_L16_PROF
+  if (blockIdx.x == 0 && tid == 0) printf("l16 staging + table: %lld cycles\n", (long long)(clock64() - t_kernel));
+#endif
+  l16_run(S, l16_tab, n, n4, nt, c, nl, pb, f_out, g_out);
+}
+
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
-                      double* d_f, double* d_g) {
+                      double* d_f, double* d_g, const int* d_count, int lag_cap) {
   (void)hipGetLastError();
   if (n_max > 250) return hipErrorInvalidValue;
+  // up to 108 training points on a lattice (lag_cap > 0: every training set of the launch sits on one with fewer than
+  // lag_cap points; the caller knows): the block sweep on the matrix cores, two waves per problem, correlation tables
+  // of lag_cap entries in dynamic LDS
+  if (n_max <= L16_MAXN && lag_cap > 0 && lag_cap <= L16_LAG_MAX && gpet_opt_lml_mfma()) {
+    const size_t dyn = (size_t)2 * lag_cap * sizeof(double);
+    hipLaunchKernelGGL(k_lml16, dim3(P), dim3(128), dyn, st, d_edges, d_edge_of, d_theta, d_f, d_g, d_count, lag_cap);
+    return hipGetLastError();
+  }
   // two tiles per thread: the only form above 128 training points, and the faster one for big launches (fewer
   // instructions per problem: 109 instead of 134 us at 900 problems of 98 points, 1.07 instead of 1.41 ms at 13312) --
   // small launches are latency-bound and keep one tile per thread (64 instead of 80 us at 256 problems)
@@ -4076,12 +4563,12 @@ hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const 
     const int tiles = nb2 * (nb2 + 1) / 2;
     int threads = (((tiles + 1) / 2 + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
-    hipLaunchKernelGGL(k_lml2, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+    hipLaunchKernelGGL(k_lml2, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g, d_count);
     return hipGetLastError();
   }
   const int nb = (n_max + 1 + 3) >> 2;
   const int threads = ((nb * (nb + 1) / 2 + 63) / 64) * 64;  // one thread per 4x4 tile of the lower triangle
-  hipLaunchKernelGGL(k_lml, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g);
+  hipLaunchKernelGGL(k_lml, dim3(P), dim3(threads), 0, st, d_edges, d_edge_of, d_theta, d_f, d_g, d_count);
   return hipGetLastError();
 }
 
@@ -4421,6 +4908,11 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
 
 int& gpet_opt_lml_two_tiles_from() {
   static int v = getenv("GPET_LML_TWO_TILES_FROM") != nullptr ? atoi(getenv("GPET_LML_TWO_TILES_FROM")) : 600;
+  return v;
+}
+
+int& gpet_opt_lml_mfma() {
+  static int v = getenv("GPET_LML_MFMA") != nullptr ? atoi(getenv("GPET_LML_MFMA")) : 1;
   return v;
 }
 

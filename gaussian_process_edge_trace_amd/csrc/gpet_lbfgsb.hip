@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(64) k_fin_prepare(EdgeDev* edges, int B, const
     tmp[i] = v * v;
   }
   const double X_s = sqrt(np_pairwise_sum(tmp, n) / dn);
+  const double lagmax = xs[n - 1] - xs[0];  // pixel columns: fin_x sits on a lattice of step 1 / X_s (k_lml16 tabulates the correlation per lag)
   for (int i = 0; i < n; ++i) {
     ys[i] = (ys[i] - y_m) / y_s;
     xs[i] = (xs[i] - X_m) / X_s;
@@ -637,6 +638,8 @@ __global__ void __launch_bounds__(64) k_fin_prepare(EdgeDev* edges, int B, const
   par[6] = y_s;
   par[7] = m2;
   par[8] = s2;
+  par[9] = X_s;
+  par[10] = lagmax;
   Eg.fin_n = n;
   // start points: theta of the kernel (gpet.py:244-245), then lo + (hi - lo) * RandomState(seed).uniform(size=(12, 3))
   double lo[3], hi[3];
@@ -829,6 +832,8 @@ __global__ void __launch_bounds__(64) k_fin_prepare_wave(EdgeDev* edges, int B, 
     par[7] = m2;
     par[8] = s2;
     Eg.fin_n = n;
+    par[9] = X_s;  // pixel columns: fin_x sits on a lattice of step 1 / X_s (k_lml16 tabulates the correlation per lag)
+    par[10] = sx[n - 1] - sx[0];
     // MT19937 init_genrand(seed); the first 72 outputs need state words 0..72 and 397..468 of the first twist only
     s_key[0] = seeds[e];
     for (int i = 1; i < 470; ++i) s_key[i] = 1812433253u * (s_key[i - 1] ^ (s_key[i - 1] >> 30)) + (unsigned int)i;

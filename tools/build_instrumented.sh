@@ -1,7 +1,7 @@
 #!/bin/bash
 # An instrumented copy of the library next to the product one (which stays as built by __graft_entry__.build()):
 #   tools/build_instrumented.sh -DGPET_JAC_PROF            -> gpurun_scratch/libgpet_prof.so
-#   GPET_LIB_PATH=$PWD/gpurun_scratch/libgpet_prof.so python tests/tools/prof_jacobi.py 1 256 1024
+#   GPET_LIB_PATH=$PWD/gpurun_scratch/libgpet_prof.so python tools/prof_jacobi.py 1 256 1024
 # Switches (csrc/gpet_kernels.hip): GPET_JAC_PROF (cycles per phase of a Jacobi round), GPET_JAC_TRACE (off-norm and
 # largest relative coupling per sweep), GPET_SH_PROF / GPET_FIT_PROF (cycles per phase of k_struct_H / k_fit),
 # GPET_GEMM_EXP=1 (sample GEMM without its stores), GPET_NO_XCD_REMAP (plain workgroup -> (edge, part) mapping).

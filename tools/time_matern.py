@@ -1,5 +1,5 @@
 """Timing of the full-rank (Matern) path at BASELINE config 5's frame shape: factor ms for one edge and for a batch,
-whole frame on the GPU and in the CPU oracle.  usage: python tests/tools/time_matern.py [N] [B] [--oracle]"""
+whole frame on the GPU and in the CPU oracle.  usage: python tools/time_matern.py [N] [B] [--oracle]"""
 import os
 import sys
 import time
