@@ -4110,7 +4110,6 @@ __host__ __device__ constexpr int l16_sj(int t) { return t < 7 ? t : (t < 12 ? t
 
 struct L16Shared {
   double Wt[2][4][L16_WS];  // panel of the current / next block step, k-major
-  double Wm[2][4][L16_WS];  // per wave: W P^-1 of the pivot tile row (16 entries per plane), for the transpose inside the diagonal tile
   double al[L16_WS];        // alpha (row n4 of the swept matrix)
   double y[L16_WS], w[L16_WS];
   double piv[L16_WS];
@@ -4136,12 +4135,16 @@ struct L16Acc {
 // copy the panel of pivot block (Jn, BN) out of the tiles: W[row][a] = A[row][16 Jn + 4 BN + a].  Per tile row of the wave at
 // most ONE tile has the panel's columns (tile column Jn: a scalar jump picks its slot) and at most one tile row has its
 // rows (the tile row Jn itself, whose register BN holds the panel rows of the tile columns left of it, by symmetry).
-#define L16_COLPART(vt)                \
-  if (pcn) {                           \
-    wc[0] = (vt)[0];                   \
-    wc[4] = (vt)[1];                   \
-    wc[8] = (vt)[2];                   \
-    wc[12] = (vt)[3];                  \
+// (the empty asm with a different immediate per case keeps the cases apart: merged, they become ONE store sequence behind
+// a phi of accumulator ADDRESSES, and those accumulators then live in scratch memory)
+#define L16_COLPART(slot)                                       \
+  if (pcn) {                                                    \
+    const double t0_ = A.v[slot][0], t1_ = A.v[slot][1], t2_ = A.v[slot][2], t3_ = A.v[slot][3]; \
+    asm volatile("; l16 panel from slot %0" ::"n"(slot));      \
+    wc[0] = t0_;                                                \
+    wc[4] = t1_;                                                \
+    wc[8] = t2_;                                                \
+    wc[12] = t3_;                                               \
   }
 template <int BN, int G>
 __device__ __forceinline__ void l16_extract_group(const L16Acc& A, double* Wn, int Jn, int role, int q, int col) {
@@ -4151,13 +4154,13 @@ __device__ __forceinline__ void l16_extract_group(const L16Acc& A, double* Wn, i
   const bool pcn = (col >> 2) == BN;
   double* wc = Wn + (col & 3) * L16_WS + 16 * I + q;
   switch (Jn) {
-    case 0: L16_COLPART(A.v[base]) break;
-    case 1: if (cap > 1) L16_COLPART(A.v[base + (cap > 1 ? 1 : 0)]) break;
-    case 2: if (cap > 2) L16_COLPART(A.v[base + (cap > 2 ? 2 : 0)]) break;
-    case 3: if (cap > 3) L16_COLPART(A.v[base + (cap > 3 ? 3 : 0)]) break;
-    case 4: if (cap > 4) L16_COLPART(A.v[base + (cap > 4 ? 4 : 0)]) break;
-    case 5: if (cap > 5) L16_COLPART(A.v[base + (cap > 5 ? 5 : 0)]) break;
-    default: if (cap > 6) L16_COLPART(A.v[base + (cap > 6 ? 6 : 0)]) break;
+    case 0: L16_COLPART(base) break;
+    case 1: if (cap > 1) L16_COLPART(base + (cap > 1 ? 1 : 0)) break;
+    case 2: if (cap > 2) L16_COLPART(base + (cap > 2 ? 2 : 0)) break;
+    case 3: if (cap > 3) L16_COLPART(base + (cap > 3 ? 3 : 0)) break;
+    case 4: if (cap > 4) L16_COLPART(base + (cap > 4 ? 4 : 0)) break;
+    case 5: if (cap > 5) L16_COLPART(base + (cap > 5 ? 5 : 0)) break;
+    default: if (cap > 6) L16_COLPART(base + (cap > 6 ? 6 : 0)) break;
   }
   if (I == Jn) {
     double* wr = Wn + q * L16_WS + col;
@@ -4227,10 +4230,9 @@ __device__ __forceinline__ bool l16_step(L16Acc& A, L16Shared& S, int Jp, int n4
   const double zs = kc == 0 ? z0 : (kc == 1 ? z1 : (kc == 2 ? z2 : z3));  // P^-1[kc][q]
   const int lb = q * L16_WS + col;
   L16_STAMP(0)
-  // B operands: W rows of every tile column (plain); A operands: -(W P^-1) rows of the wave's own tile rows, and W rows
-  // of those tile rows for the transposed product.  No branches: tile rows beyond the matrix hold zeros or stale values
-  // that only ever reach tiles nobody reads.
-  double bop[L16_NT], aop[L16_NG], wpl[L16_NG];
+  // B operands: W rows of every tile column; A operands: -(W P^-1) rows of the wave's own tile rows.  No branches: tile
+  // rows beyond the matrix hold zeros or stale values that only ever reach tiles nobody reads.
+  double bop[L16_NT], aop[L16_NG];
 #pragma unroll
   for (int J = 0; J < L16_NT; ++J) bop[J] = W[lb + 16 * J];
 #pragma unroll
@@ -4242,65 +4244,49 @@ __device__ __forceinline__ bool l16_step(L16Acc& A, L16Shared& S, int Jp, int n4
     s = fma(wr[2 * L16_WS], z2, s);
     s = fma(wr[3 * L16_WS], z3, s);
     aop[g] = -s;
-    wpl[g] = W[lb + 16 * I];
   }
-  // the operand of the pivot tile row: (P^-1 - I) in the pivot rows (both waves need it: as A in tile row Jp, as B in
-  // tile column Jp); its plain form W P^-1 goes through LDS to the lanes that own the pivot columns of the diagonal tile
-  double am;
+  // the pivot rows and columns through the OPERANDS (no accumulator is touched for them):
+  //   rows: in the tile row of the pivots the A operand of the four pivot rows is (P^-1 - I): the MFMA yields
+  //   T_pj - W_jp + (W P^-1)_jp, and the first two cancel exactly (W_jp was copied from that very register);
+  //   columns: in the tile column of the pivots the B operand of the four pivot columns is (P - I): the MFMA yields
+  //   T_ip - (W P^-1 P)_ip + (W P^-1)_ip -- the first two cancel to rounding (~eps |P|, relative to the result).
   {
-    const double* wr = W + 16 * Jp + col;
-    double s = wr[0] * z0;
-    s = fma(wr[L16_WS], z1, s);
-    s = fma(wr[2 * L16_WS], z2, s);
-    s = fma(wr[3 * L16_WS], z3, s);
-    S.Wm[role][0][lb] = s;
-    am = pc ? (zs - ((kc == q) ? 1.0 : 0.0)) : -s;
+    const double ident = (pc && kc == q) ? 1.0 : 0.0;
+    const double am = pc ? zs - ident : 0.0;  // (P^-1 - I)[kc][q]
+    const int gp2 = 6 - role - Jp;           // = 2 g of the group whose tile row is Jp, if this wave has it
+#pragma unroll
+    for (int g = 0; g < L16_NG; ++g) aop[g] = (gp2 == 2 * g && pc) ? am : aop[g];
+#pragma unroll
+    for (int J = 0; J < L16_NT; ++J) bop[J] = (J == Jp) ? bop[J] - ident : bop[J];
   }
-  const double* wp = &S.Wm[role][kc][q];
-  const double d0 = wp[0], d1 = wp[4], d2 = wp[8], d3 = wp[12];  // (W P^-1)[16 Jp + q + 4 r][kc]
   L16_STAMP(1)
   // one MFMA per tile
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {
     const int g = l16_sg(t), J = l16_sj(t);
     if (J + 2 * g == 6) continue;  // (the last slot of each group belongs to role 0 only: below)
-    const int I = 6 - 2 * g - role;
-    const bool tr = (J == Jp) && (I != Jp);  // tile column of the pivots, below the diagonal tile: transposed product
-    const double a = tr ? wpl[g] : ((I == Jp) ? am : aop[g]);
-    const double b = tr ? am : bop[J];
-    A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, A.v[t], 0, 0, 0);
+    A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop[J], A.v[t], 0, 0, 0);
   }
   if (role == 0) {
 #pragma unroll
     for (int t = 0; t < L16_NS; ++t) {
       const int g = l16_sg(t), J = l16_sj(t);
       if (J + 2 * g != 6) continue;
-      const int I = 6 - 2 * g;  // (= J: the diagonal tiles of role 0)
-      const double a = (I == Jp) ? am : aop[g];
-      A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop[J], A.v[t], 0, 0, 0);
+      A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop[J], A.v[t], 0, 0, 0);
     }
   }
   L16_STAMP(2)
-  // diagonal tile of the pivots (slot (g, 6 - 2 g - role) of the group whose tile row is Jp): columns <- W P^-1 rows of the
-  // tile row, block <- -P^-1
-#define L16_DIAGFIX(vt)                     \
-  if (pc) {                                 \
-    (vt)[0] = (B == 0) ? -zs : d0;          \
-    (vt)[1] = (B == 1) ? -zs : d1;          \
-    (vt)[2] = (B == 2) ? -zs : d2;          \
-    (vt)[3] = (B == 3) ? -zs : d3;          \
-  }
+  // the 4x4 block of the pivots itself (diagonal tile of tile row Jp, register B, lanes of the pivot columns): -P^-1.
+  // Selects, not branches: identical stores behind different branches get merged into one store through a phi of
+  // accumulator ADDRESSES, and those accumulators then live in scratch memory.
   {
-    const int gs2 = 6 - role - Jp;  // = 2 g of that group, if this wave has it
-    if (role == 0) {
-      if (gs2 == 0) L16_DIAGFIX(A.v[6])
-      else if (gs2 == 2) L16_DIAGFIX(A.v[11])
-      else if (gs2 == 4) L16_DIAGFIX(A.v[14])
-      else if (gs2 == 6) L16_DIAGFIX(A.v[15])
-    } else {
-      if (gs2 == 0) L16_DIAGFIX(A.v[5])
-      else if (gs2 == 2) L16_DIAGFIX(A.v[10])
-      else if (gs2 == 4) L16_DIAGFIX(A.v[13])
+    const int gs2 = 6 - role - Jp;  // = 2 g of the group whose tile row is Jp, if this wave has it
+#pragma unroll
+    for (int t = 0; t < L16_NS; ++t) {
+      const int g = l16_sg(t), J = l16_sj(t);
+      if (J != 6 - 2 * g && J != 5 - 2 * g) continue;  // (the diagonal tile of a group is one of these two slots)
+      const bool hit = gs2 == 2 * g && J == 6 - 2 * g - role;
+      A.v[t][B] = (hit && pc) ? -zs : A.v[t][B];
     }
   }
   L16_STAMP(3)

@@ -95,6 +95,11 @@ def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, k
     costs = np.asarray([tr.cost_funct(np.stack((tr.x_grid, Y[:, i]), axis=-1)) for i in range(Y.shape[1])])
     out.update(ref_costs=costs, ref_best_idxs=np.argsort(costs)[:tr.N_keep], ref_best_costs=bcost,
                ref_best_curve0=bc[:, 0, :])
+    if keep_samples is not None:
+        # the fixture keeps only a few of the samples: store the kept curves themselves (y only; x = the grid), so that
+        # the curve-KDE stage can be fed through the get_best_pixels(curves, costs, pre_fobs) seam
+        assert np.array_equal(bc[:, :, 0], np.repeat(tr.x_grid[:, None], bc.shape[1], axis=1))
+        out["ref_best_curves_y"] = bc[:, :, 1].copy()
     # ---- f1: KDE stand-in + pixel selection (reference compute_new_obs on stored inputs)
     kde_arr = tr.kernel_density_estimate(bc, bcost)
     pix = np.argwhere(kde_arr > tr.kde_thresh)
@@ -141,6 +146,35 @@ def trace_fixture(name, N, img_seed, ctor_kw):
         out["ref_optimal_curve_%02d" % i] = c[:, 1]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "iters", out["ref_n_iter"], "edge", et.shape)
+
+
+def _quality_one(args):
+    """(image seed, RNG seed) -> (n_iter, MSE, DICE, rel. area) of the UNMODIFIED reference on the README configuration."""
+    img_seed, seed, kw = args
+    img, edge, kern, grad = make_image(500, img_seed)
+    init = edge[[0, -1], :][:, [1, 0]]
+    kw = dict(kw, seed=seed, return_std=False)
+    tr = gpet.GP_Edge_Tracing(init, grad, **kw)
+    et, (all_samples, all_obs, iter_curves) = tr(return_lines=True)
+    return (img_seed, seed, len(all_obs) - 2, float(gpet_utils.trace_MSE(et, edge)), float(gpet_utils.trace_dicecoef(et, edge)),
+            float(gpet_utils.trace_relarea(et, edge)))
+
+
+def quality_fixture(name, kw, img_seeds=(1, 3), seeds=range(1, 25), workers=4):
+    """Trace quality of the reference itself over image seeds x RNG seeds (a few KB): the distribution the device's
+    own quality is held against (T3: the device draws equally valid samples with other eigenvector signs, so single
+    traces differ; their distribution must not)."""
+    import multiprocessing as mp
+    jobs = [(a, b, kw) for a in img_seeds for b in seeds]
+    with mp.get_context("fork").Pool(workers) as pool:
+        rows = pool.map(_quality_one, jobs, chunksize=1)
+    rows = np.asarray(sorted(rows), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), ref_quality=rows,
+                        columns=np.array(["img_seed", "seed", "n_iter", "mse", "dice", "relarea"]), kde_standin=1)
+    for a in img_seeds:
+        r = rows[rows[:, 0] == a]
+        print(name, "image seed", a, "n_iter", r[:, 2].min(), r[:, 2].max(), "MSE median %.1f max %.1f" % (np.median(r[:, 3]), r[:, 3].max()),
+              "DICE median %.4f min %.4f" % (np.median(r[:, 4]), r[:, 4].min()))
 
 
 def kernel_fixture():
@@ -210,3 +244,5 @@ if __name__ == "__main__":
                                                    seed=7, fix_endpoints=False))
     if want("trace_rbf500"):
         trace_fixture("trace_rbf500", 500, 1, dict(readme))
+    if want("quality_rbf500"):
+        quality_fixture("quality_rbf500", dict(readme))
