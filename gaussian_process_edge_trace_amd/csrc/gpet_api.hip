@@ -354,6 +354,7 @@ const char* gpet_last_error(const gpet_ctx* c) { return c ? c->err.c_str() : "nu
 
 int gpet_sync(gpet_ctx* c) {
   if (!c) return GPET_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));  // (gpet_wait keys its blocking event on the calling thread's current device)
   HIPCHK(c, gpet_wait(c->stream));
   return GPET_OK;
 }

@@ -89,7 +89,10 @@ class SequenceTracer(object):
             imgs = [np.asarray(self.frames[f]) for _, f in active]
             seeds = [self.seeds[f] for _, f in active]
             if self._tracer is None or len(active) != self._tracer.B:
-                # (first step, or the shorter chains have run out: a smaller batch from here on)
+                # (first step, or the shorter chains have run out: a smaller batch from here on; the old batch's arena,
+                # streams and events are released now, not whenever the garbage collector gets to them)
+                if self._tracer is not None:
+                    self._tracer._batch.close()
                 self._tracer = GP_Edge_Tracing_Batch([self.init] * len(active), imgs, seeds, obs=obs, device=self.device,
                                                      _ctx=self._ctx, **self.kw)
                 if self._ctx is None:

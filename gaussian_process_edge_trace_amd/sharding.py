@@ -26,6 +26,10 @@ def broadcast_tensor(arr, shape, dtype, dist, src=0, device="cpu"):
     if dist.get_rank() == src:
         t.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)))
     dist.broadcast(t, src=src)
+    if t.is_cuda:
+        # the collective (and rank src's host-to-device copy) only order torch's current stream; the tracer reads the
+        # tensor on the library's own HIP stream through data_ptr(): wait here, once, before handing it out
+        torch.cuda.current_stream(t.device).synchronize()
     return t
 
 

@@ -206,6 +206,57 @@ def test_t3_device_trace_vs_reference_trace(amd, ctx, golden, name):
         assert dice >= dice_ref - 0.02
 
 
+def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
+    """T3 as a DISTRIBUTION (tests/golden/quality_rbf500.npz: the unmodified reference on the README configuration,
+    image seeds {1, 3} x RNG seeds 1..24 -> iterations, MSE, DICE vs the true edge).  The library draws equally valid
+    samples with other eigenvector signs than LAPACK, so a single trace is a different draw; the spread of its quality
+    over seeds must be the reference's.  Image seed 1 is bistable IN THE REFERENCE (a third of its seeds end on a branch
+    with MSE 2000-12000, e.g. the 8443 of trace_rbf500's sign-flipped twin), image seed 3 is not.  The table goes to
+    gpurun_out/r03_t3_quality.json (kept as profiles/r03_t3_quality.json)."""
+    import json
+    import os
+    ref = golden("quality_rbf500")["ref_quality"]
+    kw = CTOR["stage_rbf500"]
+    seeds = list(range(1, 25))
+    report = {"config": "README: 500x500, RBF sigma_f=75 l=20, N_samples=1000, delta_x=5, pixel_thresh=5; RNG seeds 1..24",
+              "columns": ["n_iter", "mse", "dice"], "images": {}}
+    for img_seed in (1, 3):
+        img, truth = orc.synth_sinusoid_image(500, img_seed)
+        grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+        if img_seed == 1:
+            assert np.array_equal(grad, golden("stage_rbf500")["ref_grad"])
+        init = truth[[0, -1], :][:, [1, 0]]
+        kwb = {k: v for k, v in kw.items() if k != "seed"}
+        batch = amd.GP_Edge_Tracing_Batch([init] * len(seeds), np.asarray(grad, dtype=np.float32), seeds, **kwb, _ctx=ctx)
+        traces = batch()
+        dev = np.array([[it, amd.gpet_utils.trace_MSE(et, truth), amd.gpet_utils.trace_dicecoef(et, truth)]
+                        for it, et in zip(batch.timings["iters"], traces)])
+        r = ref[ref[:, 0] == img_seed][:, 2:5]
+        assert r.shape == dev.shape
+
+        def summary(x):
+            return {"n_iter_median": float(np.median(x[:, 0])), "n_iter_range": [int(x[:, 0].min()), int(x[:, 0].max())],
+                    "good_fraction_mse_lt_2000": float(np.mean(x[:, 1] < 2000.0)),
+                    "mse_quartiles": [float(v) for v in np.percentile(x[:, 1], [25, 50, 75])],
+                    "mse_median_good_branch": float(np.median(x[x[:, 1] < 2000.0, 1])),
+                    "dice_quartiles": [float(v) for v in np.percentile(x[:, 2], [25, 50, 75])], "dice_min": float(x[:, 2].min())}
+        sd, sr = summary(dev), summary(r)
+        report["images"][str(img_seed)] = {"device": sd, "reference": sr, "device_rows": dev.tolist(), "reference_rows": r.tolist()}
+        print("image seed %d: device %s" % (img_seed, sd))
+        print("image seed %d: reference %s" % (img_seed, sr))
+        # bands: 24 draws each -- a fraction has a standard error of ~0.1, medians of this heavy-tailed MSE move by tens of %
+        assert abs(sd["good_fraction_mse_lt_2000"] - sr["good_fraction_mse_lt_2000"]) <= 0.25
+        assert abs(sd["n_iter_median"] - sr["n_iter_median"]) <= 1.5
+        assert sd["mse_median_good_branch"] <= 1.5 * sr["mse_median_good_branch"] + 25.0
+        assert sd["dice_quartiles"][1] >= sr["dice_quartiles"][1] - 0.015
+        assert sd["dice_min"] >= sr["dice_min"] - 0.05
+    out = os.environ.get("GPET_T3_OUT", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                                     "r03_t3_quality.json"))
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump(report, f, indent=1)
+
+
 def test_rbf_without_fix_endpoints_partial_width_takes_generic_path(amd, ctx):
     """fix_endpoints=False lets the pixel selection accept columns outside [x_st, x_en] (gpet.py:655-657 filters only
     when it is set); those are not on the grid the structured loop path indexes, so such an edge must run the generic

@@ -8,7 +8,7 @@ rm -rf $O; mkdir -p $O
 i=0
 for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F64" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --output-format csv -d $O/g$i -- python3 "$@" > $O/run$i.log 2>&1 || true
+  rocprofv3 --pmc $G --output-format csv -d $O/g$i -- python3 "$@" > $O/run$i.log 2>&1
 done
 python3 - "$K" <<'PY'
 import csv, glob, sys, collections
