@@ -243,10 +243,10 @@ class Batch:
         return cache[key]
 
     def info(self, e=0):
-        v = (C.c_int32 * 12)()
-        self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 12))
+        v = (C.c_int32 * 14)()
+        self.ctx.check(self.lib.gpet_batch_info(self.h, e, v, 14))
         keys = ["Lg", "S", "n_keep", "n_cap", "factor_cap", "z_cols", "factor_rows_cap", "n_bins", "obs_cap",
-                "algo_thresh", "structured", "r0"]
+                "algo_thresh", "structured", "r0", "z_ring", "arena_mib"]
         return dict(zip(keys, list(v)))
 
     def scalars(self, e=0) -> GpetScalars:

@@ -85,6 +85,10 @@ struct gpet_batch {
   int big_chunk = 0, big_ncap = 0;
   void *big_vedges = nullptr, *big_vsc = nullptr;
   double *big_scratch = nullptr, *big_part = nullptr;  // pairs around every objective launch of a converged fit (gpet_lml_stats)
+  // chunked normal generator (one long MT19937 stream on many workgroups): workspace + the jump tables on the device
+  void* mtj_work = nullptr;
+  size_t mtj_bytes = 0;
+  unsigned int* d_mtj_poly = nullptr;
   // largest lattice lag of every edge's converged-fit training set as the HOST knows it (fin_par[9..10] on the device):
   // -1 = no lattice (caller-supplied x off any grid) -> the vector objective kernels; see fin_lattice()
   std::vector<int> fin_lag;
@@ -252,6 +256,44 @@ static int fin_lattice(const double* x, int n, double* hinv) {
   return (int)mr;
 }
 
+static int& opt_rng_chunked() {
+  static int v = getenv("GPET_RNG_CHUNKED") != nullptr ? atoi(getenv("GPET_RNG_CHUNKED")) : -1;  // -1: by launch shape
+  return v;
+}
+
+// The normals of `n_ahead` iterations of B_l edges: one workgroup per stream (k_mt_normals), or -- when that leaves
+// most of the GPU idle and the streams are long -- every stream cut into chunks that many workgroups generate at once
+// (MT19937 jump-ahead, launch_normals_chunked).  The same numbers either way.
+static int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l, int add_iter,
+                        int iter_abs, int n_ahead, int z_store) {
+  gpet_ctx* c = b->ctx;
+  const int streams = B_l * n_ahead;
+  const int nc = mtj_chunks((long long)b->bd.S * b->bd.Lg);
+  const int opt = opt_rng_chunked();
+  const bool chunked = nc >= 2 && (opt > 0 || (opt < 0 && streams <= 32 && nc >= 4));
+  if (!chunked) {
+    HIPCHK(c, launch_normals(st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store));
+    return GPET_OK;
+  }
+  const size_t need = mtj_work_bytes(streams, nc);
+  if (need > b->mtj_bytes) {
+    if (b->mtj_work) {
+      HIPCHK(c, hipDeviceSynchronize());  // (launches that use the old workspace may still be in flight)
+      (void)hipFree(b->mtj_work);
+      b->mtj_work = nullptr;
+      b->mtj_bytes = 0;
+    }
+    HIPCHK(c, hipMalloc(&b->mtj_work, need));
+    b->mtj_bytes = need;
+  }
+  if (!b->d_mtj_poly) {
+    HIPCHK(c, hipMalloc(&b->d_mtj_poly, mtj_poly_bytes()));
+    HIPCHK(c, hipMemcpy(b->d_mtj_poly, mtj_poly_host(), mtj_poly_bytes(), hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, launch_normals_chunked(st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store, b->mtj_work, nc, b->d_mtj_poly));
+  return GPET_OK;
+}
+
 static int fetch_all_scalars(gpet_batch* b);
 static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const int* d_edge_of, const double* d_theta,
                           double* d_f, double* d_g, const int* d_count = nullptr, int lag_cap = 0);
@@ -266,6 +308,12 @@ int gpet_set_option(const char* name, int value) {
     const int old = v;
     v = value < 1 ? 1 : value;
     return old > 0x3fffffff ? 0x3fffffff : old;
+  }
+  if (name && strcmp(name, "rng_chunked") == 0) {
+    int& v = opt_rng_chunked();
+    const int old = v;
+    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
+    return old < 0 ? 2 : old;  // (2 = "chosen by launch shape")
   }
   if (name && strcmp(name, "lml_mfma") == 0) {
     int& v = gpet_opt_lml_mfma();
@@ -542,8 +590,11 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     if (any_big) E.z_cols = Lg;
     if (E.z_cols < E.r_cap) E.r_cap = E.z_cols;
     E.a_rows_cap = (E.z_cols >= Lg) ? Lg : E.r_cap;
-    // ring of pre-generated normals; full-stream mode (z_cols == Lg) is for tests: keep it small
-    E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : 16;
+    // ring of pre-generated normals: look-ahead + 2 slots.  Small batches are latency-bound in the generator and draw
+    // 8 iterations ahead (gpet_trace_iterate); a batch that fills the GPU draws 1 ahead (up to 3 by option): 4 slots
+    // instead of 16 -- at 1024 edges of the bench shape 2.4 GB instead of 9.4 GB of an 18 GB arena.  Full-stream mode
+    // (z_cols == Lg: full-rank covariances, tests) holds whole 8 MB streams per slot: 2.
+    E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 4);
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
     E.nu_gen = p.nu;
@@ -743,6 +794,8 @@ void gpet_batch_destroy(gpet_batch* b) {
   if (b->d_f) (void)hipFree(b->d_f);
   if (b->d_g) (void)hipFree(b->d_g);
   if (b->lb_mem) (void)hipFree(b->lb_mem);
+  if (b->mtj_work) (void)hipFree(b->mtj_work);
+  if (b->d_mtj_poly) (void)hipFree(b->d_mtj_poly);
   if (b->big_mem) (void)hipFree(b->big_mem);
   for (hipEvent_t ev : b->lb_events) (void)hipEventDestroy(ev);
   delete b;
@@ -753,9 +806,9 @@ int gpet_batch_size(const gpet_batch* b) { return b ? b->B : 0; }
 int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count) {
   if (!b || e < 0 || e >= b->B || !out) return GPET_ERR_BAD_ARG;
   const EdgeDev& E = b->h_edges[e];
-  const int32_t v[12] = {E.Lg, E.S, E.n_keep, E.n_cap, E.r_cap, E.z_cols, E.a_rows_cap, E.n_bins, E.obs_cap, E.algo_thresh,
-                         b->structured ? 1 : 0, E.r0};
-  for (int i = 0; i < count && i < 12; ++i) out[i] = v[i];
+  const int32_t v[14] = {E.Lg, E.S, E.n_keep, E.n_cap, E.r_cap, E.z_cols, E.a_rows_cap, E.n_bins, E.obs_cap, E.algo_thresh,
+                         b->structured ? 1 : 0, E.r0, E.z_ring, (int32_t)(b->arena_bytes >> 20)};
+  for (int i = 0; i < count && i < 14; ++i) out[i] = v[i];
   return GPET_OK;
 }
 
@@ -1007,7 +1060,10 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(b->d_seeds, seeds, sizeof(uint32_t) * b->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 1));
-  HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 0, -1, 1));
+  {
+    int rcn = normals_auto(b, c->stream, b->d_edges, b->B, b->d_seeds, 0, -1, 1, 0);
+    if (rcn) return rcn;
+  }
   HIPCHK(c, launch_set_force(c->stream, b->d_edges, b->B, 0));
   HIPCHK(c, gpet_wait(c->stream));
   b->have_normals = true;
@@ -1578,7 +1634,10 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         int n = ring - (j - cur);
         if (n > look) n = look;
         if (cur - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(cur - 1) % 16], 0));
-        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, n, loop_z_store(b)));
+        {
+          int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, j, n, loop_z_store(b));
+          if (rcn) return rcn;
+        }
         for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
         b->norm_issued = j + n;
       }
@@ -1589,7 +1648,10 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         } else if (j - ring >= first) {
           HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(j - ring) % 16], 0));
         }
-        HIPCHK(c, launch_normals(b->side, edges_l, B_l, seeds_l, 1, j, 1, loop_z_store(b)));
+        {
+          int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, j, 1, loop_z_store(b));
+          if (rcn) return rcn;
+        }
         HIPCHK(c, hipEventRecord(b->ev_norm[j % 16], b->side));
         b->norm_issued = j + 1;
       }

@@ -2335,26 +2335,48 @@ __device__ __forceinline__ unsigned int mt_mix(unsigned int a, unsigned int b, u
 // seeds of future iterations are known a priori (gpet.py:839), so a whole ring of them is
 // generated by one launch, one workgroup per (iteration, edge).
 #define MTQ_CAP 256  // ring of pending (r2, x1, x2, destinations) records: < 64 left over + 156 per block = 219 at most
+#include "gpet_mt_jump.inc"  // MTJ_CB, MTJ_LEVELS, mtj_poly: jump-ahead polynomials (tools/gen_mt_jump.py)
+// workspace of the chunked generator, per stream (= iteration ahead x edge): chunk states, accepted pairs per chunk and
+// their exclusive prefix; per jump of a level: the 33 blocks of raw words its convolution reads
+struct MtjWork {
+  unsigned int* T;     // [streams][nc][624]
+  int* cnt;            // [streams][nc]
+  long long* offs;     // [streams][nc]
+  unsigned int* src;   // [streams][nc / 2 + 1][MTJ_SRC]
+  int nc;              // chunks per stream
+};
+#define MTJ_SRC (33 * 624)
+// CHUNKED = false: one workgroup generates a whole stream from its seed (blockIdx = (iterations ahead, edge)).
+// CHUNKED = true: blockIdx = (chunk, iterations ahead, edge): the workgroup starts from the state of its chunk (k_mtj_*
+// below found it by jumping ahead) at the stream position the chunks before it have filled, and stops after MTJ_CB
+// blocks -- except the last chunk, which runs until the stream is complete (the chunk count is an estimate).
+template <bool CHUNKED>
 __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
-                                                    int iter_abs, int z_store) {
+                                                    int iter_abs, int z_store, MtjWork wk) {
 #pragma clang fp contract(off)
-  const EdgeDev E = edges[blockIdx.y];
+  const int e_idx = CHUNKED ? (int)blockIdx.z : (int)blockIdx.y, ahead = CHUNKED ? (int)blockIdx.y : (int)blockIdx.x;
+  const EdgeDev E = edges[e_idx];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   // iter_abs >= 0: the host names the iteration (the RNG stream runs ahead of the loop, so the
   // device counter is not meaningful here); otherwise relative to the edge's current iteration
-  const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + (int)blockIdx.x;
+  const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + ahead;
   double* __restrict__ Zs = E.Z + (size_t)(iter_idx % E.z_ring) * ((size_t)E.S * E.z_cols);
+  const int chunk = CHUNKED ? (int)blockIdx.x : 0;
+  const size_t stream = CHUNKED ? (size_t)e_idx * gridDim.y + blockIdx.y : 0;
   __shared__ unsigned int s_mt[2][624];
   __shared__ int s_cnt[2][4];
   __shared__ int s_qtail;  // records queued so far (monotonic; slots are taken with one LDS atomic per wave)
   __shared__ double q_r2[MTQ_CAP], q_x1[MTQ_CAP], q_x2[MTQ_CAP];
   __shared__ int q_d0[MTQ_CAP], q_d1[MTQ_CAP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) {
-    s_qtail = 0;
+  if (tid == 0) s_qtail = 0;
+  if (CHUNKED) {
+    const unsigned int* st0 = wk.T + (stream * wk.nc + chunk) * 624;
+    for (int i = tid; i < 624; i += 256) s_mt[0][i] = st0[i];
+  } else if (tid == 0) {
     // seed of iteration k (0-based) = base + k + 1 (gpet.py:839)
-    unsigned int p = seeds[blockIdx.y] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);
+    unsigned int p = seeds[e_idx] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);
     s_mt[0][0] = p;
     for (int i = 1; i < 624; ++i) {
       p = 1812433253u * (p ^ (p >> 30)) + (unsigned int)i;
@@ -2373,8 +2395,10 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   // in LDS and the fourth wave -- idle during the attempts -- evaluates them 64 at a time; when most are stored
   // they are evaluated in place.
   const bool queued = 2 * zs <= Lg;
-  long long done_pairs = 0;
-  int row0 = 0, col0 = 0;  // (row, column) of the normal at stream position 2 * done_pairs
+  long long done_pairs = CHUNKED ? wk.offs[stream * wk.nc + chunk] : 0;
+  // (row, column) of the normal at stream position 2 * done_pairs
+  int row0 = (int)((2 * done_pairs) / Lg), col0 = (int)((2 * done_pairs) - (long long)row0 * Lg);
+  const bool last_chunk = !CHUNKED || chunk == wk.nc - 1;
   int q_popped = 0;  // records evaluated so far (same value in every thread)
   int cur = 0, it = 0;
   auto emit = [&](double r2, double x1, double x2, int d0, int d1) {
@@ -2382,7 +2406,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     if (d0 >= 0) Zs[d0] = f * x2;
     if (d1 >= 0) Zs[d1] = f * x1;
   };
-  while (done_pairs < need_pairs) {
+  while (done_pairs < need_pairs && (last_chunk || it < MTJ_CB)) {
     unsigned int* o = s_mt[cur];
     unsigned int* nw = s_mt[cur ^ 1];
     if (tid < 227) nw[tid] = mt_mix(o[tid], o[tid + 1], o[tid + 397]);
@@ -2509,6 +2533,216 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------
+// K5, one LONG stream in parallel (BASELINE config 3: RandomState(seed).standard_normal((4000, 2048)) is 21 M words of ONE
+// MT19937 stream; a single edge of the bench: 1.3 M).  The stream is cut into chunks of MTJ_CB blocks of 624 words.
+// The raw state words x_k obey a linear recurrence over GF(2) with characteristic polynomial phi (degree 19937); with
+// g = x^J mod phi:  x_{k+J} = XOR_{i : g_i = 1} x_{k+i}  (tools/gen_mt_jump.py computes phi by Berlekamp-Massey and the
+// tables g for J = 624 MTJ_CB 2^m, and checks them on the sequence).  So the state J words ahead of a known state is
+// a binary convolution of 19937 + 623 consecutive words: 33 blocks of the recurrence (k_mtj_src) and ~10 k x 624 word
+// XORs that parallelise trivially (k_mtj_conv).  Doubling (states of chunks c known for c = 0 mod 2^(m+1) -> chunks
+// c + 2^m) reaches every chunk in log2(chunks) levels of two launches.  Then every chunk counts its accepted polar
+// attempts (k_mtj_count), a scan turns the counts into stream positions (k_mtj_scan), and k_mt_normals<true> emits.
+// The numbers are those of the sequential generator bit for bit: same words, same attempts, same arithmetic.
+// (The low 31 bits of x_0 are not part of the generator's state; they reach only the low bits of the first word of a
+// jumped state, which the recurrence never reads.)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mtj_init(EdgeDev* edges, const unsigned int* seeds, int add_iter, int iter_abs,
+                                                  MtjWork wk) {
+  const int e_idx = blockIdx.y, ahead = blockIdx.x;
+  const EdgeDev E = edges[e_idx];
+  const gpet_scalars* sc = E.sc;
+  const size_t stream = (size_t)e_idx * gridDim.x + ahead;
+  unsigned int* T = wk.T + stream * wk.nc * 624;
+  for (size_t i = 624 + threadIdx.x; i < (size_t)wk.nc * 624; i += blockDim.x) T[i] = 0u;  // (the convolutions XOR into them)
+  if (threadIdx.x == 0) {
+    const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + ahead;
+    unsigned int p = seeds[e_idx] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);  // gpet.py:839
+    T[0] = p;
+    for (int i = 1; i < 624; ++i) {
+      p = 1812433253u * (p ^ (p >> 30)) + (unsigned int)i;
+      T[i] = p;
+    }
+  }
+}
+
+// level m, jump jj: the state of chunk c = jj 2^(m+1) and the 32 blocks after it -> src[jj] (20592 raw words)
+__global__ void __launch_bounds__(256) k_mtj_src(MtjWork wk, int m) {
+  const int jj = blockIdx.x;
+  const size_t stream = blockIdx.y;
+  const int c = jj << (m + 1);
+  if (c + (1 << m) >= wk.nc) return;
+  __shared__ unsigned int s_mt[2][624];
+  const int tid = threadIdx.x;
+  const unsigned int* st0 = wk.T + (stream * wk.nc + c) * 624;
+  unsigned int* dst = wk.src + (stream * (wk.nc / 2 + 1) + jj) * MTJ_SRC;
+  for (int i = tid; i < 624; i += 256) {
+    const unsigned int v = st0[i];
+    s_mt[0][i] = v;
+    dst[i] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int b = 1; b < 33; ++b) {
+    unsigned int* o = s_mt[cur];
+    unsigned int* nw = s_mt[cur ^ 1];
+    if (tid < 227) nw[tid] = mt_mix(o[tid], o[tid + 1], o[tid + 397]);
+    __syncthreads();
+    if (tid < 227) nw[227 + tid] = mt_mix(o[227 + tid], o[228 + tid], nw[tid]);
+    __syncthreads();
+    if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
+    if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+    __syncthreads();
+    for (int i = tid; i < 624; i += 256) dst[b * 624 + i] = nw[i];
+    cur ^= 1;
+  }
+}
+
+// level m, jump jj, part p: taps 640 p .. 640 p + 639 of g_m; XORs its share into the state of chunk c + 2^m
+#define MTJ_TAPS 640
+#define MTJ_PARTS 32  // 32 x 640 >= 19968
+__global__ void __launch_bounds__(256) k_mtj_conv(MtjWork wk, int m, const unsigned int* __restrict__ poly) {
+  const int p = blockIdx.x, jj = blockIdx.y;
+  const size_t stream = blockIdx.z;
+  const int c = jj << (m + 1), tgt = c + (1 << m);
+  if (tgt >= wk.nc) return;
+  __shared__ unsigned int s_w[MTJ_TAPS + 624];
+  const int tid = threadIdx.x;
+  const unsigned int* src = wk.src + (stream * (wk.nc / 2 + 1) + jj) * MTJ_SRC + MTJ_TAPS * p;
+  const int avail = MTJ_SRC - MTJ_TAPS * p;  // (the last part's window ends with the source)
+  for (int i = tid; i < MTJ_TAPS + 624; i += 256) s_w[i] = i < avail ? src[i] : 0u;
+  __syncthreads();
+  unsigned int a0 = 0u, a1 = 0u, a2 = 0u;
+  const int j2 = tid + 512 < 624 ? tid + 512 : tid;  // (threads 112..255 recompute a word they already own: no branch)
+  const unsigned int* g = poly + (size_t)m * 624 + (MTJ_TAPS / 32) * p;
+  for (int w = 0; w < MTJ_TAPS / 32; ++w) {
+    unsigned int bits = (MTJ_TAPS / 32) * p + w < 624 ? g[w] : 0u;  // (uniform)
+    while (bits) {
+      const int i = 32 * w + __builtin_ctz(bits);
+      bits &= bits - 1;
+      a0 ^= s_w[i + tid];
+      a1 ^= s_w[i + tid + 256];
+      a2 ^= s_w[i + j2];
+    }
+  }
+  unsigned int* T = wk.T + (stream * wk.nc + tgt) * 624;
+  atomicXor(&T[tid], a0);
+  atomicXor(&T[tid + 256], a1);
+  if (tid + 512 < 624) atomicXor(&T[tid + 512], a2);
+}
+
+// accepted polar attempts of every chunk (the decisions of k_mt_normals, nothing else of it)
+__global__ void __launch_bounds__(256) k_mtj_count(MtjWork wk) {
+#pragma clang fp contract(off)
+  const int chunk = blockIdx.x;
+  const size_t stream = blockIdx.y;
+  __shared__ unsigned int s_mt[2][624];
+  __shared__ int s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned int* st0 = wk.T + (stream * wk.nc + chunk) * 624;
+  for (int i = tid; i < 624; i += 256) s_mt[0][i] = st0[i];
+  __syncthreads();
+  int cur = 0, acc = 0;
+  for (int it = 0; it < MTJ_CB; ++it) {
+    unsigned int* o = s_mt[cur];
+    unsigned int* nw = s_mt[cur ^ 1];
+    if (tid < 227) nw[tid] = mt_mix(o[tid], o[tid + 1], o[tid + 397]);
+    __syncthreads();
+    if (tid < 227) nw[227 + tid] = mt_mix(o[227 + tid], o[228 + tid], nw[tid]);
+    __syncthreads();
+    if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
+    if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+    __syncthreads();
+    bool ok = false;
+    if (tid < 156) {
+      const unsigned int wa = mt_temper(nw[4 * tid]) >> 5, wc = mt_temper(nw[4 * tid + 2]) >> 5;
+      const float xf = (float)((int)wa - 67108864) * 1.4901161193847656e-08f;  // 2^-26
+      const float yf = (float)((int)wc - 67108864) * 1.4901161193847656e-08f;
+      const float rf = xf * xf + yf * yf;
+      ok = rf < 1.0f;
+      if (!(fabsf(rf - 1.0f) > 1e-5f && rf > 1e-5f)) {
+        const unsigned int b = mt_temper(nw[4 * tid + 1]) >> 6, d = mt_temper(nw[4 * tid + 3]) >> 6;
+        const double u1 = ((double)wa * 67108864.0 + (double)b) / 9007199254740992.0;
+        const double u2 = ((double)wc * 67108864.0 + (double)d) / 9007199254740992.0;
+        const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+        const double r2 = x1 * x1 + x2 * x2;
+        ok = !(r2 >= 1.0 || r2 == 0.0);
+      }
+    }
+    acc += __popcll(__ballot(ok));
+    cur ^= 1;
+  }
+  if (lane == 0) s_part[w] = acc;
+  __syncthreads();
+  if (tid == 0) wk.cnt[stream * wk.nc + chunk] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// exclusive prefix of the counts: the stream position (in pairs) where every chunk starts
+__global__ void __launch_bounds__(64) k_mtj_scan(MtjWork wk) {
+  const size_t stream = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int* cnt = wk.cnt + stream * wk.nc;
+  long long* offs = wk.offs + stream * wk.nc;
+  long long base = 0;
+  for (int c0 = 0; c0 < wk.nc; c0 += 64) {
+    const int c = c0 + lane;
+    const long long v = c < wk.nc ? (long long)cnt[c] : 0;
+    long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (c < wk.nc) offs[c] = base + incl - v;
+    base += __shfl(incl, 63, 64);
+  }
+}
+
+size_t mtj_work_bytes(int streams, int nc) {
+  return (size_t)streams * ((size_t)nc * 624 * 4 + (size_t)nc * 4 + (size_t)nc * 8 + (size_t)(nc / 2 + 1) * MTJ_SRC * 4) + 1024;
+}
+
+// chunks for a stream of S x Lg normals: expected attempts + 6 sigma (the last chunk runs on if that was too few)
+int mtj_chunks(long long normals) {
+  const double pairs = 0.5 * (double)(normals + 1);
+  const double attempts = pairs / 0.7853981633974483;
+  const double blocks = (attempts + 6.0 * 0.523 * sqrt(attempts)) / 156.0 + 1.0;
+  long long nc = (long long)ceil(blocks / (double)MTJ_CB);
+  if (nc > (1LL << MTJ_LEVELS)) return 0;  // (longer than the jump tables reach: the sequential generator)
+  return (int)nc;
+}
+
+hipError_t launch_normals_chunked(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
+                                  int iter_abs, int n_ahead, int z_store, void* work, int nc, const unsigned int* d_poly) {
+  (void)hipGetLastError();
+  const int streams = B * n_ahead;
+  MtjWork wk;
+  char* base = (char*)work;
+  wk.nc = nc;
+  wk.T = (unsigned int*)base;
+  base += (size_t)streams * nc * 624 * 4;
+  wk.offs = (long long*)base;
+  base += (size_t)streams * nc * 8;
+  wk.cnt = (int*)base;
+  base += (((size_t)streams * nc * 4 + 15) / 16) * 16;
+  wk.src = (unsigned int*)base;
+  hipLaunchKernelGGL(k_mtj_init, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, wk);
+  int top = 0;
+  while ((2 << top) < nc) ++top;  // jumps of 2^top chunks from chunk 0 first
+  for (int m = top; m >= 0; --m) {
+    const int jumps = (nc + (2 << m) - 1) / (2 << m);
+    hipLaunchKernelGGL(k_mtj_src, dim3(jumps, streams), dim3(256), 0, st, wk, m);
+    hipLaunchKernelGGL(k_mtj_conv, dim3(MTJ_PARTS, jumps, streams), dim3(256), 0, st, wk, m, d_poly);
+  }
+  hipLaunchKernelGGL(k_mtj_count, dim3(nc, streams), dim3(256), 0, st, wk);
+  hipLaunchKernelGGL(k_mtj_scan, dim3(streams), dim3(64), 0, st, wk);
+  hipLaunchKernelGGL(k_mt_normals<true>, dim3(nc, n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, wk);
+  return hipGetLastError();
+}
+
+const unsigned int* mtj_poly_host() { return &mtj_poly[0][0]; }
+size_t mtj_poly_bytes() { return sizeof(mtj_poly); }
 
 // K6 on the matrix cores: v_mfma_f64_16x16x4_f64.  64x64 output tile per workgroup, 4 waves, wave w
 // owns rows 16w..16w+15 and all 64 columns (4 accumulators of 4 f64 per lane); K streamed through
@@ -5039,7 +5273,7 @@ hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const Ba
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead, int z_store) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_mt_normals, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store);
+  hipLaunchKernelGGL(k_mt_normals<false>, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
   return hipGetLastError();
 }
 

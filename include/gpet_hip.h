@@ -175,7 +175,8 @@ int gpet_batch_create2(gpet_ctx* ctx, int B, int M, int N, const float* const* g
 void gpet_batch_destroy(gpet_batch* b);
 int gpet_batch_size(const gpet_batch* b);
 /* out[0..count): Lg, S, n_keep, n_cap, factor_cap, z_cols, factor_rows_cap, n_bins, obs_cap, algo_thresh,
- * structured (1: the loop uses the prior-eigenbasis path), r0 (rank of the grid's correlation matrix) */
+ * structured (1: the loop uses the prior-eigenbasis path), r0 (rank of the grid's correlation matrix), z_ring (slots
+ * of pre-generated normals per edge), arena size of the batch in MiB */
 int gpet_batch_info(const gpet_batch* b, int e, int32_t* out, int count);
 
 /* Back to the state right after gpet_batch_create: no observations, initial score threshold,

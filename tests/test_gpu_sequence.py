@@ -73,6 +73,31 @@ def test_matern_sequence_bit_exact_vs_chained_oracle(amd, ctx, N, T, chains):
     print("N=%d: iterations per frame %s, MSE vs truth %s" % (N, st.iterations, np.round(mse, 1)))
 
 
+def test_config5_length_64_frames_8_chains(amd, ctx):
+    """BASELINE config 5 at its stated LENGTH: 64 frames at 1024x1024, Matern-5/2, 8 chains of 8 frames traced as batches
+    of 8 edges (N_samples=300 to keep the CPU oracle affordable).  One chain -- the last -- is re-traced by the oracle,
+    chained the same way: its first (cold) frame, its second and its last (7 warm starts deep) frame bit for bit with
+    their iteration counts; every frame of the sequence must land on its true edge."""
+    N, T, chains = 1024, 64, 8
+    frames, truths, init = make_sequence(amd, ctx, N, T)
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=300, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    seeds = [3 + t for t in range(T)]
+    st = amd.SequenceTracer(frames, init, n_chains=chains, warm_every=16, seeds=seeds, _ctx=ctx, **kw)
+    got = st()
+    from gaussian_process_edge_trace_amd.sequence import chain_slices
+    lo, hi = chain_slices(T, chains)[-1]
+    assert hi - lo == 8
+    want, iters = oracle_chain(frames[lo:hi], init, 16, seeds[lo:hi], kw)
+    for k in (0, 1, hi - lo - 1):
+        assert st.iterations[lo + k] == iters[k], "frame %d" % (lo + k)
+        assert np.array_equal(got[lo + k], want[k]), "frame %d" % (lo + k)
+    dice = [amd.gpet_utils.trace_dicecoef(got[t], truths[t]) for t in range(T)]
+    print("64 frames / 8 chains: iterations %s, DICE min %.4f median %.4f" % (st.iterations, min(dice), float(np.median(dice))))
+    assert min(dice) > 0.97
+    assert all(st.iterations[l + k] >= 1 for l, h in chain_slices(T, chains) for k in range(1, h - l))  # warm frames do iterate
+
+
 def test_sequence_single_chain_equals_per_frame_objects(amd, ctx):
     """One chain through the batch machinery (set_frame on one batch object) == a fresh GP_Edge_Tracing per frame
     with ``obs`` from the previous trace, the way a user of the reference chains frames (RBF: structured loop path,

@@ -136,6 +136,51 @@ def test_normals_stream_odd_count(amd, ctx, golden, z_cols):
     np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
 
 
+@pytest.mark.parametrize("name,z_cols,n_samples", [("stage_rbf500", 500, 1000), ("stage_rbf500", 96, 1000), ("stage_rbf500", 251, 1000),
+                                                   ("stage_rbf65", 65, 4001), ("stage_rbf65", 16, 9000), ("stage_rbf64", 64, 700)])
+def test_normals_stream_chunked_equals_sequential(amd, ctx, golden, name, z_cols, n_samples):
+    """One long MT19937 stream generated by many workgroups (jump-ahead to the state of every chunk of 64 blocks, accept
+    counts, prefix, emit; option rng_chunked=1) must be the sequential generator's stream bit for bit -- and numpy's
+    RandomState(seed).standard_normal: full and sparse column sets, odd widths and an odd total (a pair straddling rows /
+    ending the stream), streams of 2..33 chunks, the last chunk running on past its 64 blocks."""
+    g = golden(name)
+    L = amd._lib
+    kw = dict(CTOR[name], N_samples=n_samples)
+    seed = 987654
+    out = {}
+    for mode in (0, 1):
+        old = L.set_option("rng_chunked", mode)
+        try:
+            tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **kw, _ctx=ctx, z_cols=z_cols)
+            tr._batch.normals([seed])
+            out[mode] = tr._batch.read(L.BUF_NORMALS)
+        finally:
+            L.set_option("rng_chunked", -1 if old == 2 else old)
+    assert out[0].shape == (n_samples, z_cols)
+    assert np.array_equal(out[0], out[1])
+    N = int(g["ref_scalars"][8])
+    ref = orc.legacy_standard_normal(seed, n_samples * N).reshape(n_samples, N)[:, :z_cols]
+    np.testing.assert_allclose(out[1], ref, rtol=0, atol=5e-15)
+
+
+def test_normals_stream_config3_shape(amd, ctx):
+    """BASELINE config 3's stream: RandomState(seed).standard_normal((4000, 2048)) = 8.2 M normals of ONE stream (21 M words,
+    ~525 chunks, ten doubling levels of the jump-ahead), chosen automatically for a single edge; against numpy's own
+    generator (the test may use numpy: the product does not)."""
+    L = amd._lib
+    N = 2048
+    img, truth = orc.synth_sinusoid_image(N, 0)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=4000,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx, z_cols=N)
+    tr._batch.normals([7])
+    Z = tr._batch.read(L.BUF_NORMALS)
+    ref = np.random.RandomState(7).standard_normal((4000, N))
+    np.testing.assert_allclose(Z, ref, rtol=0, atol=5e-15)
+
+
 @pytest.mark.parametrize("name", ["stage_rbf64", "stage_rbf65", "stage_mat128", "stage_mat15_96", "stage_mat35_96"])
 def test_sample_T2_injected_factor(amd, ctx, golden, name):
     """T2: with the reference's factor sqrt(s)*v injected, samples match the reference."""
