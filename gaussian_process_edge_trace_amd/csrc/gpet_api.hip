@@ -177,6 +177,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.yt = cv.take<double>(nc);
   E.wt = cv.take<double>(nc);
   E.alpha = cv.take<double>(nc);
+  E.chol_inv = cv.take<double>(nc > 128 ? (nc / 64 + 1) * 4096 : 1);
   E.K = cv.take<double>(nc * nc);
   E.V = cv.take<double>(nc * Lg);
   E.mean = cv.take<double>(Lg);

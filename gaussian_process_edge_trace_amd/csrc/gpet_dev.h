@@ -40,6 +40,8 @@ struct EdgeDev {
   double *xt, *yt, *wt;  // [n_cap]
   double* K;             // [n_cap*n_cap] row-major; lower triangle becomes L
   double* alpha;         // [n_cap]
+  double* chol_inv;      // [n_cap / 64 + 1][64][64] inverses of L's diagonal blocks (blocked fit, n_cap > 128): the
+                         // triangular solves against a panel become matrix products on the matrix cores
   double* V;             // [n_cap*Lg]  L^-1 K_*^T
   double *mean, *std;    // [Lg]
   double* cov;           // [Lg*Lg]

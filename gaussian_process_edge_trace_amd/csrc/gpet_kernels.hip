@@ -552,21 +552,26 @@ __global__ void __launch_bounds__(576) k_fit(EdgeDev* edges) {
 // for alpha.  The panel kernels are enqueued for every 64-block of n_cap and return at once past the actual n.
 // ---------------------------------------------------------------------------------------
 #define CB 64
-__global__ void __launch_bounds__(256) k_fit_head(EdgeDev* edges) {
+__global__ void __launch_bounds__(1024) k_fit_head(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   __shared__ double s_red[16];
+  extern __shared__ long long s_key[];  // [n_cap] x coordinates (the rank of a point = a pass over all of them: from LDS,
+                                        // not n global loads per thread -- 1.0 -> 0.05 ms at 1500 points)
   const int tid = threadIdx.x, bs = blockDim.x;
   const int n = E.n_init + sc->n_obs;
   // 1. gather + stable rank sort by x (np.argsort, gpet.py:212)
   const double w_init = E.fix_endpoints ? 1e-7 : 0.5;  // gpet.py:161
+  for (int j = tid; j < n; j += bs) s_key[j] = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+  __syncthreads();
   for (int i = tid; i < n; i += bs) {
-    const long long* pi = (i < E.n_init) ? (E.init_xy + 2 * i) : (E.obs_xy + 2 * (i - E.n_init));
-    const long long xi = pi[0], yi = pi[1];
+    const long long xi = s_key[i];
+    const long long yi = (i < E.n_init) ? E.init_xy[2 * i + 1] : E.obs_xy[2 * (i - E.n_init) + 1];
     int r = 0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) {
-      const long long xj = (j < E.n_init) ? E.init_xy[2 * j] : E.obs_xy[2 * (j - E.n_init)];
+      const long long xj = s_key[j];
       r += (xj < xi) || (xj == xi && j < i);
     }
     E.xt[r] = (double)xi;
@@ -633,8 +638,13 @@ __global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
   }
 }
 
-// diagonal block k0: Cholesky in LDS (right-looking), written back in place
-__global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0) {
+// diagonal block k0: Cholesky in LDS, written back in place, and -- with_inv -- its INVERSE to E.chol_inv: every
+// triangular solve against this block (the rows of L below it, V = L^-1 K_*^T) then becomes a 64x64x64 product on the
+// matrix cores.  ONE wave, no workgroup barriers: lane i owns row i, left-looking by columns -- l_ik = (a_ik - sum_{t<k}
+// l_it l_kt) / l_kk reads its own row (stride 65: conflict-free) and row k (the same address in every lane: a
+// broadcast); LDS operations of a wave complete in order.  ~2 x 2048 dependent FMAs per lane: 30 us for factor and
+// inverse, against 85 us for the factor alone with three workgroup barriers per pivot.
+__global__ void __launch_bounds__(64) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -642,42 +652,85 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0) {
   if (k0 >= n) return;
   const int nb = (n - k0) < CB ? (n - k0) : CB;
   __shared__ double s[CB][CB + 1];
-  const int tid = threadIdx.x, bs = blockDim.x;
-  for (int e = tid; e < nb * nb; e += bs) {
-    const int i = e / nb, j = e - i * nb;
-    if (j <= i) s[i][j] = E.K[(size_t)(k0 + i) * ld + k0 + j];
+  __shared__ double sx[CB][CB + 1];
+  const int i = threadIdx.x;
+  // (row r: lanes 0..r, a coalesced run; eight rows' loads in flight -- one at a time is 64 memory round trips)
+  for (int r0 = 0; r0 < nb; r0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (r0 + u < nb && i <= r0 + u) ? E.K[(size_t)(k0 + r0 + u) * ld + k0 + i] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r0 + u < nb && i <= r0 + u) s[r0 + u][i] = v[u];
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   bool bad = false;
   for (int k = 0; k < nb; ++k) {
-    const double d = s[k][k];
+    double acc = (i >= k && i < nb) ? s[i][k] : 0.0;
+    if (i >= k && i < nb) {
+      // (four partial sums, eight loads in flight: the chain is LDS latency otherwise)
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int t = 0;
+      for (; t + 4 <= k; t += 4) {
+        a0 = fma(s[i][t], s[k][t], a0);
+        a1 = fma(s[i][t + 1], s[k][t + 1], a1);
+        a2 = fma(s[i][t + 2], s[k][t + 2], a2);
+        a3 = fma(s[i][t + 3], s[k][t + 3], a3);
+      }
+      for (; t < k; ++t) a0 = fma(s[i][t], s[k][t], a0);
+      acc -= (a0 + a1) + (a2 + a3);
+    }
+    const double d = __shfl(acc, k, WAVE);  // a_kk - sum l_kt^2
     if (!(d > 0.0)) {
       bad = true;
       break;
     }
     const double dk = sqrt(d);
-    __syncthreads();
-    for (int i = k + tid; i < nb; i += bs) s[i][k] = (i == k) ? dk : s[i][k] / dk;
-    __syncthreads();
-    const int m = nb - k - 1;
-    for (int e = tid; e < m * m; e += bs) {
-      const int ii = e / m, jj = e - ii * m;
-      if (jj <= ii) s[k + 1 + ii][k + 1 + jj] -= s[k + 1 + ii][k] * s[k + 1 + jj][k];
-    }
-    __syncthreads();
+    if (i >= k && i < nb) s[i][k] = (i == k) ? dk : acc / dk;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (other lanes read this column next: keep the compiler from moving loads above it)
   }
   if (bad) {
-    if (tid == 0) sc->status = GPET_ERR_NOT_PD;
+    if (i == 0) sc->status = GPET_ERR_NOT_PD;
     return;
   }
-  for (int e = tid; e < nb * nb; e += bs) {
-    const int i = e / nb, j = e - i * nb;
-    if (j <= i) E.K[(size_t)(k0 + i) * ld + k0 + j] = s[i][j];
+  for (int r = 0; r < nb; ++r)
+    if (i <= r) E.K[(size_t)(k0 + r) * ld + k0 + i] = s[r][i];
+  if (!with_inv) return;
+  // inverse: lane j owns column j of X = L^-1: x_rj = (delta_rj - sum_{j <= t < r} l_rt x_tj) / l_rr (identity padding
+  // beyond nb, zero above the diagonal)
+  {
+    const int j = i;
+    for (int r = 0; r < CB; ++r) {
+      double x = (r == j) ? 1.0 : 0.0;
+      if (r < nb && j < nb && r >= j) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int t = j;
+        for (; t + 4 <= r; t += 4) {
+          a0 = fma(s[r][t], sx[t][j], a0);
+          a1 = fma(s[r][t + 1], sx[t + 1][j], a1);
+          a2 = fma(s[r][t + 2], sx[t + 2][j], a2);
+          a3 = fma(s[r][t + 3], sx[t + 3][j], a3);
+        }
+        for (; t < r; ++t) a0 = fma(s[r][t], sx[t][j], a0);
+        x -= (a0 + a1) + (a2 + a3);
+        x /= s[r][r];
+      } else if (r != j) {
+        x = 0.0;
+      }
+      sx[r][j] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
+    for (int r = 0; r < CB; ++r) inv[r * CB + j] = sx[r][j];
   }
 }
 
-// row blocks below the diagonal block: X L_kk^T = A_ik, one row per lane of the first wave
-__global__ void __launch_bounds__(256) k_chol_trsm(EdgeDev* edges, int k0) {
+// row blocks below the diagonal block by SUBSTITUTION (one row per lane of the first wave): the blocked objective of
+// the converged fits keeps it -- the optimiser visits nearly singular matrices (noise 1e-10 of the amplitude) where a
+// product with the explicit inverse of a diagonal block costs digits (2e-8 instead of 1e-9 relative on f = 1.2e8)
+__global__ void __launch_bounds__(256) k_chol_trsm_sub(EdgeDev* edges, int k0) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -709,8 +762,47 @@ __global__ void __launch_bounds__(256) k_chol_trsm(EdgeDev* edges, int k0) {
   }
 }
 
-// trailing update A_ij -= X_i X_j^T for the 64x64 tiles (bj <= bi) behind panel k0, v_mfma_f64_16x16x4_f64
+// row blocks below the diagonal block: X L_kk^T = A_ik, i.e. X = A_ik (L_kk^-1)^T on v_mfma_f64_16x16x4_f64
+// (A lane l <- A[16 w + (l & 15)][kk + (l >> 4)], B lane l <- Linv[16 t + (l & 15)][kk + (l >> 4)])
 typedef double v4f64c __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_chol_trsm(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  const int i0 = k0 + CB * ((int)blockIdx.x + 1);
+  if (i0 >= n) return;
+  const int rows = (n - i0) < CB ? (n - i0) : CB;
+  __shared__ double sL[CB][CB + 1];
+  __shared__ double sA[CB][CB + 1];
+  const int tid = threadIdx.x, bs = blockDim.x;
+  const double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
+  for (int e = tid; e < CB * CB; e += bs) {
+    const int i = e >> 6, j = e & 63;
+    sL[i][j] = inv[e];
+    sA[i][j] = (i < rows) ? E.K[(size_t)(i0 + i) * ld + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64c acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < CB; kk += 4) {
+    const double a = sA[16 * w + li][kk + lq];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sL[16 * t + li][kk + lq], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = 16 * w + lq + 4 * g, j = 16 * t + li;
+      if (i < rows) E.K[(size_t)(i0 + i) * ld + k0 + j] = acc[t][g];
+    }
+}
+
+// trailing update A_ij -= X_i X_j^T for the 64x64 tiles (bj <= bi) behind panel k0, v_mfma_f64_16x16x4_f64
 __global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
@@ -748,9 +840,12 @@ __global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
     }
 }
 
-// alpha = L^-T L^-1 y on the factor in HBM, blocked by 64: diagonal blocks through LDS (column form, one wave),
-// the updates of the remaining rows as 64-long dot products spread over the workgroup; the vector stays in LDS
-__global__ void __launch_bounds__(256) k_chol_solve(EdgeDev* edges) {
+// alpha = L^-T L^-1 y on the factor in HBM, blocked by 64: diagonal blocks through LDS (column form, one wave).  The
+// updates of the rest of the vector read L the way it lies in memory: forward -- the 64 columns of the block, one ROW per
+// 64 consecutive lanes' ... per thread group of 16 (a 512-byte run per row); backward -- the 64 ROWS of the block, thread i
+// owns vector entry i and walks down the rows (every load a coalesced run).  The vector stays in LDS.
+// (One 256-thread workgroup reading the transposed block column by column took 3.2 ms at 1500 points: 5.6 GB/s.)
+__global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -777,11 +872,21 @@ __global__ void __launch_bounds__(256) k_chol_solve(EdgeDev* edges) {
       if (tid < nb) s_z[k0 + tid] = z;
     }
     __syncthreads();
-    for (int i = k0 + nb + tid; i < n; i += bs) {
+    // rows below: 16 lanes per row (four columns each, a 512-byte run), summed in the order t = 0..nb-1 per lane and
+    // then across the 16 lanes
+    for (int i = k0 + nb + (tid >> 4); i < n; i += bs >> 4) {
       const double* ri = E.K + (size_t)i * ld + k0;
-      double acc = 0.0;
-      for (int t = 0; t < nb; ++t) acc += ri[t] * s_z[k0 + t];
-      s_z[i] -= acc;
+      const int t0 = tid & 15;
+      // (four loads in flight per lane; entries beyond nb of the last block are not read)
+      const double v0 = ri[t0], v1 = t0 + 16 < nb ? ri[t0 + 16] : 0.0, v2 = t0 + 32 < nb ? ri[t0 + 32] : 0.0,
+                   v3 = t0 + 48 < nb ? ri[t0 + 48] : 0.0;
+      double acc = (t0 < nb ? v0 : 0.0) * s_z[k0 + t0];
+      acc += v1 * s_z[k0 + ((t0 + 16) & 63)];
+      acc += v2 * s_z[k0 + ((t0 + 32) & 63)];
+      acc += v3 * s_z[k0 + ((t0 + 48) & 63)];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+      if ((tid & 15) == 0) s_z[i] -= acc;
     }
     __syncthreads();
   }
@@ -803,9 +908,23 @@ __global__ void __launch_bounds__(256) k_chol_solve(EdgeDev* edges) {
     }
     __syncthreads();
     for (int i = tid; i < k0; i += bs) {
-      double acc = 0.0;
-      for (int t = 0; t < nb; ++t) acc += E.K[(size_t)(k0 + t) * ld + i] * s_z[k0 + t];
-      s_z[i] -= acc;
+      const double* ci = E.K + (size_t)k0 * ld + i;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int t = 0;
+      for (; t + 8 <= nb; t += 8) {  // (eight rows in flight, four partial sums)
+        const double u0 = ci[(size_t)t * ld], u1 = ci[(size_t)(t + 1) * ld], u2 = ci[(size_t)(t + 2) * ld], u3 = ci[(size_t)(t + 3) * ld];
+        const double u4 = ci[(size_t)(t + 4) * ld], u5 = ci[(size_t)(t + 5) * ld], u6 = ci[(size_t)(t + 6) * ld], u7 = ci[(size_t)(t + 7) * ld];
+        a0 = fma(u0, s_z[k0 + t], a0);
+        a1 = fma(u1, s_z[k0 + t + 1], a1);
+        a2 = fma(u2, s_z[k0 + t + 2], a2);
+        a3 = fma(u3, s_z[k0 + t + 3], a3);
+        a0 = fma(u4, s_z[k0 + t + 4], a0);
+        a1 = fma(u5, s_z[k0 + t + 5], a1);
+        a2 = fma(u6, s_z[k0 + t + 6], a2);
+        a3 = fma(u7, s_z[k0 + t + 7], a3);
+      }
+      for (; t < nb; ++t) a0 = fma(ci[(size_t)t * ld], s_z[k0 + t], a0);
+      s_z[i] -= (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
   }
@@ -815,17 +934,17 @@ __global__ void __launch_bounds__(256) k_chol_solve(EdgeDev* edges) {
 // the whole fit for n_cap > 128
 static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   const int nt = cdiv(bd.n_cap, CB);
-  hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(256), 0, st, d_edges);
+  hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(long long), st, d_edges);
   hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
   for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(64), 0, st, d_edges, k0, 1);
     const int below = cdiv(bd.n_cap - k0 - CB, CB);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);
       hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0);
     }
   }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1, B), dim3(256), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  hipLaunchKernelGGL(k_chol_solve, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(double), st, d_edges);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -4816,6 +4935,7 @@ __global__ void __launch_bounds__(64) k_lmlbig_setup(EdgeDev* edges, int P, cons
   V.K = base;
   V.V = base + (size_t)ncap_v * ncap_v;
   V.alpha = V.V + (size_t)ncap_v * ncap_v;
+  V.chol_inv = nullptr;  // (the blocked objective solves by substitution: k_chol_trsm_sub, k_struct_trsm)
   V.n_cap = ncap_v;
   V.Lg = ncap_v;  // column count / stride of V in the blocked substitution; != n, so the weights are not zeroed again
   V.length_scale = l;
@@ -4963,10 +5083,10 @@ hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, co
   const int ntn = cdiv(n_max, CB);  // tiles that can hold training points
   hipLaunchKernelGGL(k_fit_kbuild, dim3(ntn, ntn, P), dim3(256), 0, st, ve);
   for (int k0 = 0; k0 < n_max; k0 += CB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1, P), dim3(256), 0, st, ve, k0);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, P), dim3(64), 0, st, ve, k0, 0);
     const int below = cdiv(n_max - k0 - CB, CB);
     if (below > 0) {
-      hipLaunchKernelGGL(k_chol_trsm, dim3(below, P), dim3(256), 0, st, ve, k0);
+      hipLaunchKernelGGL(k_chol_trsm_sub, dim3(below, P), dim3(256), 0, st, ve, k0);
       hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, P), dim3(256), 0, st, ve, k0);
     }
   }
@@ -5020,6 +5140,89 @@ __global__ void __launch_bounds__(256) k_kstar_build(EdgeDev* edges) {
   for (int i = blockIdx.y * 4 + (threadIdx.x >> 6); i < n; i += gridDim.y * 4)
     E.V[(size_t)i * Lg + j] = amp * corr_px(E, (double)(E.x_st + j), E.xt[i], length);
 }
+// block k0 of V = L^-1 K_*^T for 32 columns of the grid per workgroup, on the matrix cores:
+//   X = K_*^T[k0.., cols] - sum_{j0 < k0} L[k0.., j0..] V[j0.., cols]   (64 x 64 by 64 x 32 products, left-looking),
+//   V[k0.., cols] = L_kk^-1 X   (the inverse of the diagonal block from k_chol_diag).
+// Wave w owns rows 16 w .. 16 w + 15 of the block and both 16-column halves.
+#define VS_COLS 32
+__global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, Lg = E.Lg, ld = E.n_cap;
+  const int a0 = blockIdx.x * VS_COLS;
+  if (k0 >= n || a0 >= Lg) return;
+  const int nb = (n - k0) < CB ? (n - k0) : CB;
+  __shared__ double sL[CB][CB + 1];
+  __shared__ double sU[CB][VS_COLS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64c acc[2];
+  acc[0] = acc[1] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+  // the blocks of the next j0 are loaded into registers while the matrix cores work on the current ones (a launch has
+  // only Lg / 32 workgroups: nothing else hides the two dependent round trips per block otherwise -- 85 -> ~25 us)
+  double pl[16], pu[8];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, t = e & 63;
+      pl[u] = (i < nb) ? E.K[(size_t)(k0 + i) * ld + j0 + t] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u, t = e >> 5, a = e & 31;
+      pu[u] = (a0 + a < Lg) ? E.V[(size_t)(j0 + t) * Lg + a0 + a] : 0.0;
+    }
+  };
+  if (k0 > 0) fetch(0);
+  for (int j0 = 0; j0 < k0; j0 += CB) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u;
+      sL[e >> 6][e & 63] = pl[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u;
+      sU[e >> 5][e & 31] = pu[u];
+    }
+    __syncthreads();
+    if (j0 + CB < k0) fetch(j0 + CB);
+#pragma unroll
+    for (int kk = 0; kk < CB; kk += 4) {
+      const double a = sL[16 * w + li][kk + lq];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][li], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 + li], acc[1], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  // X = B - acc into sU (rows of the block beyond n: zero), the inverse into sL
+  const double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
+  for (int e = tid; e < CB * CB; e += 256) sL[e >> 6][e & 63] = inv[e];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = 16 * w + lq + 4 * g, a = 16 * h + li;
+      sU[i][a] = (i < nb && a0 + a < Lg) ? E.V[(size_t)(k0 + i) * Lg + a0 + a] - acc[h][g] : 0.0;
+    }
+  __syncthreads();
+  acc[0] = acc[1] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < CB; kk += 4) {
+    const double a = sL[16 * w + li][kk + lq];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][li], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 + li], acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = 16 * w + lq + 4 * g, a = 16 * h + li;
+      if (i < nb && a0 + a < Lg) E.V[(size_t)(k0 + i) * Lg + a0 + a] = acc[h][g];
+    }
+}
+
 // mean_j = y_std * sum_i K_*[i][j] alpha_i + y_mean   (sklearn_gpr.py:381-385; before V is overwritten)
 __global__ void __launch_bounds__(256) k_pred_mean_big(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
@@ -5087,9 +5290,8 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
     // many training points: V through HBM, blocked substitution with the panel kernel of the structured path
     hipLaunchKernelGGL(k_kstar_build, dim3(cdiv(bd.Lg, 64), 64, B), dim3(256), 0, st, d_edges);
     hipLaunchKernelGGL(k_pred_mean_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
-    const int cgroups = cdiv(bd.Lg, SB_COLS);
     for (int k0 = 0; k0 < bd.n_cap; k0 += CB)
-      hipLaunchKernelGGL(k_struct_trsm, dim3(cgroups, B), dim3(256), 0, st, d_edges, k0, 1);
+      hipLaunchKernelGGL(k_vsolve_mfma, dim3(cdiv(bd.Lg, VS_COLS), B), dim3(256), 0, st, d_edges, k0);
     hipLaunchKernelGGL(k_pred_std_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
   } else if (plds <= 150 * 1024)
     hipLaunchKernelGGL((k_predict<true, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, 0);

@@ -1,7 +1,7 @@
 """How tall is the band of image rows that the samples of a 32-column group can touch (mean +- 6.5 sigma), iteration by
 iteration of the bench trace?  (Sizing of a band-limited image slab for scoring inside the sample GEMM.)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gaussian_process_edge_trace_amd as amd
 from bench import synth_image, README_KW

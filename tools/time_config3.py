@@ -1,6 +1,6 @@
 """Ad-hoc: device time of one GP iteration + scoring at BASELINE config 3 (2048^2, n = 1500, S = 4000)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 

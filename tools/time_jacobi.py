@@ -1,7 +1,7 @@
 """Time the LDS Jacobi variants (gpet_set_option "jacobi_variant") on the bench batch at its mid-trace state and
 compare what they produce: eigenvalues, factor rows after the rows stage, and whole traces."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gaussian_process_edge_trace_amd as amd
 from bench import synth_image, README_KW

@@ -1,6 +1,6 @@
 """Per-kernel device time of the bench batch at its mid-trace state (gpet_profile_stage ids of bench.py)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import gaussian_process_edge_trace_amd as amd
 import bench
