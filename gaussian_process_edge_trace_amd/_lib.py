@@ -92,6 +92,7 @@ SYMBOLS = {
     "gpet_batch_read_scalars_all": (C.c_int, [_P, _P]),
     "gpet_final_predict_all": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "gpet_final_fit_all": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
+    "gpet_final_optimize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int32)]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -364,6 +365,18 @@ class Batch:
         self.ctx.check(self.lib.gpet_final_fit_all(self.h, s, mean.ctypes.data, std.ctypes.data, th.ctypes.data, Lg,
                                                    C.byref(rounds)))
         return mean, std, th[:, :3].copy(), th[:, 3].copy(), rounds.value
+
+    def final_optimize(self, starts, bounds):
+        """Device L-BFGS-B on the training sets of final_set_training(_all) (gpet_final_optimize): starts
+        (B, n_starts, 3) = log(constant, length_scale, noise_level), bounds (3, 2) in the same space.  Returns
+        (theta [B, 3] of the best start per edge, its -LML [B], objective rounds)."""
+        starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(self.B, -1, 3)
+        bounds = np.ascontiguousarray(bounds, dtype=np.float64).reshape(3, 2)
+        th = np.zeros((self.B, 4))
+        rounds = C.c_int32()
+        self.ctx.check(self.lib.gpet_final_optimize(self.h, starts.shape[1], starts.ctypes.data, bounds.ctypes.data,
+                                                    th.ctypes.data, C.byref(rounds)))
+        return th[:, :3].copy(), th[:, 3].copy(), rounds.value
 
     def lml_batch(self, edge_of, theta):
         edge_of = np.ascontiguousarray(edge_of, dtype=np.int32)

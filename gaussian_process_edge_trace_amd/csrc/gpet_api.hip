@@ -71,6 +71,7 @@ struct gpet_batch {
   double *d_theta = nullptr, *d_f = nullptr, *d_g = nullptr;
   // device-resident converged fits (gpet_final_fit_all): one allocation, carved
   char* lb_mem = nullptr;
+  int lb_cap_P = 0;  // problems the optimiser's workspace holds
   void* lb_probs = nullptr;
   double *lb_starts = nullptr, *lb_scratch = nullptr, *lb_f = nullptr, *lb_g = nullptr, *lb_theta_out = nullptr;
   int* lb_slot_edge[2] = {nullptr, nullptr};
@@ -1417,64 +1418,53 @@ static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const
   return GPET_OK;
 }
 
-int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
-                       int stride, int32_t* rounds_out) {
-  if (!b || !seeds || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
+// workspace of the device optimiser for P problems (grown on demand)
+static int lb_ensure(gpet_batch* b, int P) {
   gpet_ctx* c = b->ctx;
-  HIPCHK(c, hipSetDevice(c->device));
-  int rc = fetch_all_scalars(b);  // (synchronises the loop's stream: the observation sets are final)
-  if (rc) return rc;
-  const int B = b->B, P = 13 * B;
-  int n_max = 0;
-  for (int e = 0; e < B; ++e) {
-    const int n = b->h_edges[e].n_init + b->h_scalars[e].n_obs;
-    if (n > b->h_edges[e].n_cap) return fail(c, GPET_ERR_BAD_ARG, "converged fit: edge %d n=%d exceeds n_cap", e, n);
-    b->h_edges[e].fin_n = n;
-    if (n > n_max) n_max = n;
+  const int B = b->B;
+  if (b->lb_mem && b->lb_cap_P >= P) return GPET_OK;
+  if (b->lb_mem) {
+    HIPCHK(c, gpet_wait(b->fit));
+    (void)hipFree(b->lb_mem);
+    b->lb_mem = nullptr;
   }
-  if (!b->lb_mem) {
-    b->lb_scratch_stride = b->bd.n_cap > 256 ? b->bd.n_cap : 256;
-    Carver meas;
-    for (int pass = 0; pass < 2; ++pass) {
-      Carver cv;
-      cv.base = pass ? b->lb_mem : nullptr;
-      b->lb_probs = cv.take<char>(lb_prob_bytes() * (size_t)P);
-      b->lb_starts = cv.take<double>((size_t)P * 3);
-      b->lb_scratch = cv.take<double>((size_t)B * b->lb_scratch_stride);
-      b->lb_f = cv.take<double>((size_t)P);
-      b->lb_g = cv.take<double>((size_t)P * 3);
-      b->lb_theta_out = cv.take<double>((size_t)B * 4);
-      for (int h = 0; h < 2; ++h) {
-        b->lb_slot_edge[h] = cv.take<int>((size_t)P);
-        b->lb_slot_theta[h] = cv.take<double>((size_t)P * 3);
-        b->lb_slot_src[h] = cv.take<int>((size_t)P);
-      }
-      b->lb_count = cv.take<int>(4);
-      b->lb_seeds = cv.take<unsigned int>((size_t)B);
-      if (!pass) {
-        HIPCHK(c, hipMalloc(&b->lb_mem, cv.off + 256));
-        // slots beyond the true count of a round are never evaluated (the objective kernels read the count), but the
-        // blocked path above 250 points sizes its work by the host's bound: every slot must name a valid edge
-        HIPCHK(c, hipMemsetAsync(b->lb_mem, 0, cv.off + 256, b->fit));
-      }
+  b->lb_scratch_stride = b->bd.n_cap > 256 ? b->bd.n_cap : 256;
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver cv;
+    cv.base = pass ? b->lb_mem : nullptr;
+    b->lb_probs = cv.take<char>(lb_prob_bytes() * (size_t)P);
+    b->lb_starts = cv.take<double>((size_t)P * 3);
+    b->lb_scratch = cv.take<double>((size_t)B * b->lb_scratch_stride);
+    b->lb_f = cv.take<double>((size_t)P);
+    b->lb_g = cv.take<double>((size_t)P * 3);
+    b->lb_theta_out = cv.take<double>((size_t)B * 4);
+    for (int h = 0; h < 2; ++h) {
+      b->lb_slot_edge[h] = cv.take<int>((size_t)P);
+      b->lb_slot_theta[h] = cv.take<double>((size_t)P * 3);
+      b->lb_slot_src[h] = cv.take<int>((size_t)P);
+    }
+    b->lb_count = cv.take<int>(4);
+    b->lb_seeds = cv.take<unsigned int>((size_t)B);
+    if (!pass) {
+      HIPCHK(c, hipMalloc(&b->lb_mem, cv.off + 256));
+      // slots beyond the true count of a round are never evaluated (the objective kernels read the count), but the
+      // blocked path above 250 points sizes its work by the host's bound: every slot must name a valid edge
+      HIPCHK(c, hipMemsetAsync(b->lb_mem, 0, cv.off + 256, b->fit));
     }
   }
+  b->lb_cap_P = P;
+  return GPET_OK;
+}
+
+// The rounds of the device optimiser on stream b->fit: lb_starts holds P = nstart * B start points (edge-major).  The
+// number of running problems lives on the device (lb_count[round & 1]); the host reads it only every LB_CHECK rounds and
+// sizes the launches by its last known value in between -- workgroups of the objective beyond the true count return at
+// once, threads of the advance kernel beyond it too.  A round costs the GPU ~80 us for one edge; a host round trip per
+// round would double that.
+static int lb_rounds(gpet_batch* b, int P, int n_max, int lag_cap, const LbCfg& cfg, int* rounds_out) {
+  gpet_ctx* c = b->ctx;
   hipStream_t st = b->fit;
-  // the training x are pixel columns of the image: a lattice of fewer than N points (k_fin_prepare leaves the step and
-  // the largest lag in fin_par[9..10])
-  int lag_cap = b->bd.N > b->bd.Lg ? b->bd.N : b->bd.Lg;
-  for (int e = 0; e < B; ++e) {
-    const EdgeDev& E = b->h_edges[e];
-    if (E.x_st < 0 || E.x_en >= lag_cap) lag_cap = 0;  // (end points outside the image: no bound on the lags)
-  }
-  b->fin_lag.assign(B, lag_cap > 0 ? lag_cap - 1 : -1);
-  HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride, b->bd.n_cap));
-  HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0]));
-  // Rounds.  The number of running problems lives on the device (lb_count[round & 1]); the host reads it only every
-  // LB_CHECK rounds and sizes the launches by its last known value in between -- workgroups beyond the true count
-  // evaluate stale (valid) slots, threads of the advance kernel beyond it return.  A round costs the GPU ~80 us for one
-  // edge; a host round trip per round would double that.
+  HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0], cfg));
   constexpr int LB_CHECK = 4;
   int h_count[2] = {P, 0};
   HIPCHK(c, hipMemcpyAsync(b->lb_count, h_count, sizeof h_count, hipMemcpyHostToDevice, st));
@@ -1500,7 +1490,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
     HIPCHK(c, hipEventRecord(b->lb_events[ev_used + 1], st));
     ev_used += 2;
     HIPCHK(c, launch_lb_advance(st, b->lb_probs, n_upper, cnt_cur, b->lb_slot_src[cur], b->lb_f, b->lb_g, cnt_next,
-                                b->lb_slot_edge[1 - cur], b->lb_slot_theta[1 - cur], b->lb_slot_src[1 - cur]));
+                                b->lb_slot_edge[1 - cur], b->lb_slot_theta[1 - cur], b->lb_slot_src[1 - cur], cfg));
     b->lml_evals += n_upper;
     b->lml_launches += 1;
     cur ^= 1;
@@ -1516,7 +1506,43 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->lb_events[q], b->lb_events[q + 1]) == hipSuccess) b->lml_ms += (double)ms;
   }
-  HIPCHK(c, launch_lb_pick(st, b->d_edges, B, b->lb_probs, b->lb_theta_out));
+  HIPCHK(c, launch_lb_pick(st, b->d_edges, b->B, b->lb_probs, b->lb_theta_out, cfg.nstart));
+  if (rounds_out) *rounds_out = rounds;
+  return GPET_OK;
+}
+
+int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
+                       int stride, int32_t* rounds_out) {
+  if (!b || !seeds || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = fetch_all_scalars(b);  // (synchronises the loop's stream: the observation sets are final)
+  if (rc) return rc;
+  const LbCfg cfg = lb_default_cfg();
+  const int B = b->B, P = cfg.nstart * B;
+  int n_max = 0;
+  for (int e = 0; e < B; ++e) {
+    const int n = b->h_edges[e].n_init + b->h_scalars[e].n_obs;
+    if (n > b->h_edges[e].n_cap) return fail(c, GPET_ERR_BAD_ARG, "converged fit: edge %d n=%d exceeds n_cap", e, n);
+    b->h_edges[e].fin_n = n;
+    if (n > n_max) n_max = n;
+  }
+  rc = lb_ensure(b, P);
+  if (rc) return rc;
+  hipStream_t st = b->fit;
+  // the training x are pixel columns of the image: a lattice of fewer than N points (k_fin_prepare leaves the step and
+  // the largest lag in fin_par[9..10])
+  int lag_cap = b->bd.N > b->bd.Lg ? b->bd.N : b->bd.Lg;
+  for (int e = 0; e < B; ++e) {
+    const EdgeDev& E = b->h_edges[e];
+    if (E.x_st < 0 || E.x_en >= lag_cap) lag_cap = 0;  // (end points outside the image: no bound on the lags)
+  }
+  b->fin_lag.assign(B, lag_cap > 0 ? lag_cap - 1 : -1);
+  HIPCHK(c, hipMemcpyAsync(b->lb_seeds, seeds, sizeof(uint32_t) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, launch_fin_prepare(st, b->d_edges, B, b->lb_seeds, b->lb_starts, b->lb_scratch, b->lb_scratch_stride, b->bd.n_cap));
+  int rounds = 0;
+  rc = lb_rounds(b, P, n_max, lag_cap, cfg, &rounds);
+  if (rc) return rc;
   HIPCHK(c, launch_final_predict(st, b->d_edges, B, b->bd));
   std::vector<double> host((size_t)B * 2 * b->bd.Lg), th((size_t)B * 4);
   HIPCHK(c, hipMemcpyAsync(host.data(), b->d_fin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1530,6 +1556,40 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
   }
   if (rounds_out) *rounds_out = rounds;
   b->have_fit = false;  // the loop's L/alpha were overwritten by the converged fit
+  return check_device_status(b);
+}
+
+int gpet_final_optimize(gpet_batch* b, int n_starts, const double* starts, const double* bounds, double* theta_out,
+                        int32_t* rounds_out) {
+  if (!b || n_starts < 1 || n_starts > 64 || !starts || !bounds || !theta_out) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int B = b->B, P = n_starts * B;
+  LbCfg cfg;
+  cfg.nstart = n_starts;
+  for (int k = 0; k < 3; ++k) {
+    cfg.lo[k] = bounds[2 * k];
+    cfg.hi[k] = bounds[2 * k + 1];
+    if (!(cfg.lo[k] <= cfg.hi[k])) return fail(c, GPET_ERR_BAD_ARG, "gpet_final_optimize: empty bound interval %d", k);
+  }
+  int n_max = 0, lag_cap = 1;
+  for (int e = 0; e < B; ++e) {
+    const int n = b->h_edges[e].fin_n;
+    if (n < 1) return fail(c, GPET_ERR_STATE, "gpet_final_optimize before gpet_final_set_training (edge %d)", e);
+    if (n > n_max) n_max = n;
+    const int lg = (size_t)e < b->fin_lag.size() ? b->fin_lag[e] : -1;
+    lag_cap = (lag_cap == 0 || lg < 0) ? 0 : (lg + 1 > lag_cap ? lg + 1 : lag_cap);
+  }
+  int rc = lb_ensure(b, P);
+  if (rc) return rc;
+  HIPCHK(c, gpet_wait(c->stream));  // (the training sets were written on the context's stream)
+  HIPCHK(c, hipMemcpyAsync(b->lb_starts, starts, sizeof(double) * 3 * P, hipMemcpyHostToDevice, b->fit));
+  int rounds = 0;
+  rc = lb_rounds(b, P, n_max, lag_cap, cfg, &rounds);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(theta_out, b->lb_theta_out, sizeof(double) * 4 * B, hipMemcpyDeviceToHost, b->fit));
+  HIPCHK(c, gpet_wait(b->fit));
+  if (rounds_out) *rounds_out = rounds;
   return check_device_status(b);
 }
 

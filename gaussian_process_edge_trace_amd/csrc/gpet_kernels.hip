@@ -4435,18 +4435,15 @@ __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_o
 //
 // A block step for the pivots k0..k0+3 (tile Jp, sub-block B; W = columns k0..k0+3 of the matrix = the PANEL, in LDS
 // k-major, copied out of the tiles at the end of the previous step; P = its rows k0..k0+3):
-//   P = L D L^T in every lane (the four pivots d are the squared Cholesky diagonal in the scalar order); lane group q
-//   solves P z = e_q, i.e. owns column q of P^-1;
-//   the sweep  T <- T - (W P^-1) W^T  is one MFMA per tile with A = -(W P^-1) rows of the tile row, B = W rows of the
-//   tile column;
-//   the pivot rows must become (W P^-1)^T: in the tile row of the pivots the A operand of the four pivot rows is
-//   (P^-1 - I) instead, so the MFMA yields  T_pj - W_jp + (W P^-1)_jp  and the first two cancel exactly (W_jp was copied
-//   from that very register);
-//   the pivot columns (tile column Jp below the diagonal tile) get the same treatment through the TRANSPOSED product,
-//   A = W rows, B = that modified operand;
-//   only the diagonal tile needs registers touched: its pivot columns are the transpose of its (now exact) pivot rows
-//   (cross-lane permute), the 4x4 block itself becomes -P^-1;
-//   the next panel is copied into the other panel buffer; ONE workgroup barrier per step.
+//   P = L D L^T in every lane (unit lower L; the four pivots d are the squared Cholesky diagonal in the scalar order);
+//   Y = W L^-T row by row (each lane the rows of its tile rows: six FMAs), component q of it to the plane Yp; barrier;
+//   the four rank-one updates of the scalar sweep as ONE MFMA per tile:  T -= (Y D^-1) Y^T,  A operand -Y[row][q] / d_q,
+//   B operand Y[column][q] -- the scalar algorithm's own arithmetic, no product with an explicit P^-1;
+//   the pivot rows and columns must become (W P^-1)^T and W P^-1: the A operand of the four pivot rows is
+//   Linv[q][i'] / d_q - L[i'][q] instead, the B operand of the four pivot columns Y[j'][q] - Linv[q][j']: the MFMA
+//   then yields T_pj - W_jp + (W P^-1)_jp with the first two cancelling to the rounding of Y -- no accumulator touched;
+//   only the 4x4 block itself is written: -P^-1 (P^-1[kc][q] from the two columns of L^-1 each lane solves for);
+//   the next panel is copied into the other panel buffer; TWO workgroup barriers per step.
 // n^3 / 2 FMAs of the scalar sweep become 25 x 28 MFMAs (1024 FMAs each, 68 % useful at n = 98).  The training x sit on
 // a lattice (pixel columns), so the correlation and its length-scale derivative are tabulated at the integer lags once
 // per problem: lagmax + 1 transcendentals instead of n^2 for the set-up and n^2 more for the gradient.
@@ -4463,6 +4460,7 @@ __host__ __device__ constexpr int l16_sj(int t) { return t < 7 ? t : (t < 12 ? t
 
 struct L16Shared {
   double Wt[2][4][L16_WS];  // panel of the current / next block step, k-major
+  double Yp[4][L16_WS];     // Y = W L^-T of the current step, k-major: every wave writes its own tile rows, all read after a barrier
   double al[L16_WS];        // alpha (row n4 of the swept matrix)
   double y[L16_WS], w[L16_WS];
   double piv[L16_WS];
@@ -4545,74 +4543,90 @@ __device__ __forceinline__ bool l16_step(L16Acc& A, L16Shared& S, int Jp, int n4
   constexpr int buf = B & 1;  // (four steps per tile: the parity of the step is the parity of B)
   const int k0 = 16 * Jp + 4 * B;
   const double* W = &S.Wt[buf][0][0];
-  // P = [[Pa, Pb^T], [Pb, Pc]] in 2x2 blocks (uniform: every lane reads the same ten entries); block elimination:
-  // Pa^-1 by its adjugate, X = Pb Pa^-1, S = Pc - X Pb^T, S^-1 by its adjugate.  Half the dependent chain of four scalar
-  // pivots; det Pa and det S are the products of the scalar pivots (d0 d1 and d2 d3), their signs with those of p00 and
-  // s22 the leading minors.
+  // P = L D L^T (uniform: every lane reads the same ten entries), the four pivots one after the other: d_k are the
+  // squared Cholesky diagonal in the scalar order.  (Elimination by 2x2 blocks with adjugates halves this dependent
+  // chain -- 740 instead of ~1100 cycles of a 3500-cycle step -- but forms X = Pb Pa^-1 and the Schur complement from
+  // differences of products: 6e-7 relative on the objective at c / noise = 4e4 where this form gives 6e-12.  Dropped.)
   const double p00 = W[k0], p10 = W[k0 + 1], p20 = W[k0 + 2], p30 = W[k0 + 3];
   const double p11 = W[L16_WS + k0 + 1], p21 = W[L16_WS + k0 + 2], p31 = W[L16_WS + k0 + 3];
   const double p22 = W[2 * L16_WS + k0 + 2], p32 = W[2 * L16_WS + k0 + 3];
   const double p33 = W[3 * L16_WS + k0 + 3];
-  const double detA = fma(p00, p11, -(p10 * p10));
-  const double rA = l16_rcp(detA);
-  const double x20 = fma(p20, p11, -(p21 * p10)) * rA, x21 = fma(p21, p00, -(p20 * p10)) * rA;
-  const double x30 = fma(p30, p11, -(p31 * p10)) * rA, x31 = fma(p31, p00, -(p30 * p10)) * rA;
-  const double s22 = fma(-x21, p21, fma(-x20, p20, p22));
-  const double s32 = fma(-x31, p21, fma(-x30, p20, p32));
-  const double s33 = fma(-x31, p31, fma(-x30, p30, p33));
-  const double detS = fma(s22, s33, -(s32 * s32));
-  const double rS = l16_rcp(detS);
-  const bool ok = p00 > 0.0 && detA > 0.0 && s22 > 0.0 && detS > 0.0;  // (the same in every lane of both waves)
-  if (role == 0 && (q | col) == 0) {  // log|K| = sum log sqrt(piv): the pivots pairwise
-    S.piv[k0] = detA;
-    S.piv[k0 + 1] = 1.0;
-    S.piv[k0 + 2] = detS;
-    S.piv[k0 + 3] = 1.0;
+  const double i0 = l16_rcp(p00);
+  const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+  const double u11 = fma(-p10, l10, p11), u21 = fma(-p20, l10, p21), u31 = fma(-p30, l10, p31);
+  const double i1 = l16_rcp(u11);
+  const double l21 = u21 * i1, l31 = u31 * i1;
+  const double u22 = fma(-u21, l21, fma(-p20, l20, p22));
+  const double u32 = fma(-u31, l21, fma(-p30, l20, p32));
+  const double i2 = l16_rcp(u22);
+  const double l32 = u32 * i2;
+  const double u33 = fma(-u32, l32, fma(-u31, l31, fma(-p30, l30, p33)));
+  const double i3 = l16_rcp(u33);
+  const bool ok = p00 > 0.0 && u11 > 0.0 && u22 > 0.0 && u33 > 0.0;  // (the same in every lane of both waves)
+  if (role == 0 && (q | col) == 0) {
+    S.piv[k0] = p00;
+    S.piv[k0 + 1] = u11;
+    S.piv[k0 + 2] = u22;
+    S.piv[k0 + 3] = u33;
   }
-  // column q of P^-1:  y_l = e_l - X e_u,  z_l = S^-1 y_l,  z_u = Pa^-1 e_u - X^T z_l
-  const double eu0 = (q == 0) ? 1.0 : 0.0, eu1 = (q == 1) ? 1.0 : 0.0;
-  const double yl0 = fma(-x21, eu1, fma(-x20, eu0, (q == 2) ? 1.0 : 0.0));
-  const double yl1 = fma(-x31, eu1, fma(-x30, eu0, (q == 3) ? 1.0 : 0.0));
-  const double z2 = fma(s33, yl0, -(s32 * yl1)) * rS;
-  const double z3 = fma(s22, yl1, -(s32 * yl0)) * rS;
-  const double au0 = fma(p11, eu0, -(p10 * eu1)) * rA, au1 = fma(p00, eu1, -(p10 * eu0)) * rA;
-  const double z0 = fma(-x30, z3, fma(-x20, z2, au0));
-  const double z1 = fma(-x31, z3, fma(-x21, z2, au1));
   const bool pc = (col >> 2) == B;  // this lane's row (A operand) / column (tile) index is one of the pivots
   const int kc = col & 3;
-  const double zs = kc == 0 ? z0 : (kc == 1 ? z1 : (kc == 2 ? z2 : z3));  // P^-1[kc][q]
   const int lb = q * L16_WS + col;
+  // Per lane, from the uniform factors: columns kc and q of L^-1 (forward substitution on unit vectors),
+  //   zs = P^-1[kc][q] = sum_a Linv[a][kc] Linv[a][q] / d_a   (what the 4x4 block of the pivots becomes, negated),
+  //   lkq = L[kc][q],  ykq = Linv[q][kc],  iq = 1 / d_q.
+  const double k0e = (kc == 0) ? 1.0 : 0.0;
+  const double yk1 = fma(-l10, k0e, (kc == 1) ? 1.0 : 0.0);
+  const double yk2 = fma(-l21, yk1, fma(-l20, k0e, (kc == 2) ? 1.0 : 0.0));
+  const double yk3 = fma(-l32, yk2, fma(-l31, yk1, fma(-l30, k0e, (kc == 3) ? 1.0 : 0.0)));
+  const double q0e = (q == 0) ? 1.0 : 0.0;
+  const double yq1 = fma(-l10, q0e, (q == 1) ? 1.0 : 0.0);
+  const double yq2 = fma(-l21, yq1, fma(-l20, q0e, (q == 2) ? 1.0 : 0.0));
+  const double yq3 = fma(-l32, yq2, fma(-l31, yq1, fma(-l30, q0e, (q == 3) ? 1.0 : 0.0)));
+  const double zs = fma(yk3 * i3, yq3, fma(yk2 * i2, yq2, fma(yk1 * i1, yq1, (k0e * i0) * q0e)));
+  const double iq = q == 0 ? i0 : (q == 1 ? i1 : (q == 2 ? i2 : i3));
+  const double ykq = q == 0 ? k0e : (q == 1 ? yk1 : (q == 2 ? yk2 : yk3));
+  const double lrow1 = q == 0 ? l10 : (q == 1 ? 1.0 : 0.0);                                      // L[1][q]
+  const double lrow2 = q == 0 ? l20 : (q == 1 ? l21 : (q == 2 ? 1.0 : 0.0));                   // L[2][q]
+  const double lrow3 = q == 0 ? l30 : (q == 1 ? l31 : (q == 2 ? l32 : 1.0));                   // L[3][q]
+  const double lkq = kc == 0 ? q0e : (kc == 1 ? lrow1 : (kc == 2 ? lrow2 : lrow3));
   L16_STAMP(0)
-  // B operands: W rows of every tile column; A operands: -(W P^-1) rows of the wave's own tile rows.  No branches: tile
-  // rows beyond the matrix hold zeros or stale values that only ever reach tiles nobody reads.
-  double bop[L16_NT], aop[L16_NG];
-#pragma unroll
-  for (int J = 0; J < L16_NT; ++J) bop[J] = W[lb + 16 * J];
+  // Y = W L^-T row by row (the scalar sweep's own arithmetic: four rank-one updates in a row), component q of it into
+  // the plane Yp: the rank-4 update is  T -= (Y D^-1) Y^T  -- A operand -Y[row][q] / d_q, B operand Y[column][q].
+  // (The first form of this kernel multiplied W by the explicit P^-1: entries of size 1 / lambda_min(P) against W's
+  // 433 cancel to O(1) -- 1e-6 relative on the objective at c / noise = 4e4 where the scalar sweep gives 6e-12.)
+  // Pivot rows and columns through the operands: pivot row i' carries A = Linv[q][i'] / d_q - L[i'][q], so the MFMA
+  // yields T_pj - W_jp + (W P^-1)_jp (the first two cancel to the rounding of Y); pivot column j' carries
+  // B = Y[j'][q] - Linv[q][j'] for the mirror image.  No accumulator is touched for them.
+  double aop[L16_NG];
 #pragma unroll
   for (int g = 0; g < L16_NG; ++g) {
     const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);  // (role 1 has no fourth tile row: a harmless duplicate of row 0)
     const double* wr = W + 16 * I + col;
-    double s = wr[0] * z0;
-    s = fma(wr[L16_WS], z1, s);
-    s = fma(wr[2 * L16_WS], z2, s);
-    s = fma(wr[3 * L16_WS], z3, s);
-    aop[g] = -s;
+    const double y0 = wr[0];
+    const double y1 = fma(-l10, y0, wr[L16_WS]);
+    const double y2 = fma(-l21, y1, fma(-l20, y0, wr[2 * L16_WS]));
+    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, wr[3 * L16_WS])));
+    const double yq = q == 0 ? y0 : (q == 1 ? y1 : (q == 2 ? y2 : y3));
+    S.Yp[0][lb + 16 * I] = yq;
+    aop[g] = -(yq * iq);
   }
-  // the pivot rows and columns through the OPERANDS (no accumulator is touched for them):
-  //   rows: in the tile row of the pivots the A operand of the four pivot rows is (P^-1 - I): the MFMA yields
-  //   T_pj - W_jp + (W P^-1)_jp, and the first two cancel exactly (W_jp was copied from that very register);
-  //   columns: in the tile column of the pivots the B operand of the four pivot columns is (P - I): the MFMA yields
-  //   T_ip - (W P^-1 P)_ip + (W P^-1)_ip -- the first two cancel to rounding (~eps |P|, relative to the result).
   {
-    const double ident = (pc && kc == q) ? 1.0 : 0.0;
-    const double am = pc ? zs - ident : 0.0;  // (P^-1 - I)[kc][q]
-    const int gp2 = 6 - role - Jp;           // = 2 g of the group whose tile row is Jp, if this wave has it
+    const double apiv = fma(ykq, iq, -lkq);
+    const int gp2 = 6 - role - Jp;  // = 2 g of the group whose tile row is Jp, if this wave has it
 #pragma unroll
-    for (int g = 0; g < L16_NG; ++g) aop[g] = (gp2 == 2 * g && pc) ? am : aop[g];
-#pragma unroll
-    for (int J = 0; J < L16_NT; ++J) bop[J] = (J == Jp) ? bop[J] - ident : bop[J];
+    for (int g = 0; g < L16_NG; ++g) aop[g] = (gp2 == 2 * g && pc) ? apiv : aop[g];
   }
+  __syncthreads();  // (the other wave's rows of Y)
   L16_STAMP(1)
+  double bop[L16_NT];
+#pragma unroll
+  for (int J = 0; J < L16_NT; ++J) bop[J] = S.Yp[0][lb + 16 * J];
+  {
+    const double bdel = pc ? ykq : 0.0;
+#pragma unroll
+    for (int J = 0; J < L16_NT; ++J) bop[J] = (J == Jp) ? bop[J] - bdel : bop[J];
+  }
   // one MFMA per tile
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {

@@ -670,14 +670,14 @@ __global__ void __launch_bounds__(64) k_fin_prepare(EdgeDev* edges, int B, const
   }
 }
 
-// problem i = (edge i / 13, start i % 13): projected start, first evaluation requested
+// problem i = (edge i / nstart, start i % nstart): projected start, first evaluation requested
 __global__ void __launch_bounds__(256) k_lb_init(LbProb* probs, int P, const double* starts, int* slot_edge,
-                                                 double* slot_theta, int* slot_src) {
+                                                 double* slot_theta, int* slot_src, LbCfg cfg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   LbProb& p = probs[i];
-  double lo[3], hi[3];
-  lb_bounds(lo, hi);
+  const double* lo = cfg.lo;
+  const double* hi = cfg.hi;
   for (int c = 0; c < 3; ++c) {
     double v = starts[(size_t)i * 3 + c];
     v = v < lo[c] ? lo[c] : (v > hi[c] ? hi[c] : v);
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(256) k_lb_init(LbProb* probs, int P, const dou
   p.ifun = 0;
   p.task = LB_TASK_FIRST;
   p.why = 0;
-  p.edge = i / 13;
+  p.edge = i / cfg.nstart;
   p.f = 0.0;
   slot_edge[i] = p.edge;
   slot_src[i] = i;
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) k_lb_init(LbProb* probs, int P, const dou
 // slot k of the round just evaluated -> its problem advances; problems still running claim a slot of the next round
 __global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, const int* cur_count, const int* slot_src, const double* f,
                                                    const double* g, int* next_count, int* next_edge, double* next_theta,
-                                                   int* next_src) {
+                                                   int* next_src, LbCfg cfg) {
 #pragma clang fp contract(off)
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   // the launch is sized by the host's last KNOWN count (it reads the counter only every few rounds); the true number of
@@ -709,8 +709,7 @@ __global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, const int* cur
   if (k >= *cur_count) return;
   const int pid = slot_src[k];
   LbProb p = probs[pid];
-  double lo[3], hi[3];
-  lb_bounds(lo, hi);
+  double lo[3] = {cfg.lo[0], cfg.lo[1], cfg.lo[2]}, hi[3] = {cfg.hi[0], cfg.hi[1], cfg.hi[2]};
   const double gk[3] = {g[(size_t)k * 3], g[(size_t)k * 3 + 1], g[(size_t)k * 3 + 2]};
   lb_advance(p, f[k], gk, lo, hi);
   if (p.task != LB_TASK_DONE) {
@@ -723,19 +722,19 @@ __global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, const int* cur
 }
 
 // best restart of every edge (first minimum, np.argmin in sklearn_gpr.py:292) -> fin_par[0..2] = exp(theta)
-__global__ void __launch_bounds__(64) k_lb_pick(EdgeDev* edges, int B, const LbProb* probs, double* theta_out) {
+__global__ void __launch_bounds__(64) k_lb_pick(EdgeDev* edges, int B, const LbProb* probs, double* theta_out, int nstart) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B) return;
   int best = 0;
-  double fb = probs[(size_t)e * 13].f;
-  for (int r = 1; r < 13; ++r) {
-    const double fv = probs[(size_t)e * 13 + r].f;
+  double fb = probs[(size_t)e * nstart].f;
+  for (int r = 1; r < nstart; ++r) {
+    const double fv = probs[(size_t)e * nstart + r].f;
     if (fv < fb) {
       fb = fv;
       best = r;
     }
   }
-  const LbProb& p = probs[(size_t)e * 13 + best];
+  const LbProb& p = probs[(size_t)e * nstart + best];
   double* par = edges[e].fin_par;
   for (int c = 0; c < 3; ++c) {
     par[c] = exp(p.x[c]);
@@ -881,26 +880,38 @@ hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const uns
   return hipGetLastError();
 }
 
+LbCfg lb_default_cfg() {
+  LbCfg c;
+  c.lo[0] = log(0.01);  // gpet.py:246-248
+  c.hi[0] = log(1e3);
+  c.lo[1] = log(0.1);
+  c.hi[1] = log(100.0);
+  c.lo[2] = log(1e-18);
+  c.hi[2] = log(1.0);
+  c.nstart = 13;
+  return c;
+}
+
 hipError_t launch_lb_init(hipStream_t st, void* d_probs, int P, const double* d_starts, int* slot_edge, double* slot_theta,
-                          int* slot_src) {
+                          int* slot_src, const LbCfg& cfg) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(k_lb_init, dim3((P + 255) / 256), dim3(256), 0, st, (LbProb*)d_probs, P, d_starts, slot_edge,
-                     slot_theta, slot_src);
+                     slot_theta, slot_src, cfg);
   return hipGetLastError();
 }
 
 hipError_t launch_lb_advance(hipStream_t st, void* d_probs, int n_upper, const int* cur_count, const int* slot_src,
                              const double* d_f, const double* d_g, int* next_count, int* next_edge, double* next_theta,
-                             int* next_src) {
+                             int* next_src, const LbCfg& cfg) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(k_lb_advance, dim3((n_upper + 63) / 64), dim3(64), 0, st, (LbProb*)d_probs, cur_count, slot_src, d_f,
-                     d_g, next_count, next_edge, next_theta, next_src);
+                     d_g, next_count, next_edge, next_theta, next_src, cfg);
   return hipGetLastError();
 }
 
-hipError_t launch_lb_pick(hipStream_t st, EdgeDev* d_edges, int B, const void* d_probs, double* d_theta_out) {
+hipError_t launch_lb_pick(hipStream_t st, EdgeDev* d_edges, int B, const void* d_probs, double* d_theta_out, int nstart) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(k_lb_pick, dim3((B + 63) / 64), dim3(64), 0, st, d_edges, B, (const LbProb*)d_probs, d_theta_out);
+  hipLaunchKernelGGL(k_lb_pick, dim3((B + 63) / 64), dim3(64), 0, st, d_edges, B, (const LbProb*)d_probs, d_theta_out, nstart);
   return hipGetLastError();
 }
 

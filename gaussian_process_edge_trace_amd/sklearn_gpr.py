@@ -6,9 +6,14 @@ exercises -- ``fit`` with ``optimizer=None`` and ``predict`` (mean / std) -- wit
 modified ``normalize_y`` semantics (True centres only, False standardises; sklearn_gpr.py:221-234)
 and runs them in libgpet_hip.so (the kernels of the converged fit: Cholesky + alpha + forward
 substitution per query point).  Query points must be an arithmetic progression (the tracer's
-x-grid).  ``predict(return_cov=True)``, ``sample_y`` (the device eigen-factor sampler on the query grid)
-and ``log_marginal_likelihood`` run on the device too; hyper-parameter optimisation (``optimizer != None``)
-lives in ``GP_Edge_Tracing`` (the converged fit), not here.
+x-grid): the device kernels index the posterior by grid position.  ``predict(return_cov=True)``, ``sample_y`` (the
+device eigen-factor sampler on the query grid) and ``log_marginal_likelihood`` run on the device too, and so does
+``optimizer="fmin_l_bfgs_b"`` (sklearn_gpr.py:254-295, 587-607): theta0 plus ``n_restarts_optimizer`` log-uniform
+restarts drawn like the reference draws them, minimised by the device L-BFGS-B of the tracer's converged fit
+(``gpet_final_optimize``) inside the kernel's bounds.  The device objective carries its regulariser as
+``noise_level * w_i + 1e-6`` on the diagonal, so the optimiser needs ``alpha == 1e-6`` when a ``WeightedWhiteKernel`` is
+present (the reference's only use, gpet.py:154-158); without one any ``alpha`` is folded into fixed weights.  A callable
+optimiser is not supported.
 """
 from __future__ import annotations
 
@@ -26,6 +31,29 @@ class WeightedWhiteKernel(object):
         self.edge_length = int(edge_length)
         self.noise_level = float(noise_level)
         self.noise_level_bounds = noise_level_bounds
+
+
+def _log_bounds(obj, name, value):
+    """log bounds of one hyper-parameter as scikit-learn kernels carry them (``<name>_bounds``; "fixed" -> lo == hi)."""
+    b = getattr(obj, name + "_bounds", None) if obj is not None else None
+    if b is None or isinstance(b, str):
+        return [np.log(value), np.log(value)] if isinstance(b, str) or obj is None else [np.log(1e-5), np.log(1e5)]
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return [float(np.log(b[0])), float(np.log(b[1]))]
+
+
+def _kernel_bounds(kernel, const, ell, white):
+    """(3, 2) log bounds of (constant, length_scale, noise_level); a dict kernel may carry 'bounds' = that array in linear units."""
+    if isinstance(kernel, dict):
+        b = kernel.get("bounds")
+        if b is not None:
+            return np.log(np.asarray(b, dtype=np.float64).reshape(3, 2))
+        lo_hi = [np.log(1e-5), np.log(1e5)]
+        return np.array([lo_hi, lo_hi, lo_hi if white is not None else [0.0, 0.0]])
+    k = kernel.k1 if hasattr(kernel, "k1") and isinstance(getattr(kernel, "k2", None), WeightedWhiteKernel) else kernel
+    rows = [_log_bounds(k.k1, "constant_value", const), _log_bounds(k.k2, "length_scale", ell)]
+    rows.append(_log_bounds(white, "noise_level", white.noise_level) if white is not None else [0.0, 0.0])
+    return np.array(rows)
 
 
 def _unpack_kernel(kernel):
@@ -61,9 +89,10 @@ def add_white(kernel, white):
 class GaussianProcessRegressor(object):
     def __init__(self, kernel=None, alpha=1e-10, optimizer=None, n_restarts_optimizer=0, normalize_y=False,
                  copy_X_train=True, random_state=None, *, device=0, _ctx=None):
-        if optimizer is not None:
-            raise NotImplementedError("hyper-parameter optimisation runs inside GP_Edge_Tracing.__call__")
+        if optimizer is not None and optimizer != "fmin_l_bfgs_b":
+            raise NotImplementedError("optimizer must be None or 'fmin_l_bfgs_b' (the device L-BFGS-B); callables are not supported")
         self.kernel = kernel
+        self._batches = {}  # device batches of _device_fit_predict, by (grid length, samples, factor): built once, reused
         self.alpha = alpha
         self.optimizer = optimizer
         self.n_restarts_optimizer = n_restarts_optimizer
@@ -94,14 +123,79 @@ class GaussianProcessRegressor(object):
             if n == white.edge_length:
                 w = np.zeros(n)
         alpha = np.broadcast_to(np.asarray(self.alpha, dtype=np.float64), (n,))
-        if n > 4096:
-            raise NotImplementedError("more than 4096 training points")
+        if n > 16384:
+            raise NotImplementedError("more than 16384 training points (the n x n kernel matrix lives in HBM per edge)")
         self._fit = dict(kt=kt, nu=nu, const=const, ell=ell, x=X[:, 0].copy(), yt=yt, noise=nl * w + alpha)
         self.X_train_, self.y_train_ = X, yt
+        self.log_marginal_likelihood_value_ = None
+        if self.optimizer is not None:
+            self._optimise(const, ell, nl, w, alpha, white)
         return self
 
+    def _optimise(self, const, ell, nl, w, alpha, white):
+        """sklearn_gpr.py:254-295: maximise the log marginal likelihood from theta0 and n_restarts_optimizer log-uniform
+        restarts (RandomState(random_state).uniform over the log bounds, one restart at a time like the reference), keep
+        the best; on the device (gpet_final_optimize)."""
+        f = self._fit
+        bounds = _kernel_bounds(self.kernel, const, ell, white)
+        if white is not None:
+            if not np.allclose(alpha, 1e-6, rtol=0, atol=1e-18):
+                raise NotImplementedError("optimizer with a WeightedWhiteKernel needs alpha == 1e-6 (the objective's fixed jitter)")
+            weights, theta0 = w, np.log([const, ell, nl])
+        else:
+            weights, theta0 = alpha - 1e-6, np.log([const, ell, 1.0])  # K_ii = c + 1 * (alpha - 1e-6) + 1e-6
+            bounds[2] = [0.0, 0.0]
+        starts = [theta0]
+        if self.n_restarts_optimizer > 0:
+            if not np.all(np.isfinite(bounds)):
+                raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+            rng = self.random_state if isinstance(self.random_state, np.random.RandomState) else np.random.RandomState(self.random_state)
+            for _ in range(self.n_restarts_optimizer):
+                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
+        b = self._batch_for(np.arange(4.0), 1, False)
+        b.final_set_training_all([f["x"]], [f["yt"]], [weights])
+        theta, fmin, self._opt_rounds = b.final_optimize(np.asarray(starts)[None], bounds)
+        c_opt, l_opt, nl_opt = np.exp(theta[0])
+        self.log_marginal_likelihood_value_ = -float(fmin[0])
+        self.kernel_theta_ = theta[0].copy()
+        f.update(const=float(c_opt), ell=float(l_opt), noise=(nl_opt * w + alpha) if white is not None else f["noise"])
+        self._fit_nl = float(nl_opt) if white is not None else 1.0
+
+    def _batch_for(self, X, n_samples, want_factor):
+        """The device batch of one edge whose grid is the query progression: built once per (length, samples, factor)
+        and kept (a 4 x Lq image upload, its gradient KDE and the arena cost more than the fit)."""
+        f = self._fit
+        xq = np.asarray(X, dtype=np.float64).reshape(-1)
+        Lq = xq.shape[0]
+        key = (Lq, max(1, int(n_samples)), bool(want_factor), f["kt"], f["nu"], max(8, len(f["x"])))
+        b = self._batches.get(key)
+        if b is None:
+            p = _lib.GpetParams()
+            p.kernel_type = _lib.KERNEL_MATERN if f["kt"] == "Matern" else _lib.KERNEL_RBF
+            p.nu, p.sigma_f, p.length_scale, p.noise_y = f["nu"], 1.0, f["ell"], 1.0
+            p.n_samples, p.n_keep, p.delta_x, p.pixel_thresh, p.score_thresh = key[1], 1, max(2, Lq // 4), 2, 1.0
+            p.fix_endpoints, p.x_st, p.x_en, p.n_init = 1, 0, Lq - 1, 1
+            p.obs_cap, p.jitter = key[5], 0.0
+            p.factor_cap, p.z_cols = (Lq, Lq) if want_factor else (4, 4)
+            img = np.zeros((4, Lq), dtype=np.float32)
+            img[0, 0] = 1.0
+            b = _lib.Batch(self._ctx, [img], [p], [np.array([[0, 0]], dtype=np.int64)])
+            self._batches[key] = b
+        return b
+
+    def close(self):
+        for b in self._batches.values():
+            b.close()
+        self._batches = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _device_fit_predict(self, X, n_samples=1, want_factor=False):
-        """One throw-away batch of a single edge whose grid is 0..Lq-1 ((x - X_m)/X_s maps it onto the query points):
+        """A (cached) batch of a single edge whose grid is 0..Lq-1 ((x - X_m)/X_s maps it onto the query points):
         the converged-fit kernels evaluate K, its Cholesky factor, alpha and the posterior at the queries."""
         f = self._fit
         xq = np.asarray(X, dtype=np.float64).reshape(-1)
@@ -109,16 +203,7 @@ class GaussianProcessRegressor(object):
         step = (xq[-1] - xq[0]) / (Lq - 1) if Lq > 1 else 1.0
         if Lq < 4 or step <= 0 or not np.allclose(xq, xq[0] + step * np.arange(Lq), rtol=0, atol=1e-9 * max(1.0, abs(step))):
             raise NotImplementedError("query points must be an increasing arithmetic progression of >= 4 points")
-        p = _lib.GpetParams()
-        p.kernel_type = _lib.KERNEL_MATERN if f["kt"] == "Matern" else _lib.KERNEL_RBF
-        p.nu, p.sigma_f, p.length_scale, p.noise_y = f["nu"], 1.0, f["ell"], 1.0
-        p.n_samples, p.n_keep, p.delta_x, p.pixel_thresh, p.score_thresh = max(1, int(n_samples)), 1, max(2, Lq // 4), 2, 1.0
-        p.fix_endpoints, p.x_st, p.x_en, p.n_init = 1, 0, Lq - 1, 1
-        p.obs_cap, p.jitter = max(8, len(f["x"])), 0.0
-        p.factor_cap, p.z_cols = (Lq, Lq) if want_factor else (4, 4)
-        img = np.zeros((4, Lq), dtype=np.float32)
-        img[0, 0] = 1.0
-        b = _lib.Batch(self._ctx, [img], [p], [np.array([[0, 0]], dtype=np.int64)])
+        b = self._batch_for(X, n_samples, want_factor)
         # per-point noise folded into the weights: K_ii = const + 1.0 * noise_i + 1e-6 - 1e-6
         b.final_set_training_all([f["x"]], [f["yt"]], [f["noise"] - 1e-6])
         X_s = 1.0 / step
@@ -133,12 +218,9 @@ class GaussianProcessRegressor(object):
         if return_std and return_cov:
             raise RuntimeError("At most one of return_std or return_cov can be requested.")  # sklearn_gpr.py:355-357
         b, mean, std = self._device_fit_predict(X)
-        try:
-            if return_cov:
-                b.final_cov()  # (K** - V^T V) * y_train_std^2 on the f64 matrix cores
-                return mean, b.read(_lib.BUF_COV)
-        finally:
-            b.close()
+        if return_cov:
+            b.final_cov()  # (K** - V^T V) * y_train_std^2 on the f64 matrix cores
+            return mean, b.read(_lib.BUF_COV)
         if return_std:
             return mean, std
         return mean
@@ -150,18 +232,15 @@ class GaussianProcessRegressor(object):
         library's convention (include/gpet_hip.h, gpet_gp_factor); LAPACK's are implementation-defined."""
         n_samples = int(n_samples)
         b, mean, _ = self._device_fit_predict(X, n_samples, want_factor=True)
-        try:
-            b.final_cov()
-            b.factor()
-            b.normals([int(random_state)])
-            sc = b.scalars()
-            sc.y_s = 1.0
-            b.write_scalars(sc)
-            b.write(_lib.BUF_MEAN, mean)
-            b.sample()
-            return b.read(_lib.BUF_SAMPLES).T.copy()
-        finally:
-            b.close()
+        b.final_cov()
+        b.factor()
+        b.normals([int(random_state)])
+        sc = b.scalars()
+        sc.y_s = 1.0
+        b.write_scalars(sc)
+        b.write(_lib.BUF_MEAN, mean)
+        b.sample()
+        return b.read(_lib.BUF_SAMPLES).T.copy()
 
     def log_marginal_likelihood(self, theta=None, eval_gradient=False):
         """Log marginal likelihood of theta = log(constant, length_scale, noise_level) on the training set of ``fit``
@@ -171,10 +250,7 @@ class GaussianProcessRegressor(object):
         if theta is None:
             theta = np.log([f["const"], f["ell"], 1.0])
         b, _, _ = self._device_fit_predict(np.arange(4.0))
-        try:
-            val, grad = b.lml_batch([0], np.asarray(theta, dtype=np.float64).reshape(1, 3))
-        finally:
-            b.close()
+        val, grad = b.lml_batch([0], np.asarray(theta, dtype=np.float64).reshape(1, 3))
         if eval_gradient:
             return -float(val[0]), -grad[0]
         return -float(val[0])

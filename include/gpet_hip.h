@@ -271,6 +271,14 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
 int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
                        int stride, int32_t* rounds_out);
 
+/* The optimiser alone, for a caller's own training sets (GaussianProcessRegressor.fit with optimizer="fmin_l_bfgs_b",
+ * sklearn_gpr.py:254-295, 587-607): L-BFGS-B from n_starts start points per edge (starts [B][n_starts][3], theta = log
+ * (constant, length_scale, noise_level)) inside bounds [3][2] = (lo, hi) per component, on the training sets of
+ * gpet_final_set_training(_all); theta_out [B*4] = the best start's optimum (first minimum, np.argmin) and its objective
+ * value (-log marginal likelihood); it is also left in GPET_BUF_FIN_PAR[0..2] as exp(theta). */
+int gpet_final_optimize(gpet_batch* b, int n_starts, const double* starts, const double* bounds, double* theta_out,
+                        int32_t* rounds_out);
+
 /* Device time of the LML kernel launches of this batch since the last reset (hipEvents around each launch), the
  * number of objective evaluations and of launches; any of the outputs may be NULL.  (bench.py's roofline leg.) */
 int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches);

@@ -335,6 +335,54 @@ def test_gaussian_process_regressor_mirror(amd, ctx, golden):
     np.testing.assert_allclose(gp.predict(xq[:, None]), orc.gp_predict(fit, xq, want_cov=False)["mean"], rtol=1e-8)
 
 
+def test_gaussian_process_regressor_optimizer(amd, ctx):
+    """GaussianProcessRegressor(optimizer="fmin_l_bfgs_b", n_restarts_optimizer=4) (sklearn_gpr.py:254-295, 587-607) on the
+    device: the start points are the reference's (theta0, then RandomState(seed).uniform over the log bounds, one restart at
+    a time), every start reaches the minimum scipy's L-BFGS-B reaches on the same (oracle) objective, the best one is kept,
+    and predictions use the optimised kernel.  scikit-learn kernel objects with bounds, and the dict form."""
+    import scipy.optimize
+    from gaussian_process_edge_trace_amd.sklearn_gpr import GaussianProcessRegressor, WeightedWhiteKernel, add_white
+    sk = pytest.importorskip("sklearn.gaussian_process.kernels")
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.choice(np.arange(0, 300), size=60, replace=False)).astype(float)
+    y = 4 * np.sin(x / 25.0) + rng.normal(0, 0.25, x.size) + 1.0
+    w = np.ones(x.size)
+    w[[0, -1]] = 1e-7
+    xq = np.arange(0, 300, dtype=float)
+    bounds = np.array([[1e-2, 1e3], [1.0, 200.0], [1e-4, 1.0]])
+    white = WeightedWhiteKernel(noise_weight=w, edge_length=xq.size, noise_level=0.3, noise_level_bounds=tuple(bounds[2]))
+    kern = add_white(sk.ConstantKernel(2.0, tuple(bounds[0])) * sk.RBF(20.0, tuple(bounds[1])), white)
+    gp = GaussianProcessRegressor(kernel=kern, alpha=1e-6, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=4, normalize_y=False,
+                                  random_state=11, _ctx=ctx).fit(x[:, None], y)
+    # the reference's start points and scipy on the oracle's objective (standardised y: normalize_y=False standardises)
+    yt = (y - y.mean()) / y.std()
+    lb = np.log(bounds)
+    starts = [np.log([2.0, 20.0, 0.3])]
+    r = np.random.RandomState(11)
+    for _ in range(4):
+        starts.append(r.uniform(lb[:, 0], lb[:, 1]))
+
+    def obj(th):
+        lml, g = orc.lml_and_grad(th, x, yt, w, "RBF", 2.5)
+        return -lml, -g
+    res = [scipy.optimize.minimize(obj, th0, method="L-BFGS-B", jac=True, bounds=list(map(tuple, lb))) for th0 in starts]
+    best = min(res, key=lambda q: q.fun)
+    np.testing.assert_allclose(-gp.log_marginal_likelihood_value_, best.fun, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(gp.kernel_theta_, best.x, rtol=0, atol=2e-3)
+    c, l, nl = np.exp(gp.kernel_theta_)
+    fit = orc.gp_fit(x, y, w, c, l, "RBF", 2.5, nl, xq.size, jitter=1e-6, center=True, scale=True)
+    pred = orc.gp_predict(fit, xq, want_cov=False)
+    mean, std = gp.predict(xq[:, None], return_std=True)
+    np.testing.assert_allclose(mean, pred["mean"], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(std, pred["std"], rtol=1e-5, atol=1e-7)
+    # dict kernel with explicit bounds, no restarts: the optimum from theta0 alone
+    kd = dict(kernel="RBF", nu=2.5, constant=2.0, length_scale=20.0, white=white, bounds=bounds)
+    gp2 = GaussianProcessRegressor(kernel=kd, alpha=1e-6, optimizer="fmin_l_bfgs_b", normalize_y=False, _ctx=ctx).fit(x[:, None], y)
+    np.testing.assert_allclose(-gp2.log_marginal_likelihood_value_, res[0].fun, rtol=1e-7, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        GaussianProcessRegressor(kernel=kd, optimizer=lambda *a: None, _ctx=ctx)
+
+
 def test_gaussian_process_regressor_mirror_many_points(amd, ctx):
     """The GPR mirror beyond the LDS-resident sizes: 300 training points (K and the factor in HBM)."""
     from gaussian_process_edge_trace_amd.sklearn_gpr import GaussianProcessRegressor, WeightedWhiteKernel
