@@ -4426,24 +4426,28 @@ __global__ void __launch_bounds__(1024) k_lml2(EdgeDev* edges, const int* edge_o
 // Layout of the bordered matrix (size n4 + 1 <= 112, n4 = n rounded up to a multiple of 4): indices 0..n-1 = K,
 // n..n4-1 = identity padding (pivots 1: log 1 = 0, no coupling), n4 = the y border (never a pivot), the rest zero.
 // The lower triangle of 16x16 tiles (diagonal tiles whole) lives in the accumulator registers of TWO waves: wave
-// `role` owns the tile rows I_g = 6 - 2 g - role, g = 0..3, i.e. {6, 4, 2, 0} and {5, 3, 1} (16 and 12 tiles).  ONE
-// instruction stream serves both: 16 static accumulator slots (g, J), J < 7 - 2 g, whose tile row is a scalar of the
-// wave; slot (g, J) is in use when J <= I_g.  (Two streams with exactly 14 tiles each were built first: the register
-// allocator kept both sets of accumulators apart -- 224 + 165 registers, one wave per SIMD.)
+// `role` owns the tile rows {6, 3, 1, 0} (role 0) and {5, 4, 2} (role 1): 14 tiles each.  ONE instruction stream serves
+// both: 16 static accumulator slots (g, J), J < 7 - 2 g, whose tile row l16_row(g, role) is a scalar of the wave; slot
+// (g, J) is in use when J <= that row -- 12 slots in both waves, two in one of them each.  (Two separate streams were
+// built first: the register allocator kept both sets of accumulators apart -- 224 + 165 registers, one wave per SIMD.
+// On this chip the f64 MFMA runs on the vector unit's own FMA lanes -- SQ_VALU_MFMA_BUSY_CYCLES + the VALU issue cycles
+// add up to the kernel's time, nothing overlaps between the waves of a SIMD -- so what counts is the SUM of MFMA and
+// VALU cycles of the busier wave: the split 16 + 12 of {6, 4, 2, 0} / {5, 3, 1} cost 128 cycles a step more.)
 // f64 C/D layout: lane (q = l >> 4, col = l & 15), register r holds element (row q + 4 r, column col) of its tile;
 // A operand: lane holds A[row = col][k = q], B operand: B[k = q][column = col].
 //
 // A block step for the pivots k0..k0+3 (tile Jp, sub-block B; W = columns k0..k0+3 of the matrix = the PANEL, in LDS
 // k-major, copied out of the tiles at the end of the previous step; P = its rows k0..k0+3):
 //   P = L D L^T in every lane (unit lower L; the four pivots d are the squared Cholesky diagonal in the scalar order);
-//   Y = W L^-T row by row (each lane the rows of its tile rows: six FMAs), component q of it to the plane Yp; barrier;
+//   Y = W L^-T row by row, straight from the panel (each lane the rows 16 J + col of all seven tile columns: six FMAs
+//   each; component q of them are its B operands, four of them -- its own tile rows -- its A operands);
 //   the four rank-one updates of the scalar sweep as ONE MFMA per tile:  T -= (Y D^-1) Y^T,  A operand -Y[row][q] / d_q,
 //   B operand Y[column][q] -- the scalar algorithm's own arithmetic, no product with an explicit P^-1;
 //   the pivot rows and columns must become (W P^-1)^T and W P^-1: the A operand of the four pivot rows is
 //   Linv[q][i'] / d_q - L[i'][q] instead, the B operand of the four pivot columns Y[j'][q] - Linv[q][j']: the MFMA
 //   then yields T_pj - W_jp + (W P^-1)_jp with the first two cancelling to the rounding of Y -- no accumulator touched;
-//   only the 4x4 block itself is written: -P^-1 (P^-1[kc][q] from the two columns of L^-1 each lane solves for);
-//   the next panel is copied into the other panel buffer; TWO workgroup barriers per step.
+//   the 4x4 block of the pivots gets both and becomes 2 I - P^-1: the epilogue takes the 2 off the diagonal;
+//   the next panel is copied into the other panel buffer (one scalar jump on its tile column); ONE barrier per step.
 // n^3 / 2 FMAs of the scalar sweep become 25 x 28 MFMAs (1024 FMAs each, 68 % useful at n = 98).  The training x sit on
 // a lattice (pixel columns), so the correlation and its length-scale derivative are tabulated at the integer lags once
 // per problem: lagmax + 1 transcendentals instead of n^2 for the set-up and n^2 more for the gradient.
@@ -4457,10 +4461,15 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define L16_NS 16
 __host__ __device__ constexpr int l16_sg(int t) { return t < 7 ? 0 : (t < 12 ? 1 : (t < 15 ? 2 : 3)); }  // slot -> group
 __host__ __device__ constexpr int l16_sj(int t) { return t < 7 ? t : (t < 12 ? t - 7 : (t < 15 ? t - 12 : 0)); }  // slot -> tile column
+// tile row of group g of wave `role`: {6, 3, 1, 0} and {5, 4, 2} -- 14 tiles each (-1: role 1 has no fourth tile row)
+__host__ __device__ constexpr int l16_row(int g, int role) { return g == 0 ? 6 - role : (g == 1 ? 3 + role : (g == 2 ? 1 + role : -role)); }
+// slot (g, J) belongs to both waves / to one of them only (the widest tile of the group's lower tile row)
+__host__ __device__ constexpr int l16_owner(int g, int J) {  // 2: both, 0 / 1: that role only
+  return g == 0 ? (J == 6 ? 0 : 2) : (g == 1 ? (J == 4 ? 1 : 2) : (g == 2 ? (J == 2 ? 1 : 2) : 0));
+}
 
 struct L16Shared {
   double Wt[2][4][L16_WS];  // panel of the current / next block step, k-major
-  double Yp[4][L16_WS];     // Y = W L^-T of the current step, k-major: every wave writes its own tile rows, all read after a barrier
   double al[L16_WS];        // alpha (row n4 of the swept matrix)
   double y[L16_WS], w[L16_WS];
   double piv[L16_WS];
@@ -4497,35 +4506,53 @@ struct L16Acc {
     wc[8] = t2_;                                                \
     wc[12] = t3_;                                               \
   }
-template <int BN, int G>
-__device__ __forceinline__ void l16_extract_group(const L16Acc& A, double* Wn, int Jn, int role, int q, int col) {
-  constexpr int base = G == 0 ? 0 : (G == 1 ? 7 : (G == 2 ? 12 : 15)), cap = 7 - 2 * G;
-  const int I = 6 - 2 * G - role;
-  if (I < Jn) return;  // (tile row above the pivots: its panel rows come out of tile row Jn)
-  const bool pcn = (col >> 2) == BN;
-  double* wc = Wn + (col & 3) * L16_WS + 16 * I + q;
-  switch (Jn) {
-    case 0: L16_COLPART(base) break;
-    case 1: if (cap > 1) L16_COLPART(base + (cap > 1 ? 1 : 0)) break;
-    case 2: if (cap > 2) L16_COLPART(base + (cap > 2 ? 2 : 0)) break;
-    case 3: if (cap > 3) L16_COLPART(base + (cap > 3 ? 3 : 0)) break;
-    case 4: if (cap > 4) L16_COLPART(base + (cap > 4 ? 4 : 0)) break;
-    case 5: if (cap > 5) L16_COLPART(base + (cap > 5 ? 5 : 0)) break;
-    default: if (cap > 6) L16_COLPART(base + (cap > 6 ? 6 : 0)) break;
+// ONE scalar jump on the tile column Jn of the next pivots; inside a case everything but the wave's role is a constant:
+// the tiles (I, Jn) of the tile rows I >= Jn hold the panel's columns, and the tile row Jn itself -- which exactly one
+// of the two waves owns -- holds its rows for the tile columns left of it.
+template <int BN, int JN, int G>
+__device__ __forceinline__ void l16_extract_col(const L16Acc& A, double* Wn, int role, int q, int col) {
+  constexpr int base = G == 0 ? 0 : (G == 1 ? 7 : (G == 2 ? 12 : 15));
+  constexpr int lo = l16_row(G, 0) < l16_row(G, 1) ? l16_row(G, 0) : l16_row(G, 1);
+  constexpr int hi = l16_row(G, 0) < l16_row(G, 1) ? l16_row(G, 1) : l16_row(G, 0);
+  if constexpr (JN <= hi) {
+    if (JN <= lo || role == (l16_row(G, 0) == hi ? 0 : 1)) {  // this wave's tile row of the group is not above the pivots
+      const bool pcn = (col >> 2) == BN;
+      double* wc = Wn + (col & 3) * L16_WS + 16 * l16_row(G, role) + q;
+      L16_COLPART(base + JN)
+    }
   }
-  if (I == Jn) {
+}
+template <int BN, int JN>
+__device__ __forceinline__ void l16_extract_case(const L16Acc& A, double* Wn, int role, int q, int col) {
+  l16_extract_col<BN, JN, 0>(A, Wn, role, q, col);
+  l16_extract_col<BN, JN, 1>(A, Wn, role, q, col);
+  l16_extract_col<BN, JN, 2>(A, Wn, role, q, col);
+  l16_extract_col<BN, JN, 3>(A, Wn, role, q, col);
+  // tile row JN = l16_row(G, par)
+  constexpr int par = (JN == 5 || JN == 4 || JN == 2) ? 1 : 0, G = JN >= 5 ? 0 : (JN >= 3 ? 1 : (JN >= 1 ? 2 : 3));
+  static_assert(l16_row(G, par) == JN, "owner of the tile row");
+  constexpr int base = G == 0 ? 0 : (G == 1 ? 7 : (G == 2 ? 12 : 15));
+  if (JN > 0 && role == par) {
     double* wr = Wn + q * L16_WS + col;
 #pragma unroll
-    for (int J = 0; J + 1 < cap; ++J)
-      if (J < Jn) wr[16 * J] = A.v[base + J][BN];
+    for (int J = 0; J < JN; ++J) {
+      const double t_ = A.v[base + J][BN];
+      asm volatile("; l16 panel row from slot %0" ::"n"(base + J));
+      wr[16 * J] = t_;
+    }
   }
 }
 template <int BN>
 __device__ __forceinline__ void l16_extract(const L16Acc& A, double* Wn, int Jn, int role, int q, int col) {
-  l16_extract_group<BN, 0>(A, Wn, Jn, role, q, col);
-  l16_extract_group<BN, 1>(A, Wn, Jn, role, q, col);
-  l16_extract_group<BN, 2>(A, Wn, Jn, role, q, col);
-  l16_extract_group<BN, 3>(A, Wn, Jn, role, q, col);
+  switch (Jn) {
+    case 0: l16_extract_case<BN, 0>(A, Wn, role, q, col); break;
+    case 1: l16_extract_case<BN, 1>(A, Wn, role, q, col); break;
+    case 2: l16_extract_case<BN, 2>(A, Wn, role, q, col); break;
+    case 3: l16_extract_case<BN, 3>(A, Wn, role, q, col); break;
+    case 4: l16_extract_case<BN, 4>(A, Wn, role, q, col); break;
+    case 5: l16_extract_case<BN, 5>(A, Wn, role, q, col); break;
+    default: l16_extract_case<BN, 6>(A, Wn, role, q, col); break;
+  }
 }
 
 #ifdef GPET_L16_PROF  // cycles per phase of a block step (wave 0 of workgroup 0 prints them)
@@ -4572,90 +4599,81 @@ __device__ __forceinline__ bool l16_step(L16Acc& A, L16Shared& S, int Jp, int n4
   const bool pc = (col >> 2) == B;  // this lane's row (A operand) / column (tile) index is one of the pivots
   const int kc = col & 3;
   const int lb = q * L16_WS + col;
-  // Per lane, from the uniform factors: columns kc and q of L^-1 (forward substitution on unit vectors),
-  //   zs = P^-1[kc][q] = sum_a Linv[a][kc] Linv[a][q] / d_a   (what the 4x4 block of the pivots becomes, negated),
-  //   lkq = L[kc][q],  ykq = Linv[q][kc],  iq = 1 / d_q.
-  const double k0e = (kc == 0) ? 1.0 : 0.0;
-  const double yk1 = fma(-l10, k0e, (kc == 1) ? 1.0 : 0.0);
-  const double yk2 = fma(-l21, yk1, fma(-l20, k0e, (kc == 2) ? 1.0 : 0.0));
-  const double yk3 = fma(-l32, yk2, fma(-l31, yk1, fma(-l30, k0e, (kc == 3) ? 1.0 : 0.0)));
-  const double q0e = (q == 0) ? 1.0 : 0.0;
-  const double yq1 = fma(-l10, q0e, (q == 1) ? 1.0 : 0.0);
-  const double yq2 = fma(-l21, yq1, fma(-l20, q0e, (q == 2) ? 1.0 : 0.0));
-  const double yq3 = fma(-l32, yq2, fma(-l31, yq1, fma(-l30, q0e, (q == 3) ? 1.0 : 0.0)));
-  const double zs = fma(yk3 * i3, yq3, fma(yk2 * i2, yq2, fma(yk1 * i1, yq1, (k0e * i0) * q0e)));
+  // Per lane, from the uniform factors: row q of L^-1 (component q of a row of Y = W L^-T is its product with the four
+  // panel entries of that row),  ykq = Linv[q][kc],  lkq = L[kc][q],  iq = 1 / d_q.
+  const double m20 = fma(l21, l10, -l20), m31 = fma(l32, l21, -l31);  // L^-1 below its first subdiagonal (uniform)
+  const double m30 = fma(-l32, m20, fma(l31, l10, -l30));
+  const double cq0 = q == 0 ? 1.0 : (q == 1 ? -l10 : (q == 2 ? m20 : m30));
+  const double cq1 = q == 1 ? 1.0 : (q == 2 ? -l21 : (q == 3 ? m31 : 0.0));
+  const double cq2 = q == 2 ? 1.0 : (q == 3 ? -l32 : 0.0);
+  const double cq3 = q == 3 ? 1.0 : 0.0;
   const double iq = q == 0 ? i0 : (q == 1 ? i1 : (q == 2 ? i2 : i3));
-  const double ykq = q == 0 ? k0e : (q == 1 ? yk1 : (q == 2 ? yk2 : yk3));
+  const double ykq = kc == 0 ? cq0 : (kc == 1 ? cq1 : (kc == 2 ? cq2 : cq3));
   const double lrow1 = q == 0 ? l10 : (q == 1 ? 1.0 : 0.0);                                      // L[1][q]
   const double lrow2 = q == 0 ? l20 : (q == 1 ? l21 : (q == 2 ? 1.0 : 0.0));                   // L[2][q]
   const double lrow3 = q == 0 ? l30 : (q == 1 ? l31 : (q == 2 ? l32 : 1.0));                   // L[3][q]
-  const double lkq = kc == 0 ? q0e : (kc == 1 ? lrow1 : (kc == 2 ? lrow2 : lrow3));
+  const double lkq = kc == 0 ? (q == 0 ? 1.0 : 0.0) : (kc == 1 ? lrow1 : (kc == 2 ? lrow2 : lrow3));
   L16_STAMP(0)
-  // Y = W L^-T row by row (the scalar sweep's own arithmetic: four rank-one updates in a row), component q of it into
-  // the plane Yp: the rank-4 update is  T -= (Y D^-1) Y^T  -- A operand -Y[row][q] / d_q, B operand Y[column][q].
+  // Y = W L^-T row by row (the scalar sweep's own arithmetic: four rank-one updates in a row), component q of it is what
+  // a lane contributes: the rank-4 update is  T -= (Y D^-1) Y^T  -- A operand -Y[row][q] / d_q, B operand Y[column][q].
   // (The first form of this kernel multiplied W by the explicit P^-1: entries of size 1 / lambda_min(P) against W's
   // 433 cancel to O(1) -- 1e-6 relative on the objective at c / noise = 4e4 where the scalar sweep gives 6e-12.)
   // Pivot rows and columns through the operands: pivot row i' carries A = Linv[q][i'] / d_q - L[i'][q], so the MFMA
   // yields T_pj - W_jp + (W P^-1)_jp (the first two cancel to the rounding of Y); pivot column j' carries
-  // B = Y[j'][q] - Linv[q][j'] for the mirror image.  No accumulator is touched for them.
+  // B = Y[j'][q] - Linv[q][j'] for the mirror image.  The 4x4 block of the pivots gets both: with Y = L D on the
+  // pivot rows the product is 2 I - P^-1 - P, so the block becomes 2 I - P^-1 (P cancels to its own rounding, 1e-16 of
+  // entries a hundred times smaller than those of P^-1); the epilogue takes the 2 off the diagonal of the swept
+  // matrix.  No accumulator is written outside the MFMAs.
+  // Every wave forms ALL the rows of Y it needs from the panel itself: its B operands are component q of the rows of
+  // all seven tile columns, its A operands those of its own four tile rows among them -- 7 instead of 4 short chains
+  // per lane, and no plane of Y through LDS, no second barrier in the step.
+  double yv[L16_NT];
+#pragma unroll
+  for (int J = 0; J < L16_NT; ++J) {
+    const double* wr = W + 16 * J + col;
+    yv[J] = fma(cq0, wr[0], fma(cq1, wr[L16_WS], fma(cq2, wr[2 * L16_WS], cq3 * wr[3 * L16_WS])));
+  }
   double aop[L16_NG];
-#pragma unroll
-  for (int g = 0; g < L16_NG; ++g) {
-    const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);  // (role 1 has no fourth tile row: a harmless duplicate of row 0)
-    const double* wr = W + 16 * I + col;
-    const double y0 = wr[0];
-    const double y1 = fma(-l10, y0, wr[L16_WS]);
-    const double y2 = fma(-l21, y1, fma(-l20, y0, wr[2 * L16_WS]));
-    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, wr[3 * L16_WS])));
-    const double yq = q == 0 ? y0 : (q == 1 ? y1 : (q == 2 ? y2 : y3));
-    S.Yp[0][lb + 16 * I] = yq;
-    aop[g] = -(yq * iq);
-  }
   {
+    const double niq = -iq;
+    aop[0] = (role ? yv[l16_row(0, 1)] : yv[l16_row(0, 0)]) * niq;
+    aop[1] = (role ? yv[l16_row(1, 1)] : yv[l16_row(1, 0)]) * niq;
+    aop[2] = (role ? yv[l16_row(2, 1)] : yv[l16_row(2, 0)]) * niq;
+    aop[3] = yv[0] * niq;  // (role 1 has no fourth tile row: its slot 15 is never multiplied)
     const double apiv = fma(ykq, iq, -lkq);
-    const int gp2 = 6 - role - Jp;  // = 2 g of the group whose tile row is Jp, if this wave has it
 #pragma unroll
-    for (int g = 0; g < L16_NG; ++g) aop[g] = (gp2 == 2 * g && pc) ? apiv : aop[g];
+    for (int g = 0; g < L16_NG; ++g) aop[g] = ((role ? l16_row(g, 1) : l16_row(g, 0)) == Jp && pc) ? apiv : aop[g];
   }
-  __syncthreads();  // (the other wave's rows of Y)
   L16_STAMP(1)
   double bop[L16_NT];
-#pragma unroll
-  for (int J = 0; J < L16_NT; ++J) bop[J] = S.Yp[0][lb + 16 * J];
   {
     const double bdel = pc ? ykq : 0.0;
 #pragma unroll
-    for (int J = 0; J < L16_NT; ++J) bop[J] = (J == Jp) ? bop[J] - bdel : bop[J];
+    for (int J = 0; J < L16_NT; ++J) bop[J] = fma(-bdel, (J == Jp) ? 1.0 : 0.0, yv[J]);  // (the factor is a scalar of the wave)
   }
   // one MFMA per tile
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {
     const int g = l16_sg(t), J = l16_sj(t);
-    if (J + 2 * g == 6) continue;  // (the last slot of each group belongs to role 0 only: below)
+    if (l16_owner(g, J) != 2) continue;
     A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop[J], A.v[t], 0, 0, 0);
   }
   if (role == 0) {
 #pragma unroll
     for (int t = 0; t < L16_NS; ++t) {
       const int g = l16_sg(t), J = l16_sj(t);
-      if (J + 2 * g != 6) continue;
+      if (l16_owner(g, J) != 0) continue;
+      A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop[J], A.v[t], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < L16_NS; ++t) {
+      const int g = l16_sg(t), J = l16_sj(t);
+      if (l16_owner(g, J) != 1) continue;
       A.v[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[g], bop[J], A.v[t], 0, 0, 0);
     }
   }
   L16_STAMP(2)
-  // the 4x4 block of the pivots itself (diagonal tile of tile row Jp, register B, lanes of the pivot columns): -P^-1.
-  // Selects, not branches: identical stores behind different branches get merged into one store through a phi of
-  // accumulator ADDRESSES, and those accumulators then live in scratch memory.
-  {
-    const int gs2 = 6 - role - Jp;  // = 2 g of the group whose tile row is Jp, if this wave has it
-#pragma unroll
-    for (int t = 0; t < L16_NS; ++t) {
-      const int g = l16_sg(t), J = l16_sj(t);
-      if (J != 6 - 2 * g && J != 5 - 2 * g) continue;  // (the diagonal tile of a group is one of these two slots)
-      const bool hit = gs2 == 2 * g && J == 6 - 2 * g - role;
-      A.v[t][B] = (hit && pc) ? -zs : A.v[t][B];
-    }
-  }
   L16_STAMP(3)
   // next panel
   if (k0 + 4 < n4) l16_extract<(B + 1) & 3>(A, &S.Wt[buf ^ 1][0][0], B == 3 ? Jp + 1 : Jp, role, q, col);
@@ -4678,7 +4696,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
     int mi[L16_NG][4], mjv[L16_NT];
 #pragma unroll
     for (int g = 0; g < L16_NG; ++g) {
-      const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);
+      const int I = l16_row(g, role) < 0 ? 0 : l16_row(g, role);
 #pragma unroll
       for (int r = 0; r < 4; ++r) mi[g][r] = S.m[16 * I + q + 4 * r];
     }
@@ -4693,7 +4711,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   }
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {
-    const int I = 6 - 2 * l16_sg(t) - role, J = l16_sj(t);
+    const int I = l16_row(l16_sg(t), role), J = l16_sj(t);
     const int j = 16 * J + col;
     if (!(J < I && 16 * I + 16 <= n)) {
       // every candidate value is loaded (the arrays are zero beyond the training set) and the right one selected -- no
@@ -4753,7 +4771,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   const int It = n4 >> 4, rq = n4 & 15, qs = rq & 3, rs = rq >> 2;
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {
-    const int I = 6 - 2 * l16_sg(t) - role, J = l16_sj(t);
+    const int I = l16_row(l16_sg(t), role), J = l16_sj(t);
     if (I == It && J <= I) {
       const double v = l16_sel(A.v[t], rs);
       if (q == qs) S.al[16 * J + col] = v;
@@ -4773,7 +4791,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   int mi[L16_NG][4], mjv[L16_NT];
 #pragma unroll
   for (int g = 0; g < L16_NG; ++g) {
-    const int I = (6 - 2 * g - role) < 0 ? 0 : (6 - 2 * g - role);
+    const int I = l16_row(g, role) < 0 ? 0 : l16_row(g, role);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       ai[g][r] = al[16 * I + q + 4 * r];
@@ -4785,7 +4803,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
 #pragma unroll
   for (int t = 0; t < L16_NS; ++t) {
     const int g = l16_sg(t), J = l16_sj(t);
-    const int I = 6 - 2 * g - role;
+    const int I = l16_row(g, role);
     const int j = 16 * J + col;
     const double aj = al[j];
     if (J < I && 16 * I + 16 <= n) {  // (all rows and columns are training points, none on the diagonal)
@@ -4805,7 +4823,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
       for (int r = 0; r < 4; ++r) {
         const int ii = 16 * I + q + 4 * r;
         const int ic = (ii >= 0 && ii < L16_WS) ? ii : 0;
-        const double inner = fma(ai[g][r], aj, A.v[t][r]);
+        const double inner = fma(ai[g][r], aj, A.v[t][r] - ((ii == j) ? 2.0 : 0.0));  // (the pivot blocks hold 2 I - P^-1: l16_step)
         const double2 rd = tab[abs(mi[g][r] - mjv[J])];
         const bool in = ii < n && j < n;
         const bool dg = in && ii == j, od = in && ii != j;
