@@ -4864,7 +4864,10 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   }
 }
 
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_lml16(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+#ifndef GPET_L16_WAVES
+#define GPET_L16_WAVES 2  // waves per SIMD (3 spills 44 doubles in the block step: tools/build_instrumented.sh -DGPET_L16_WAVES=3 to try)
+#endif
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GPET_L16_WAVES, GPET_L16_WAVES))) k_lml16(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                                double* g_out, const int* count, int lag_cap) {
   const int pb = blockIdx.x;
 #ifdef GPET_L16_PROF
