@@ -496,7 +496,7 @@ def main():
     ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)  # flop per byte
     use_flops = (a_flops / a_bytes) > ridge
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(tp):
         prof = json.load(open(tp))
         if prof.get("edges") == E and prof.get("image") == [N, N] and dom in prof.get("kernels", {}):

@@ -638,13 +638,17 @@ __global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
   }
 }
 
-// diagonal block k0: Cholesky in LDS, written back in place, and -- with_inv -- its INVERSE to E.chol_inv: every
-// triangular solve against this block (the rows of L below it, V = L^-1 K_*^T) then becomes a 64x64x64 product on the
-// matrix cores.  ONE wave, no workgroup barriers: lane i owns row i, left-looking by columns -- l_ik = (a_ik - sum_{t<k}
-// l_it l_kt) / l_kk reads its own row (stride 65: conflict-free) and row k (the same address in every lane: a
-// broadcast); LDS operations of a wave complete in order.  ~2 x 2048 dependent FMAs per lane: 30 us for factor and
-// inverse, against 85 us for the factor alone with three workgroup barriers per pivot.
-__global__ void __launch_bounds__(64) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
+// diagonal block k0: Cholesky, written back in place, and -- with_inv -- its INVERSE to E.chol_inv: every triangular
+// solve against this block (the rows of L below it, V = L^-1 K_*^T) then becomes a 64x64x64 product on the matrix cores.
+// RIGHT-looking, four waves, one workgroup barrier per pivot: every wave forms column k (lane i: l_ik = a_ik / sqrt(a_kk),
+// through a refined reciprocal square root -- the square root + division chain was half of a pivot's time) and row k of
+// the inverse (lane j: x_kj = b_kj / l_kk, the column sweep of L X = I), then the waves share the columns j > k:
+//   a_ij -= l_ik l_jk      (lane i, its row: stride 65, conflict-free; l_jk: one address for the wave, a broadcast)
+//   b_jc -= l_jk x_kc      (lane c, column c of the inverse)
+// in batches of eight columns whose 24 LDS reads are in flight together.  Finished columns and rows go straight to HBM.
+// (Left-looking with one wave -- a dot product of length k per pivot, a chain of LDS round trips -- took 101 us per block,
+// 2.4 of the 6.1 ms of config 3's fit; with three workgroup barriers per pivot before that, 85 us for the factor alone.)
+__global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -653,78 +657,63 @@ __global__ void __launch_bounds__(64) k_chol_diag(EdgeDev* edges, int k0, int wi
   const int nb = (n - k0) < CB ? (n - k0) : CB;
   __shared__ double s[CB][CB + 1];
   __shared__ double sx[CB][CB + 1];
-  const int i = threadIdx.x;
-  // (row r: lanes 0..r, a coalesced run; eight rows' loads in flight -- one at a time is 64 memory round trips)
-  for (int r0 = 0; r0 < nb; r0 += 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (r0 + u < nb && i <= r0 + u) ? E.K[(size_t)(k0 + r0 + u) * ld + k0 + i] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (r0 + u < nb && i <= r0 + u) s[r0 + u][i] = v[u];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  bool bad = false;
-  for (int k = 0; k < nb; ++k) {
-    double acc = (i >= k && i < nb) ? s[i][k] : 0.0;
-    if (i >= k && i < nb) {
-      // (four partial sums, eight loads in flight: the chain is LDS latency otherwise)
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int t = 0;
-      for (; t + 4 <= k; t += 4) {
-        a0 = fma(s[i][t], s[k][t], a0);
-        a1 = fma(s[i][t + 1], s[k][t + 1], a1);
-        a2 = fma(s[i][t + 2], s[k][t + 2], a2);
-        a3 = fma(s[i][t + 3], s[k][t + 3], a3);
-      }
-      for (; t < k; ++t) a0 = fma(s[i][t], s[k][t], a0);
-      acc -= (a0 + a1) + (a2 + a3);
-    }
-    const double d = __shfl(acc, k, WAVE);  // a_kk - sum l_kt^2
-    if (!(d > 0.0)) {
-      bad = true;
-      break;
-    }
-    const double dk = sqrt(d);
-    if (i >= k && i < nb) s[i][k] = (i == k) ? dk : acc / dk;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // (other lanes read this column next: keep the compiler from moving loads above it)
-  }
-  if (bad) {
-    if (i == 0) sc->status = GPET_ERR_NOT_PD;
-    return;
-  }
-  for (int r = 0; r < nb; ++r)
-    if (i <= r) E.K[(size_t)(k0 + r) * ld + k0 + i] = s[r][i];
-  if (!with_inv) return;
-  // inverse: lane j owns column j of X = L^-1: x_rj = (delta_rj - sum_{j <= t < r} l_rt x_tj) / l_rr (identity padding
-  // beyond nb, zero above the diagonal)
+  const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
   {
-    const int j = i;
-    for (int r = 0; r < CB; ++r) {
-      double x = (r == j) ? 1.0 : 0.0;
-      if (r < nb && j < nb && r >= j) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int t = j;
-        for (; t + 4 <= r; t += 4) {
-          a0 = fma(s[r][t], sx[t][j], a0);
-          a1 = fma(s[r][t + 1], sx[t + 1][j], a1);
-          a2 = fma(s[r][t + 2], sx[t + 2][j], a2);
-          a3 = fma(s[r][t + 3], sx[t + 3][j], a3);
-        }
-        for (; t < r; ++t) a0 = fma(s[r][t], sx[t][j], a0);
-        x -= (a0 + a1) + (a2 + a3);
-        x /= s[r][r];
-      } else if (r != j) {
-        x = 0.0;
-      }
-      sx[r][j] = x;
+    double v[CB / 4];
+#pragma unroll
+    for (int u = 0; u < CB / 4; ++u) {
+      const int r = w + 4 * u;
+      v[u] = (r < nb && i <= r) ? E.K[(size_t)(k0 + r) * ld + k0 + i] : 0.0;
     }
-    __builtin_amdgcn_wave_barrier();
-    double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
-    for (int r = 0; r < CB; ++r) inv[r * CB + j] = sx[r][j];
+#pragma unroll
+    for (int u = 0; u < CB / 4; ++u) {
+      const int r = w + 4 * u;
+      s[r][i] = v[u];
+      sx[r][i] = (r == i) ? 1.0 : 0.0;
+    }
   }
+  __syncthreads();
+  double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
+  for (int k = 0; k < nb; ++k) {
+    const double d = s[k][k];  // (the same value in every thread: the exit below is uniform)
+    if (!(d > 0.0)) {
+      if (tid == 0) sc->status = GPET_ERR_NOT_PD;
+      return;
+    }
+    const double aik = s[i][k], bk = sx[k][i];
+    double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+    const double dk = d * r;
+    const double lik = (i > k) ? aik * r : (i == k ? dk : 0.0);
+    const double xk = bk * r;
+    if (w == (k & 3)) {
+      if (i >= k && i < nb) E.K[(size_t)(k0 + i) * ld + k0 + k] = lik;
+      if (with_inv) inv[k * CB + i] = xk;
+    }
+    for (int j0 = k + 1 + 8 * w; j0 < nb; j0 += 32) {
+      double lj[8], sv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = (j0 + u < nb) ? j0 + u : nb - 1;
+        lj[u] = s[j][k];
+        sv[u] = s[i][j];
+        xv[u] = sx[j][i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u;
+        if (j < nb) {
+          const double ljk = lj[u] * r;
+          s[i][j] = fma(-lik, ljk, sv[u]);
+          sx[j][i] = fma(-ljk, xk, xv[u]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (with_inv)  // identity beyond a short last block
+    for (int r = nb + w; r < CB; r += 4) inv[r * CB + i] = (r == i) ? 1.0 : 0.0;
 }
 
 // row blocks below the diagonal block by SUBSTITUTION (one row per lane of the first wave): the blocked objective of
@@ -937,7 +926,7 @@ static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(long long), st, d_edges);
   hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
   for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(64), 0, st, d_edges, k0, 1);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, 1);
     const int below = cdiv(bd.n_cap - k0 - CB, CB);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);
@@ -5118,7 +5107,7 @@ hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, co
   const int ntn = cdiv(n_max, CB);  // tiles that can hold training points
   hipLaunchKernelGGL(k_fit_kbuild, dim3(ntn, ntn, P), dim3(256), 0, st, ve);
   for (int k0 = 0; k0 < n_max; k0 += CB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1, P), dim3(64), 0, st, ve, k0, 0);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1, P), dim3(256), 0, st, ve, k0, 0);
     const int below = cdiv(n_max - k0 - CB, CB);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_trsm_sub, dim3(below, P), dim3(256), 0, st, ve, k0);

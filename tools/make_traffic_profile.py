@@ -1,4 +1,4 @@
-"""profiles/r02_pmc_traffic.json from two rocprofv3 PMC passes of tools/prof_stages.py:
+"""profiles/r03_pmc_traffic.json from two rocprofv3 PMC passes of tools/prof_stages.py:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_stages.py 1024 2
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stages.py 1024 2
@@ -41,7 +41,7 @@ def main():
                                      hbm_bytes_per_launch=(2.0 * fe[k] + wr[k]) * 1024.0)
     # the LML kernel of the converged fits is not part of tools/prof_stages.py: its entry comes from two more PMC passes
     # over `tools/prof_final.py E 0` (gpurun_out/pmc_lml_f, pmc_lml_w), averaged over all its launches
-    old_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    old_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if glob.glob(os.path.join(ROOT, "gpurun_out/pmc_lml_f", "*", "*_counter_collection.csv")):
         lf, lw = mean_of("gpurun_out/pmc_lml_f", "FETCH_SIZE", "k_lml"), mean_of("gpurun_out/pmc_lml_w", "WRITE_SIZE", "k_lml")
         out["kernels"]["k_lml"] = dict(fetch_size_kb=lf[0], write_size_kb=lw[0], launches=lf[1],
