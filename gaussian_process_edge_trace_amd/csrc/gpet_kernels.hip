@@ -674,43 +674,55 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int w
   }
   __syncthreads();
   double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
+  double* kcol = E.K + (size_t)(k0 + i) * ld + k0;
+  // the pivot and its reciprocal square root are formed one step AHEAD (a_k+1,k+1 - l_k+1,k^2 is all the update does to
+  // the next pivot), so the chain rsq + three Newton steps runs under the LDS traffic of the update
+  double d = s[0][0];
+  double r = __builtin_amdgcn_rsq(d);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
   for (int k = 0; k < nb; ++k) {
-    const double d = s[k][k];  // (the same value in every thread: the exit below is uniform)
-    if (!(d > 0.0)) {
+    if (!(d > 0.0)) {  // (the same value in every thread: the exit is uniform)
       if (tid == 0) sc->status = GPET_ERR_NOT_PD;
       return;
     }
     const double aik = s[i][k], bk = sx[k][i];
-    double r = __builtin_amdgcn_rsq(d);
-#pragma unroll
-    for (int it = 0; it < 3; ++it) r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
+    const int kn = (k + 1 < CB) ? k + 1 : k;
+    const double lnk = s[kn][k] * r;
+    const double dn = fma(-lnk, lnk, s[kn][kn]);
+    double rn = __builtin_amdgcn_rsq(dn);
     const double dk = d * r;
     const double lik = (i > k) ? aik * r : (i == k ? dk : 0.0);
     const double xk = bk * r;
     if (w == (k & 3)) {
-      if (i >= k && i < nb) E.K[(size_t)(k0 + i) * ld + k0 + k] = lik;
+      if (i >= k && i < nb) kcol[k] = lik;
       if (with_inv) inv[k * CB + i] = xk;
     }
-    for (int j0 = k + 1 + 8 * w; j0 < nb; j0 += 32) {
+    // columns j > k in batches of eight (the last batch repeats column 63: the same value written twice; rows and
+    // columns beyond a short last block are zero and stay zero)
+    for (int j0 = k + 1 + 8 * w; j0 < CB; j0 += 32) {
       double lj[8], sv[8], xv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int j = (j0 + u < nb) ? j0 + u : nb - 1;
+        const int j = (j0 + u < CB) ? j0 + u : CB - 1;
         lj[u] = s[j][k];
         sv[u] = s[i][j];
         xv[u] = sx[j][i];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int j = j0 + u;
-        if (j < nb) {
-          const double ljk = lj[u] * r;
-          s[i][j] = fma(-lik, ljk, sv[u]);
-          sx[j][i] = fma(-ljk, xk, xv[u]);
-        }
+        const int j = (j0 + u < CB) ? j0 + u : CB - 1;
+        const double ljk = lj[u] * r;
+        s[i][j] = fma(-lik, ljk, sv[u]);
+        sx[j][i] = fma(-ljk, xk, xv[u]);
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 3; ++it) rn = fma(0.5 * rn, fma(-dn * rn, rn, 1.0), rn);
+    d = dn;
+    r = rn;
+    // (LDS only: __syncthreads() would also wait for the column and the row just stored to HBM)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (with_inv)  // identity beyond a short last block
     for (int r = nb + w; r < CB; r += 4) inv[r * CB + i] = (r == i) ? 1.0 : 0.0;
