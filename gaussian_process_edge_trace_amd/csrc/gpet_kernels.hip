@@ -4084,7 +4084,7 @@ __device__ __forceinline__ void corr_and_dlog(const EdgeDev& E, double a, double
 // total and n barriers, against the ~3n barriers and the LDS-resident L / L^-1 (2 x 66 KB, one
 // workgroup per CU) of a Cholesky + triangular inverse; LDS use is ~3 KB so several problems share a CU.
 #define LML_MAXD 136  // 4 * ceil((128 + 1) / 4) + slack
-__global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(6, 6))) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
+__global__ void __launch_bounds__(576) __attribute__((amdgpu_waves_per_eu(5, 5))) k_lml(EdgeDev* edges, const int* edge_of, const double* theta, double* f_out,
                                              double* g_out, const int* count) {
   const int pb = blockIdx.x;
   if (count != nullptr && pb >= *count) return;  // (launches are sized by the host's last KNOWN number of running problems)
