@@ -4714,9 +4714,20 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   for (int t = 0; t < L16_NS; ++t) {
     const int I = l16_row(l16_sg(t), role), J = l16_sj(t);
     const int j = 16 * J + col;
-    if (!(J < I && 16 * I + 16 <= n)) {
-      // every candidate value is loaded (the arrays are zero beyond the training set) and the right one selected -- no
-      // divergent branches
+    if (J > I) {  // (a slot this wave does not use)
+      A.v[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    } else if (J < I && 16 * I + 16 > n) {
+      // off-diagonal tile of a tile row that reaches beyond the training set: kernel entries where both indices are
+      // training points, y in the border row, zero elsewhere (no diagonal, no padding pivot in it)
+      const double yj = S.y[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * I + q + 4 * r;
+        A.v[t][r] = (ii < n && j < n) ? A.v[t][r] : ((ii == n4 && j < n) ? yj : 0.0);
+      }
+    } else if (J == I) {
+      // diagonal tile: every candidate value is loaded (the arrays are zero beyond the training set) and the right one
+      // selected -- no divergent branches
       const double yj = S.y[j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -4729,7 +4740,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
         v = (!in && ii == j && ii < n4) ? 1.0 : v;
         v = (ii == n4 && j < n) ? yj : v;
         v = (j == n4 && ii < n) ? yi : v;
-        A.v[t][r] = (J <= I) ? v : 0.0;
+        A.v[t][r] = v;
       }
     }
   }
@@ -4781,8 +4792,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
   __syncthreads();
   const double* al = S.al;
   double ld = 0.0;
-  if (role == 0)
-    for (int k = lane; k < n; k += 64) ld += log(sqrt(S.piv[k]));
+  for (int k = (int)threadIdx.x; k < n; k += 128) ld += log(sqrt(S.piv[k]));  // (both waves: a log is ~80 instructions)
   // gradient: 0.5 * sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij; off-diagonal tiles stand for both triangles.
   // sR, sD: sums of inner_ij R_ij and inner_ij dR_ij over i != j (c applied at the end); gd, gn: the diagonal terms.
   // Same two passes as the set-up: every slot that is an off-diagonal tile of training points without a branch inside,
@@ -4818,8 +4828,17 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
       }
       sR = fma(2.0, tR, sR);
       sD = fma(2.0, tD, sD);
-    } else if (J <= I) {
-      const double wt = (I == J) ? 1.0 : 2.0;
+    } else if (J < I) {  // (off-diagonal tile of a tile row that reaches beyond the training set)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = 16 * I + q + 4 * r;
+        const double inner = fma(ai[g][r], aj, A.v[t][r]);
+        const double2 rd = tab[abs(mi[g][r] - mjv[J])];
+        const bool od = ii < n && j < n;
+        sR += od ? 2.0 * inner * rd.x : 0.0;
+        sD += od ? 2.0 * inner * rd.y : 0.0;
+      }
+    } else if (J == I) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ii = 16 * I + q + 4 * r;
@@ -4830,8 +4849,8 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
         const bool dg = in && ii == j, od = in && ii != j;
         gd += dg ? inner : 0.0;
         gn += dg ? inner * (nl * S.w[ic]) : 0.0;
-        sR += od ? wt * inner * rd.x : 0.0;
-        sD += od ? wt * inner * rd.y : 0.0;
+        sR += od ? inner * rd.x : 0.0;
+        sD += od ? inner * rd.y : 0.0;
       }
     }
   }
@@ -4844,6 +4863,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
     S.red[0] = gc;
     S.red[1] = gl;
     S.red[2] = gn;
+    S.red[3] = ld;
   }
   __syncthreads();
 #ifdef GPET_L16_PROF
@@ -4856,6 +4876,7 @@ __device__ __forceinline__ void l16_run(L16Shared& S, const double2* tab, int n,
     gc += S.red[0];
     gl += S.red[1];
     gn += S.red[2];
+    ld += S.red[3];
     const double yta = -al[n4];
     const double lml = -0.5 * yta - ld - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
     f_out[pb] = -lml;
