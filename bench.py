@@ -513,7 +513,8 @@ def main():
                           ("bound by the samples it stores (8 S Lg bytes per edge: 2.7-2.85 TB/s is what a store-only kernel of this "
                            "shape reaches, tools/ubench/gemm_pipe.hip), see DESIGN.md section 6" if dom == "k_sample_gemm_mfma_r" else
                           ("objective of the converged fits: %d evaluations of ~%.0f-point problems in %d launches per step; "
-                           "f64 vector peak; latency-bound (one barrier per pivot), DESIGN.md section 6"
+                           "f64 peak (vector = matrix on MI355X); k_lml16: block-4 sweep on v_mfma_f64_16x16x4, two waves per problem -- MFMA "
+                           "cycles and VALU issue share the vector unit's FMA lanes, DESIGN.md section 6b"
                            % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None))),
                     state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
                                loop_path="structured" if structured else "generic", iterations_per_trace=iters_per_trace,
