@@ -258,6 +258,14 @@ static int fin_lattice(const double* x, int n, double* hinv) {
   return (int)mr;
 }
 
+// converged fits: every (edge, restart) problem from start to optimum in one workgroup (k_lml16_fit) instead of
+// lock-step rounds over all running problems: -1 = for problem sets resident at once (<= 1024), 0 = never, 1 = always
+// (where the training sets allow it)
+static int& opt_fit_persistent() {
+  static int v = getenv("GPET_FIT_PERSISTENT") != nullptr ? atoi(getenv("GPET_FIT_PERSISTENT")) : -1;
+  return v;
+}
+
 static int& opt_rng_chunked() {
   static int v = getenv("GPET_RNG_CHUNKED") != nullptr ? atoi(getenv("GPET_RNG_CHUNKED")) : -1;  // -1: by launch shape
   return v;
@@ -316,6 +324,12 @@ int gpet_set_option(const char* name, int value) {
     const int old = v;
     v = value < 0 ? -1 : (value > 0 ? 1 : 0);
     return old < 0 ? 2 : old;  // (2 = "chosen by launch shape")
+  }
+  if (name && strcmp(name, "fit_persistent") == 0) {
+    int& v = opt_fit_persistent();
+    const int old = v;
+    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
+    return old < 0 ? 2 : old;  // (2 = "by the number of problems")
   }
   if (name && strcmp(name, "lml_mfma") == 0) {
     int& v = gpet_opt_lml_mfma();
@@ -1465,6 +1479,37 @@ static int lb_rounds(gpet_batch* b, int P, int n_max, int lag_cap, const LbCfg& 
   gpet_ctx* c = b->ctx;
   hipStream_t st = b->fit;
   HIPCHK(c, launch_lb_init(st, b->lb_probs, P, b->lb_starts, b->lb_slot_edge[0], b->lb_slot_theta[0], b->lb_slot_src[0], cfg));
+  // (for problem sets that are resident all at once -- 4 workgroups on each of 256 CUs -- the chain of a problem's ~50
+  //  evaluations is what takes the time: 3.2 instead of 4.8 ms for a single edge; bigger sets are throughput-bound and a
+  //  workgroup that keeps its registers through the single-threaded state machine costs more than the rounds' launches:
+  //  32 instead of 23 ms of objective time per 13 312 problems)
+  const bool persistent = opt_fit_persistent() > 0 || (opt_fit_persistent() < 0 && P <= 1024);
+  if (persistent && lml16_fit_applies(n_max, lag_cap)) {
+    // one launch: a workgroup per problem runs objective and state machine until the problem is done (k_lml16_fit)
+    HIPCHK(c, hipMemsetAsync(b->lb_count, 0, 4 * sizeof(int), st));
+    if (b->lb_events.size() < 2) {
+      hipEvent_t e0, e1;
+      HIPCHK(c, hipEventCreate(&e0));
+      b->lb_events.push_back(e0);
+      HIPCHK(c, hipEventCreate(&e1));
+      b->lb_events.push_back(e1);
+    }
+    HIPCHK(c, hipEventRecord(b->lb_events[0], st));
+    HIPCHK(c, launch_lml16_fit(st, b->d_edges, b->lb_probs, P, cfg, lag_cap, 4000, b->lb_count));
+    HIPCHK(c, hipEventRecord(b->lb_events[1], st));
+    HIPCHK(c, launch_lb_pick(st, b->d_edges, b->B, b->lb_probs, b->lb_theta_out, cfg.nstart));
+    int h_cnt[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h_cnt, b->lb_count, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, gpet_wait(st));
+    if (h_cnt[2] > 0)
+      return fail(c, GPET_ERR_ITER_CAP, "converged fit: %d problems not finished (4000 evaluations, or a training set the kernel does not serve)", h_cnt[2]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->lb_events[0], b->lb_events[1]) == hipSuccess) b->lml_ms += (double)ms;
+    b->lml_evals += h_cnt[0];
+    b->lml_launches += 1;
+    if (rounds_out) *rounds_out = h_cnt[1];
+    return GPET_OK;
+  }
   constexpr int LB_CHECK = 4;
   int h_count[2] = {P, 0};
   HIPCHK(c, hipMemcpyAsync(b->lb_count, h_count, sizeof h_count, hipMemcpyHostToDevice, st));

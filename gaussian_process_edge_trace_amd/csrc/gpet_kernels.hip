@@ -1,6 +1,7 @@
 // Hand-written gfx950 kernels for the GP edge-tracing hot path.
 // Wavefront = 64 lanes everywhere.  blockIdx.y selects the edge of the batch.
 #include "gpet_kernels.h"
+#include "gpet_lbfgsb_dev.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -4937,6 +4938,97 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GPET_L
   if (blockIdx.x == 0 && tid == 0) printf("l16 staging + table: %lld cycles\n", (long long)(clock64() - t_kernel));
 #endif
   l16_run(S, l16_tab, n, n4, nt, c, nl, pb, f_out, g_out);
+}
+
+// The converged fit of one (edge, restart) problem from its start point to its optimum in ONE workgroup: objective
+// (the block sweep above) -> L-BFGS-B state machine (lb_advance, thread 0, the problem's state in LDS) -> next trial
+// point, until the machine says done.  Problems do not talk to each other, so there is nothing to synchronise across
+// workgroups and no residency requirement: a launch of P workgroups of which only some fit the GPU just runs them in
+// generations.  Against the round-based driver (one objective launch + one k_lb_advance launch per round of ALL running
+// problems, a counter read-back every fourth round) this takes the launch gaps and the host round trips out of a
+// problem's chain of ~50 evaluations and stages its training set once instead of once per evaluation.
+// counters[0] += evaluations, counters[1] = max evaluations of a problem, counters[2] += problems cut off at max_evals.
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GPET_L16_WAVES, GPET_L16_WAVES))) k_lml16_fit(EdgeDev* edges, LbProb* probs, LbCfg cfg, int lag_cap,
+                                                                                                                 int max_evals, int* counters) {
+  const int pb = blockIdx.x;
+  __shared__ L16Shared S;
+  __shared__ LbProb sp;
+  __shared__ double s_fg[4];
+  extern __shared__ double2 l16_tab[];
+  const int tid = threadIdx.x;
+  {
+    const int* src = reinterpret_cast<const int*>(&probs[pb]);
+    int* dst = reinterpret_cast<int*>(&sp);
+    for (int i = tid; i < (int)(sizeof(LbProb) / sizeof(int)); i += 128) dst[i] = src[i];
+  }
+  __syncthreads();
+  const EdgeDev E = edges[sp.edge];
+  const int n = E.fin_n;
+  const int n4 = (n + 3) & ~3;
+  const int nt = (n4 + 1 + 15) >> 4;
+  const double hinv = E.fin_par[9];
+  const int lagmax = (int)E.fin_par[10];
+  if (!(hinv > 0.0) || lagmax < 0 || lagmax >= lag_cap || n > L16_MAXN) {  // (the host routes such sets to the round-based driver)
+    if (tid == 0) {
+      E.sc->status = GPET_ERR_STATE;
+      atomicAdd(&counters[2], 1);
+    }
+    return;
+  }
+  const double x0 = E.fin_x[0];
+  for (int i = tid; i < L16_WS; i += 128) {
+    const bool in = i < n;
+    S.y[i] = in ? E.fin_y[i] : 0.0;
+    S.w[i] = in ? E.fin_w[i] : 0.0;
+    S.m[i] = in ? (int)rint((E.fin_x[i] - x0) * hinv) : 0;
+  }
+  int evals = 0;
+  for (;;) {
+    const double c = exp(sp.xe[0]), ell = exp(sp.xe[1]), nl = exp(sp.xe[2]);
+    for (int i = tid; i < L16_WS; i += 128) {
+      S.piv[i] = 1.0;
+      S.al[i] = 0.0;
+    }
+    for (int i = tid; i < 2 * 4 * L16_WS; i += 128) (&S.Wt[0][0][0])[i] = 0.0;
+    for (int m = tid; m <= lagmax; m += 128) {
+      double R, dR;
+      corr_and_dlog(E, ((double)m / hinv) / ell, 0.0, R, dR);
+      l16_tab[m] = make_double2(R, dR);
+    }
+    __syncthreads();
+    l16_run(S, l16_tab, n, n4, nt, c, nl, 0, &s_fg[0], &s_fg[1]);  // (thread 0 leaves f and the gradient in s_fg)
+    ++evals;
+    if (tid == 0) {
+      double lo[3] = {cfg.lo[0], cfg.lo[1], cfg.lo[2]}, hi[3] = {cfg.hi[0], cfg.hi[1], cfg.hi[2]};
+      const double gk[3] = {s_fg[1], s_fg[2], s_fg[3]};
+      lb_advance(sp, s_fg[0], gk, lo, hi);
+    }
+    __syncthreads();
+    if (sp.task == LB_TASK_DONE || evals >= max_evals) break;
+  }
+  {
+    int* dst = reinterpret_cast<int*>(&probs[pb]);
+    const int* src = reinterpret_cast<const int*>(&sp);
+    for (int i = tid; i < (int)(sizeof(LbProb) / sizeof(int)); i += 128) dst[i] = src[i];
+  }
+  if (tid == 0) {
+    atomicAdd(&counters[0], evals);
+    atomicMax(&counters[1], evals);
+    if (sp.task != LB_TASK_DONE) atomicAdd(&counters[2], 1);
+  }
+}
+
+bool lml16_fit_applies(int n_max, int lag_cap) {
+  return n_max <= L16_MAXN && lag_cap > 0 && lag_cap <= L16_LAG_MAX && gpet_opt_lml_mfma() != 0;
+}
+
+hipError_t launch_lml16_fit(hipStream_t st, EdgeDev* d_edges, void* d_probs, int P, const LbCfg& cfg, int lag_cap, int max_evals,
+                            int* d_counters) {
+  (void)hipGetLastError();
+  const size_t dyn = (size_t)2 * lag_cap * sizeof(double);
+  hipLaunchKernelGGL(k_lml16_fit, dim3(P), dim3(128), dyn, st, d_edges, static_cast<LbProb*>(d_probs), cfg, lag_cap, max_evals,
+                     d_counters);
+  return hipGetLastError();
 }
 
 hipError_t launch_lml(hipStream_t st, EdgeDev* d_edges, int P, int n_max, const int* d_edge_of, const double* d_theta,
