@@ -234,6 +234,38 @@ def test_device_lbfgsb_against_scipy_on_the_same_objective(amd, ctx, golden):
         np.testing.assert_allclose(theta[0][:2], g["ref_final_theta"][:2], rtol=1e-4, atol=1e-5)
 
 
+def test_final_fit_one_workgroup_per_problem_equals_rounds(amd, ctx, golden):
+    """gpet_set_option("fit_persistent"): the converged fit as one workgroup per (edge, restart) problem (k_lml16_fit:
+    objective and L-BFGS-B state machine alternate inside the workgroup) against the lock-step rounds of launches --
+    the same objective source and the same state-machine code; the two kernels the objective is compiled into round
+    differently in the last bit here and there (README edge: theta 2e-13, mean 2e-12 apart; 65-px edge, whose noise level
+    ends in the flat part of the objective: mean 3e-7), so: log amplitude and length scale to 1e-6, noise level compared
+    in linear space, best objective value to 1e-9 relative, mean / std to 1e-5, evaluation count of the longest
+    restart within 3 of the number of rounds."""
+    L = amd._lib
+    for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128"), ("trace_rbf65", "stage_rbf65")]:
+        g = golden(name)
+        tr = amd.GP_Edge_Tracing(g["in_init"], golden(stage)["ref_grad"], **CTOR[stage], _ctx=ctx)
+        n_iter = int(g["ref_n_iter"])
+        b = tr._batch
+        b.set_obs(0, g["ref_obs_%02d" % n_iter])
+        out = {}
+        old = L.set_option("fit_persistent", 0)
+        try:
+            for mode in (0, 1):
+                L.set_option("fit_persistent", mode)
+                out[mode] = b.final_fit_all([tr.seed + n_iter])
+        finally:
+            L.set_option("fit_persistent", -1 if old == 2 else old)
+        t0, t1 = np.asarray(out[0][2]), np.asarray(out[1][2])
+        np.testing.assert_allclose(t1[:, :2], t0[:, :2], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(np.exp(t1[:, 2]), np.exp(t0[:, 2]), rtol=1e-3, atol=1e-9)  # (flat direction: as above)
+        np.testing.assert_allclose(out[1][3], out[0][3], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=1e-5)
+        assert abs(out[0][4] - out[1][4]) <= 3, (name, out[0][4], out[1][4])
+
+
 def test_structured_loop_path_equals_generic(amd, ctx, golden):
     """The loop's prior-eigenbasis path (H = c Lam - U^T U in the eigenbasis of the grid's Toeplitz
     correlation matrix) must produce the factor, mean and samples of the generic path
