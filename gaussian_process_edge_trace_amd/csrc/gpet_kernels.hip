@@ -4962,7 +4962,20 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(GPET_L
     for (int i = tid; i < (int)(sizeof(LbProb) / sizeof(int)); i += 128) dst[i] = src[i];
   }
   __syncthreads();
-  const EdgeDev E = edges[sp.edge];
+  // (only what the loop needs of the edge's record.  The kernel still spills -- 114 vector registers around the set-up,
+  //  the gradient epilogue and the call of the state machine, none inside the block steps)
+  const EdgeDev* Ep = &edges[sp.edge];
+  EdgeDev E = {};
+  E.kernel_type = Ep->kernel_type;
+  E.nu_code = Ep->nu_code;
+  E.nu_gen = Ep->nu_gen;
+  E.inv_gamma_nu = Ep->inv_gamma_nu;
+  E.fin_n = Ep->fin_n;
+  E.fin_par = Ep->fin_par;
+  E.fin_x = Ep->fin_x;
+  E.fin_y = Ep->fin_y;
+  E.fin_w = Ep->fin_w;
+  E.sc = Ep->sc;
   const int n = E.fin_n;
   const int n4 = (n + 3) & ~3;
   const int nt = (n4 + 1 + 15) >> 4;
