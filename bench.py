@@ -374,6 +374,25 @@ def main():
         fw = []
         l1, f1, _, _ = timed_steps([tracer], 3, 0, executor, fw)
         secondary["no_pipeline"] = dict(traces_per_s=3 * E / (l1 + f1), loop_s_per_step=l1 / 3, fit_s_per_step=f1 / 3, edges=E)
+        # (b2) the opt-in f32 storage of the samples (BASELINE config 2: "fp64 Cholesky + fp32 posterior samples"): the same
+        #      pipelined steps with gpet_batch_set_sample_dtype(1); never the headline (parity is stated on f64 samples)
+        for tr_ in tracers:
+            tr_._ctx.sync()
+            tr_._batch.set_sample_dtype("f32")
+        timed_steps(tracers, len(tracers), depth, executor, [])
+        for tr_ in tracers:
+            tr_._ctx.sync()
+        t1 = time.time()
+        _, _, it_f32, tr_f32 = timed_steps(tracers, 4, depth, executor, [])
+        for tr_ in tracers:
+            tr_._ctx.sync()
+        dt_f32 = time.time() - t1
+        for tr_ in tracers:
+            tr_._batch.set_sample_dtype("f64")
+        secondary["f32_samples"] = dict(traces_per_s=4 * E / dt_f32, ms_per_step=1e3 * dt_f32 / 4, edges=E,
+                                        trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_f32])),
+                                        note="sample GEMM stores f32, scorer/KDE widen; all arithmetic f64; opt-in, "
+                                             "tests/test_gpu_trace.py::test_full_trace_f32_samples_vs_oracle")
         # (c) BASELINE config 4's batch size: 256 edges per step (pipelined like the headline)
         small = [make_tracer(256, tr_._ctx) for tr_ in tracers]
         timed_steps(small, len(small), depth, executor, [])

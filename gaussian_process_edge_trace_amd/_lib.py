@@ -93,6 +93,7 @@ SYMBOLS = {
     "gpet_final_predict_all": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "gpet_final_fit_all": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "gpet_final_optimize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int32)]),
+    "gpet_batch_set_sample_dtype": (C.c_int, [_P, C.c_int]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -365,6 +366,13 @@ class Batch:
         self.ctx.check(self.lib.gpet_final_fit_all(self.h, s, mean.ctypes.data, std.ctypes.data, th.ctypes.data, Lg,
                                                    C.byref(rounds)))
         return mean, std, th[:, :3].copy(), th[:, 3].copy(), rounds.value
+
+    def set_sample_dtype(self, dtype):
+        """Storage type of the posterior samples: "f64" (default, the reference's) or "f32" (gpet_batch_set_sample_dtype:
+        the GEMM rounds on store, consumers widen; opt-in, BASELINE config 2's "fp32 posterior samples")."""
+        if dtype not in (None, "f64", "f32", "float64", "float32"):
+            raise ValueError("sample_dtype must be 'f64' or 'f32'")
+        self.ctx.check(self.lib.gpet_batch_set_sample_dtype(self.h, 1 if dtype in ("f32", "float32") else 0))
 
     def final_optimize(self, starts, bounds):
         """Device L-BFGS-B on the training sets of final_set_training(_all) (gpet_final_optimize): starts

@@ -916,7 +916,20 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
     case GPET_BUF_FACTOR: src = E.A; avail = (size_t)s.rank * Lg * 8; break;
     case GPET_BUF_EIGVALS: src = E.theta; avail = (size_t)s.rank * 8; break;
     case GPET_BUF_NORMALS: src = E.Z + (size_t)(s.iter % E.z_ring) * E.S * E.z_cols; avail = (size_t)E.S * E.z_cols * 8; break;
-    case GPET_BUF_SAMPLES: src = E.Y; avail = (size_t)E.S * Lg * 8; break;
+    case GPET_BUF_SAMPLES:
+      if (E.y_f32) {  // stored as f32 (gpet_batch_set_sample_dtype): the interface stays f64, widened here
+        const size_t cnt = (size_t)E.S * Lg;
+        if (bytes > cnt * 8) bytes = cnt * 8;
+        std::vector<float> tmp(cnt);
+        HIPCHK(c, hipMemcpyAsync(tmp.data(), E.Y, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, gpet_wait(c->stream));
+        double* o = (double*)dst;
+        for (size_t i = 0; i < bytes / 8; ++i) o[i] = (double)tmp[i];
+        return GPET_OK;
+      }
+      src = E.Y;
+      avail = (size_t)E.S * Lg * 8;
+      break;
     case GPET_BUF_COSTS: src = E.costs; avail = (size_t)E.S * 8; break;
     case GPET_BUF_BEST_IDX: src = E.best_idx; avail = (size_t)E.n_keep * 4; break;
     case GPET_BUF_BEST_COSTS: src = E.best_costs; avail = (size_t)E.n_keep * 8; break;
@@ -1010,7 +1023,21 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
       b->have_normals = true;
       break;
     }
-    case GPET_BUF_SAMPLES: dst = E.Y; cap = (size_t)E.S * Lg * 8; b->have_samples = true; break;
+    case GPET_BUF_SAMPLES:
+      b->have_samples = true;
+      if (E.y_f32) {  // (rounded to f32 here, as the GEMM does when it stores)
+        const size_t cnt = (size_t)E.S * Lg;
+        if (bytes > cnt * 8) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cnt * 8);
+        std::vector<float> tmp(bytes / 8);
+        const double* in = (const double*)src;
+        for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)in[i];
+        HIPCHK(c, hipMemcpyAsync(E.Y, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, gpet_wait(c->stream));
+        return GPET_OK;
+      }
+      dst = E.Y;
+      cap = (size_t)E.S * Lg * 8;
+      break;
     case GPET_BUF_GRAD_KDE: dst = (void*)E.grad_kde; cap = px * 4; break;
     case GPET_BUF_KDE: dst = E.kde; cap = px * 4; break;
     case GPET_BUF_COSTS: dst = E.costs; cap = (size_t)E.S * 8; break;
@@ -1025,6 +1052,21 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
   if (bytes > cap) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cap);
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, gpet_wait(c->stream));
+  return GPET_OK;
+}
+
+int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gpet_wait(c->stream));
+  if (b->side) HIPCHK(c, gpet_wait(b->side));
+  const int v = f32 ? 1 : 0;
+  for (int e = 0; e < b->B; ++e) b->h_edges[e].y_f32 = v;
+  b->bd.y_f32 = v;
+  HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * (size_t)b->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
+  b->have_samples = false;
   return GPET_OK;
 }
 

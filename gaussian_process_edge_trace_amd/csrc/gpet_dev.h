@@ -63,7 +63,8 @@ struct EdgeDev {
   double* pcx_cand;      // [2][4 (Lg/32 + 1)][2] per-wave pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
-  double* Y;             // [S*Lg]
+  double* Y;             // [S*Lg] samples, row = sample; f32 in the same buffer when y_f32 is set
+  int y_f32;             // gpet_batch_set_sample_dtype: 1 = the GEMM stores f32, consumers widen (opt-in; default f64)
   double* costs;         // [S]
   double* cost_part;     // [n_tiles][S][2] per-column-tile partial (arc length, line integral) sums
   double* best_costs;    // [n_keep]

@@ -2870,6 +2870,25 @@ size_t mtj_poly_bytes() { return sizeof(mtj_poly); }
 // LDS in chunks of 32.  Operand maps (cdna_hip_programming.md section 3): A lane l <- A[l&15][l>>4],
 // B lane l <- B[l>>4][l&15]; D register g of lane l -> row (l>>4) + 4g, column l&15.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+// The samples are f64 (the reference's; every parity tier is stated on them).  Opt-in (gpet_batch_set_sample_dtype, BASELINE
+// config 2's "fp32 posterior samples"): the GEMM rounds each sample to f32 when it stores it and every consumer widens
+// it again -- all arithmetic stays f64, the buffer and its HBM traffic halve.  y_ld / y_st: the sites that are not hot.
+__device__ __forceinline__ double y_ld(const EdgeDev& E, size_t idx) {
+  return E.y_f32 ? (double)reinterpret_cast<const float*>(E.Y)[idx] : E.Y[idx];
+}
+__device__ __forceinline__ void y_st(const EdgeDev& E, size_t idx, double v) {
+  if (E.y_f32) reinterpret_cast<float*>(E.Y)[idx] = (float)v;
+  else E.Y[idx] = v;
+}
+template <bool F32>
+struct YT {
+  typedef double type;
+};
+template <>
+struct YT<true> {
+  typedef float type;
+};
+
 __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.z];
   const gpet_scalars* sc = E.sc;
@@ -2918,7 +2937,7 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int sidx = s0 + 16 * w + lq + 4 * g;
-      if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[t][g] + mu) * y_s;
+      if (sidx < S) y_st(E, (size_t)sidx * Lg + j, (acc[t][g] + mu) * y_s);
     }
   }
 }
@@ -2938,8 +2957,10 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // with four 4-wave workgroups per CU (+8 %), a half-tile phase offset between the workgroups of a CU (+-0).
 #define GEMM_KMAX 96
 #define GEMM_LDS_MAX (150 * 1024)
-template <int KS>
+template <int KS, bool F32>
 __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part, bool mu_lds) {
+  typedef typename YT<F32>::type yt;
+  yt* __restrict__ Yo = reinterpret_cast<yt*>(E.Y);
   constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = part * 128;
@@ -3000,9 +3021,9 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
       for (int g = 0; g < 4; ++g) {
         const int sidx = s0 + 16 * w + lq + 4 * g;
 #if defined(GPET_GEMM_EXP) && GPET_GEMM_EXP == 1  // experiment: no stores (the condition is never true)
-        if (sidx < S && acc[g] == 1.2345e300) E.Y[(size_t)sidx * Lg + j] = (acc[g] + mu) * y_s;
+        if (sidx < S && acc[g] == 1.2345e300) Yo[(size_t)sidx * Lg + j] = (yt)((acc[g] + mu) * y_s);
 #else  // (streaming stores, __builtin_nontemporal_store, were measured 35 % slower here)
-        if (sidx < S) E.Y[(size_t)sidx * Lg + j] = (acc[g] + mu) * y_s;
+        if (sidx < S) Yo[(size_t)sidx * Lg + j] = (yt)((acc[g] + mu) * y_s);
 #endif
       }
     }
@@ -3012,7 +3033,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 // One kernel per K extent (the launcher picks it from the batch's largest possible rank; an edge of smaller
 // rank multiplies a few zero rows): register allocation is per kernel, and the variants up to K = 72 fit the
 // 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
-template <int KS>
+template <int KS, bool F32>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges, int mu_in_lds) {
   int edge, part;  // the row blocks of an edge on one XCD: its factor comes out of HBM once, not once per row block
   xcd_edge_part((int)gridDim.x, edge, part);
@@ -3021,9 +3042,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];  // [4 KS][65]
-  sample_gemm_body<KS>(E, sc, s_fa, part, mu_in_lds != 0);
+  sample_gemm_body<KS, F32>(E, sc, s_fa, part, mu_in_lds != 0);
 }
-template <int KS>
+template <int KS, bool F32>
 __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int mu_in_lds) {  // (K > 72: one workgroup per CU)
   int edge, part;
   xcd_edge_part((int)gridDim.x, edge, part);
@@ -3032,7 +3053,7 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];
-  sample_gemm_body<KS>(E, sc, s_fa, part, mu_in_lds != 0);
+  sample_gemm_body<KS, F32>(E, sc, s_fa, part, mu_in_lds != 0);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -3116,11 +3137,12 @@ __device__ __forceinline__ double grad_at(const float* __restrict__ grad, int M,
 // Even number of Simpson samples (odd edge length): scipy >= 1.11 adds Cartwright's correction for the
 // last interval, alpha*y[-1] + beta*y[-2] - eta*y[-3] with the last two spacings h0, h1
 // (scipy/integrate/_quadrature.py simpson; version dependent in the reference).
-__device__ __forceinline__ void simpson_tail(const EdgeDev& E, const double* __restrict__ row, double& al, double& li) {
+template <typename T>
+__device__ __forceinline__ void simpson_tail(const EdgeDev& E, const T* __restrict__ row, double& al, double& li) {
   const int Lg = E.Lg;
   if ((Lg & 1) == 0 || Lg < 5) return;
   const int k = Lg - 2;  // index of the last sample (N-1); samples are points 0..Lg-2
-  const double ya = row[k - 2], yb = row[k - 1], yc = row[k], yd = row[k + 1];
+  const double ya = (double)row[k - 2], yb = (double)row[k - 1], yc = (double)row[k], yd = (double)row[k + 1];
   const double da = yb - ya, db = yc - yb, dc = yd - yc;
   const double l3 = sqrt(1.0 + da * da), l2 = sqrt(1.0 + db * db), l1 = sqrt(1.0 + dc * dc);  // l_{N-3}, l_{N-2}, l_{N-1}
   // arc length: unit spacing h0 = h1 = 1
@@ -3141,7 +3163,9 @@ __device__ __forceinline__ void simpson_tail(const EdgeDev& E, const double* __r
 // length are the next lane's own values and arrive by wave shuffle -- each sample, each gather and
 // each square root is done exactly once per curve.  (Lane 63 fetches its successor's data itself.)
 typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <bool F32>
 __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
+  typedef typename YT<F32>::type yt;
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
@@ -3149,8 +3173,8 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (s >= E.S) return;
   const int Lg = E.Lg;
-  const double* __restrict__ row = E.Y + (size_t)s * Lg;
-  const bool aligned = ((((size_t)row) & 15) == 0);
+  const yt* __restrict__ row = reinterpret_cast<const yt*>(E.Y) + (size_t)s * Lg;
+  const bool aligned = !F32 && ((((size_t)row) & 15) == 0);
   const int npair = (Lg - 2) / 2;  // Simpson over Lg-1 samples (odd count)
   double al = 0.0, li = 0.0;
   for (int i0 = 0; i0 < npair; i0 += WAVE) {
@@ -3164,8 +3188,8 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
         y0 = v[0];
         y1 = v[1];
       } else {
-        y0 = row[k];
-        y1 = row[k + 1];
+        y0 = (double)row[k];
+        y1 = (double)row[k + 1];
       }
     }
     // segment length l = sqrt(1 + d^2) and its reciprocal from ONE rsqrt each (the Simpson weights
@@ -3178,8 +3202,8 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
     double y2 = __shfl_down(y0, 1, WAVE), l2 = __shfl_down(l0, 1, WAVE), r2 = __shfl_down(r0, 1, WAVE);
     double g2 = __shfl_down(g0, 1, WAVE);
     if (lane == 63 && i < npair) {  // successor lives in the next chunk
-      y2 = row[k + 2];
-      const double y3 = row[k + 3];
+      y2 = (double)row[k + 2];
+      const double y3 = (double)row[k + 3];
       const double d2 = y3 - y2;
       const double q2 = 1.0 + d2 * d2;
       r2 = rsqrt(q2);
@@ -3243,7 +3267,9 @@ __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M,
   return (double)col[iy] * w0 + (double)col[iy + 1] * w1;
 }
 
+template <bool F32>
 __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
+  typedef typename YT<F32>::type yt;
   // the tiles of an edge on one XCD: neighbouring tiles split cache lines of the sample rows (a tile's 256-byte runs
   // start on 32-byte boundaries), which then come out of HBM once instead of once per L2
   int edge, part;
@@ -3278,15 +3304,15 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const bool edge_lane = (pl == 15);  // its successor pair belongs to the next tile
   auto fetch = [&](int s0, double& a0, double& a1, double& a2, double& a3) {
     const int s = s0 + (tid >> 4);
-    const double* __restrict__ row = E.Y + (size_t)(s < s_hi ? s : s_lo) * Lg;
+    const yt* __restrict__ row = reinterpret_cast<const yt*>(E.Y) + (size_t)(s < s_hi ? s : s_lo) * Lg;
     a0 = a1 = a2 = a3 = 0.0;
     if (k + 1 < Lg) {
-      a0 = row[k];
-      a1 = row[k + 1];
+      a0 = (double)row[k];
+      a1 = (double)row[k + 1];
     }
     if (edge_lane && i < npair) {
-      a2 = row[k + 2];
-      a3 = row[k + 3];
+      a2 = (double)row[k + 2];
+      a3 = (double)row[k + 3];
     }
   };
   double y0, y1, ye2, ye3;
@@ -3347,7 +3373,8 @@ __global__ void __launch_bounds__(256) k_score_combine(EdgeDev* edges, int n_til
     al += E.cost_part[((size_t)t * E.S + s) * 2];
     li += E.cost_part[((size_t)t * E.S + s) * 2 + 1];
   }
-  simpson_tail(E, E.Y + (size_t)s * E.Lg, al, li);
+  if (E.y_f32) simpson_tail(E, reinterpret_cast<const float*>(E.Y) + (size_t)s * E.Lg, al, li);
+  else simpson_tail(E, E.Y + (size_t)s * E.Lg, al, li);
   E.costs[s] = al / li;
 }
 
@@ -3588,11 +3615,11 @@ __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
     // wave w takes curves w, w + 16, ...; its lanes walk the columns: coalesced rows, no division per point
     const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
     for (int b = wv; b < nk; b += nw) {
-      const double* __restrict__ row = E.Y + (size_t)s_row[b] * E.Lg;
+      const size_t row = (size_t)s_row[b] * E.Lg;
       const double wb = s_ic[b];
 #pragma unroll 4
       for (int k = lane; k < E.Lg; k += 64) {
-        const double y = row[k];
+        const double y = y_ld(E, row + k);
         if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
       }
     }
@@ -3601,7 +3628,7 @@ __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
 #pragma unroll 4
     for (int e = tid; e < total; e += blockDim.x) {
       const int b = e / E.Lg, k = e - b * E.Lg;
-      const double y = E.Y[(size_t)E.best_idx[b] * E.Lg + k];
+      const double y = y_ld(E, (size_t)E.best_idx[b] * E.Lg + k);
       const double wb = (1.0 / E.best_costs[b]) / inv_sum;
       if (y < 0.0 || y > ymax) ++removed; else wsum += wb;
     }
@@ -3672,7 +3699,7 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
         const int bb = e / NC, c = e - bb * NC;
         const int xc = x0 + c - 4;
         double y = -1.0;
-        if (xc >= E.x_st && xc <= E.x_en) y = E.Y[(size_t)s_brow[bb] * E.Lg + (xc - E.x_st)];
+        if (xc >= E.x_st && xc <= E.x_en) y = y_ld(E, (size_t)s_brow[bb] * E.Lg + (xc - E.x_st));
         if (y < 0.0 || y > ymax) y = -1.0;  // gpet.py:498-500
         s_y[e] = y;
         if (y >= 0.0) {
@@ -5740,19 +5767,26 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     {  // (the chunk plus the posterior mean of a wide edge exceed the 64 KB a kernel gets without asking: 66 KB at K = 96, Lg = 2048)
       static PerDeviceOnce once;
       if (once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX);
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_r<18>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_rl<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_sample_gemm_mfma_rl<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+#define GPET_GEMM_ATTR(KERNEL, KS_)                                                                                       \
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX); \
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX)
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 8);
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 12);
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 16);
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 18);
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_rl, 20);
+        GPET_GEMM_ATTR(k_sample_gemm_mfma_rl, 24);
+#undef GPET_GEMM_ATTR
       }
     }
     // (an edge too wide for its posterior mean to sit behind the chunk reads it from global memory in the epilogue)
     const int mu_in_lds = ((size_t)4 * 24 * 65 + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
-#define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                          \
-  hipLaunchKernelGGL((KERNEL<KS_>), grid, block, ((size_t)4 * KS_ * 65 + (mu_in_lds ? bd.Lg : 0)) * sizeof(double), st, d_edges, \
-                     mu_in_lds)
+#define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
+  do {                                                                                                                                 \
+    const size_t lds_ = ((size_t)4 * KS_ * 65 + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
+    if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true>), grid, block, lds_, st, d_edges, mu_in_lds);                                 \
+    else hipLaunchKernelGGL((KERNEL<KS_, false>), grid, block, lds_, st, d_edges, mu_in_lds);                                         \
+  } while (0)
     if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
     else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
     else if (ks <= 16) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 16);
@@ -5773,12 +5807,17 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
     if (lds <= 150 * 1024 && B * 1 > 0 && bd.S >= 64) {
       static PerDeviceOnce once;
       if (once.first())
-        (void)hipFuncSetAttribute((const void*)k_score_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      {
+        (void)hipFuncSetAttribute((const void*)k_score_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_score_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      }
       const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
-      hipLaunchKernelGGL(k_score_tile, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
+      if (bd.y_f32) hipLaunchKernelGGL(k_score_tile<true>, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
+      else hipLaunchKernelGGL(k_score_tile<false>, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
       hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
     } else {
-      hipLaunchKernelGGL(k_score, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+      if (bd.y_f32) hipLaunchKernelGGL(k_score<true>, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
+      else hipLaunchKernelGGL(k_score<false>, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
     }
   }
   if (parts & 2u) {

@@ -271,6 +271,13 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
 int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
                        int stride, int32_t* rounds_out);
 
+/* Storage type of the posterior samples of this batch: 0 = f64 (default: the reference's sample_y, sklearn_gpr.py:440-473,
+ * every parity statement is made on it), 1 = f32 -- BASELINE config 2's "fp32 posterior samples": the sample GEMM rounds
+ * each sample to f32 when it stores it, scorer / KDE / pixel kernels widen it again, all arithmetic stays f64; GPET_BUF_SAMPLES
+ * is f64 on the interface either way.  Results equal the reference with `y_samples.astype(float32)` inserted after
+ * sample_y (oracle mode sample_dtype="f32").  Call between traces, not while a loop is enqueued. */
+int gpet_batch_set_sample_dtype(gpet_batch* b, int f32);
+
 /* The optimiser alone, for a caller's own training sets (GaussianProcessRegressor.fit with optimizer="fmin_l_bfgs_b",
  * sklearn_gpr.py:254-295, 587-607): L-BFGS-B from n_starts start points per edge (starts [B][n_starts][3], theta = log
  * (constant, length_scale, noise_level)) inside bounds [3][2] = (lo, hi) per component, on the training sets of

@@ -107,6 +107,40 @@ def test_full_trace_vs_oracle(amd, ctx, golden, name):
     np.testing.assert_allclose(ci[1], ci_o[1], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_rbf65", "trace_mat128", "trace_rbf500"])
+def test_full_trace_f32_samples_vs_oracle(amd, ctx, golden, name):
+    """Opt-in sample_dtype="f32" (gpet_batch_set_sample_dtype; BASELINE config 2's "fp32 posterior samples"): the GEMM
+    rounds every sample to f32 when it stores it, scorer / KDE / pixel kernels widen it -- all arithmetic f64.  Against
+    the oracle with `y_samples.astype(float32)` after sample_y (sample_dtype="f32"): observation sets per iteration,
+    iteration count and edge trace bit-exact; the samples the stage API returns are f32-representable; and the
+    trace is a different one than the f64 trace only where rounding to f32 moves a decision (printed)."""
+    g = golden(name)
+    stage = TRACES[name]
+    grad = golden(stage)["ref_grad"]
+    kw = dict(CTOR[stage])
+    rec = []
+    et_o, ci_o, info = orc.trace(g["in_init"], grad, record=rec, sign_convention="harmonic", sample_dtype="f32", **kw)
+    tr = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, sample_dtype="f32", _ctx=ctx)
+    et, (all_samples, all_obs, curves) = tr(return_lines=True)
+    assert tr._n_iter == info["n_iter"]
+    for i, r in enumerate(rec):
+        assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
+    assert np.array_equal(et, et_o)
+    # the stage API on the same object: samples come back as f64 values that are exactly f32
+    b = tr._batch
+    b.set_obs(0, g["ref_obs_01"] if "ref_obs_01" in g else all_obs[1])
+    b.fit_predict(want_cov=True)
+    b.factor()
+    b.normals([kw.get("seed", 42) + 1])
+    b.sample()
+    Y = b.read(amd._lib.BUF_SAMPLES)
+    assert Y.dtype == np.float64 and np.array_equal(Y, Y.astype(np.float32).astype(np.float64))
+    tr64 = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, _ctx=ctx)
+    et64 = tr64()
+    print("%s: f32-sample trace %s the f64-sample trace (%d vs %d iterations)"
+          % (name, "equals" if np.array_equal(et, et64) else "differs from", tr._n_iter, tr64._n_iter))
+
+
 def test_trace_quality_band(amd, ctx):
     """Trace quality vs ground truth on a synthetic image where the reference algorithm itself is
     stable across random draws (image seed 3: oracle MSE 39-52 over sign conventions and seeds;
