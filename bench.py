@@ -393,6 +393,27 @@ def main():
                                         trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_f32])),
                                         note="sample GEMM stores f32, scorer/KDE widen; all arithmetic f64; opt-in, "
                                              "tests/test_gpu_trace.py::test_full_trace_f32_samples_vs_oracle")
+        # (b3) the opt-in counter-based generator (Philox4x32-10 + Box-Muller instead of numpy's RandomState stream):
+        #      other numbers than the reference draws, so never the headline
+        for tr_ in tracers:
+            tr_._ctx.sync()
+            tr_._batch.set_rng("philox")
+        timed_steps(tracers, len(tracers), depth, executor, [])
+        for tr_ in tracers:
+            tr_._ctx.sync()
+        t1 = time.time()
+        _, _, it_px, tr_px = timed_steps(tracers, 4, depth, executor, [])
+        for tr_ in tracers:
+            tr_._ctx.sync()
+        dt_px = time.time() - t1
+        px_normals_ms = tracer._batch.profile_stage(2, 5)
+        for tr_ in tracers:
+            tr_._batch.set_rng("mt19937")
+        secondary["philox_rng"] = dict(traces_per_s=4 * E / dt_px, ms_per_step=1e3 * dt_px / 4, edges=E,
+                                       normals_ms_per_ring=px_normals_ms,
+                                       trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_px])),
+                                       note="gpet_batch_set_rng(1): not the reference's random numbers; "
+                                            "tests/test_gpu_stages.py::test_full_trace_philox_mode_vs_oracle")
         # (c) BASELINE config 4's batch size: 256 edges per step (pipelined like the headline)
         small = [make_tracer(256, tr_._ctx) for tr_ in tracers]
         timed_steps(small, len(small), depth, executor, [])

@@ -94,6 +94,7 @@ SYMBOLS = {
     "gpet_final_fit_all": (C.c_int, [_P, C.POINTER(C.c_uint32), _P, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "gpet_final_optimize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int32)]),
     "gpet_batch_set_sample_dtype": (C.c_int, [_P, C.c_int]),
+    "gpet_batch_set_rng": (C.c_int, [_P, C.c_int]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -366,6 +367,13 @@ class Batch:
         self.ctx.check(self.lib.gpet_final_fit_all(self.h, s, mean.ctypes.data, std.ctypes.data, th.ctypes.data, Lg,
                                                    C.byref(rounds)))
         return mean, std, th[:, :3].copy(), th[:, 3].copy(), rounds.value
+
+    def set_rng(self, rng):
+        """Random numbers of the batch: "mt19937" (default: numpy's RandomState stream, the reference's) or "philox"
+        (gpet_batch_set_rng: counter-based Philox4x32-10 + Box-Muller, opt-in, not the reference's numbers)."""
+        if rng not in (None, "mt19937", "philox"):
+            raise ValueError("rng must be 'mt19937' or 'philox'")
+        self.ctx.check(self.lib.gpet_batch_set_rng(self.h, 1 if rng == "philox" else 0))
 
     def set_sample_dtype(self, dtype):
         """Storage type of the posterior samples: "f64" (default, the reference's) or "f32" (gpet_batch_set_sample_dtype:

@@ -46,6 +46,7 @@ struct gpet_batch {
   long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
+  int rng_mode = 0;                    // 0: MT19937 + polar method = numpy's RandomState stream; 1: Philox4x32-10 + Box-Muller (opt-in)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
   double* d_fin_stage = nullptr;       // staging of the converged fits' training sets (x | y | w blocks)
   int* d_fin_n = nullptr;
@@ -277,6 +278,10 @@ static int& opt_rng_chunked() {
 static int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l, int add_iter,
                         int iter_abs, int n_ahead, int z_store) {
   gpet_ctx* c = b->ctx;
+  if (b->rng_mode == 1) {  // opt-in Philox mode (gpet_batch_set_rng)
+    HIPCHK(c, launch_normals_philox(st, edges_l, B_l, b->bd, seeds_l, add_iter, iter_abs, n_ahead, z_store));
+    return GPET_OK;
+  }
   const int streams = B_l * n_ahead;
   const int nc = mtj_chunks((long long)b->bd.S * b->bd.Lg);
   const int opt = opt_rng_chunked();
@@ -1055,6 +1060,17 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
   return GPET_OK;
 }
 
+int gpet_batch_set_rng(gpet_batch* b, int mode) {
+  if (!b || (mode != 0 && mode != 1)) return GPET_ERR_BAD_ARG;
+  gpet_ctx* c = b->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, gpet_wait(c->stream));
+  if (b->side) HIPCHK(c, gpet_wait(b->side));
+  b->rng_mode = mode;
+  b->have_normals = false;
+  return GPET_OK;
+}
+
 int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -1236,7 +1252,10 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         break;
       case 120: case 121: case 122: case 123:  // structured path: fit, (U, H, mean), Jacobi, factor rows
         HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
-      case 2: HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b))); break;
+      case 2:
+        if (b->rng_mode == 1) HIPCHK(c, launch_normals_philox(c->stream, b->d_edges, b->B, b->bd, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b)));
+        else HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b)));
+        break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;
       case 5: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, ~0u, 1)); break;  // (the loop form: raw, band only)

@@ -5661,6 +5661,62 @@ hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   return launch_set_force(st, d_edges, B, 0);
 }
 
+// ---- opt-in counter-based normals (SURVEY K5 "fast Philox mode"; gpet_batch_set_rng) ---------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror & Shaw, SC'11; the Random123 known-answer vectors are in the tests) + Box-Muller.
+// The normal of (sample row s, column j) is a pure function of (seed of the iteration, s, j): counter = (j / 2, s, 0, 0),
+// key = (seed, "Phlx"); its four words give two 53-bit uniforms u1, u2 in (0, 1) and the pair
+// sqrt(-2 ln u1) (cos 2 pi u2, sin 2 pi u2) for columns j, j + 1.  No stream to walk: every thread writes its own pair, and
+// only the columns the factor multiplies are generated at all.  NOT the reference's numbers (sklearn_gpr.py:464 draws from
+// RandomState(seed)): a mode of its own with its own oracle (oracle.philox_standard_normal), never the default.
+__device__ __forceinline__ void philox4x32_10(unsigned int c[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned int)p1;
+    c[3] = (unsigned int)p0;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__global__ void __launch_bounds__(256) k_philox_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter, int iter_abs,
+                                                        int z_store) {
+  const EdgeDev E = edges[blockIdx.z];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int iter_idx = (iter_abs >= 0 ? iter_abs : sc->iter) + (int)blockIdx.y;
+  double* __restrict__ Zs = E.Z + (size_t)(iter_idx % E.z_ring) * ((size_t)E.S * E.z_cols);
+  const int zc = E.z_cols, zs = (z_store > 0 && z_store < zc) ? z_store : zc;
+  const int hp = (zs + 1) >> 1;  // column pairs per row
+  const unsigned int key = seeds[blockIdx.z] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);  // (the loop's seed rule, gpet.py:839)
+  const long long total = (long long)E.S * hp;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int srow = (int)(e / hp), jp = (int)(e - (long long)srow * hp);
+    unsigned int c[4] = {(unsigned int)jp, (unsigned int)srow, 0u, 0u};
+    philox4x32_10(c, key, 0x50686c78u);
+    const double u1 = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6) + 0.5) * (1.0 / 9007199254740992.0);
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    double* o = Zs + (size_t)srow * zc + 2 * jp;
+    o[0] = r * cs;
+    if (2 * jp + 1 < zs) o[1] = r * sn;
+  }
+}
+hipError_t launch_normals_philox(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const unsigned int* d_seeds, int add_iter,
+                                 int iter_abs, int n_ahead, int z_store) {
+  (void)hipGetLastError();
+  const int zs = (z_store > 0 && z_store < bd.z_cols) ? z_store : bd.z_cols;
+  const long long pairs = (long long)bd.S * ((zs + 1) / 2);
+  int gx = (int)((pairs + 256 * 4 - 1) / (256 * 4));  // four pairs per thread
+  gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+  hipLaunchKernelGGL(k_philox_normals, dim3(gx, n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store);
+  return hipGetLastError();
+}
+
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead, int z_store) {
   (void)hipGetLastError();  // drop stale errors: report only these launches

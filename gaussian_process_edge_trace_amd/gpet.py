@@ -105,7 +105,7 @@ class GP_Edge_Tracing(object):
     def __init__(self, init, grad_img, kernel_options=(1, 3, 3), noise_y=1, obs=np.array([], dtype=np.int8),
                  N_samples=500, score_thresh=1, delta_x=20, keep_ratio=0.1, pixel_thresh=5, seed=42,
                  return_std=False, fix_endpoints=True, *, device=0, stream=None, factor_cap=0, z_cols=0,
-                 sample_dtype=None, _ctx=None):
+                 sample_dtype=None, rng=None, _ctx=None):
         p = resolve_params(init, np.asarray(grad_img).shape, kernel_options, noise_y, obs, N_samples, score_thresh,
                            delta_x, keep_ratio, pixel_thresh, seed, return_std, fix_endpoints)
         self._p = p
@@ -123,6 +123,8 @@ class GP_Edge_Tracing(object):
         self._batch = _lib.Batch(self._ctx, [g32], [self._abi], [p["init"]])
         if sample_dtype is not None:  # (keyword beyond the reference's signature: "f32" stores the samples in single precision)
             self._batch.set_sample_dtype(sample_dtype)
+        if rng is not None:  # ("philox": the counter-based generator instead of numpy's RandomState stream)
+            self._batch.set_rng(rng)
         self.grad_img = self._batch.read(_lib.BUF_GRAD).astype(np.float64)
         self._n_iter = 0
 
@@ -333,7 +335,7 @@ class GP_Edge_Tracing_Batch(object):
     def __init__(self, inits, grad_imgs, seeds, kernel_options=(1, 3, 3), noise_y=1, N_samples=500, score_thresh=1,
                  delta_x=20, keep_ratio=0.1, pixel_thresh=5, return_std=False, fix_endpoints=True, *, obs=None,
                  device=0, stream=None, factor_cap=0, z_cols=0, _ctx=None, grad_device_ptrs=None, grad_shape=None,
-                 sample_dtype=None):
+                 sample_dtype=None, rng=None):
         """``obs``: optional list of per-edge warm-start observation sets (xy), the reference's ``obs`` constructor
         argument (gpet.py:57-61,100,820).  ``grad_device_ptrs`` + ``grad_shape``: the gradient image(s) already live
         on this GPU (e.g. a torch tensor an RCCL broadcast filled): integer device addresses of f32 (M, N) arrays,
@@ -363,6 +365,8 @@ class GP_Edge_Tracing_Batch(object):
             self._batch = _lib.Batch(self._ctx, g32, abi, [p["init"] for p in self._ps], share_image=share)
         if sample_dtype is not None:
             self._batch.set_sample_dtype(sample_dtype)
+        if rng is not None:
+            self._batch.set_rng(rng)
         self._set_obs()
         self.B = B
         self.return_std = return_std

@@ -271,6 +271,12 @@ int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* t
 int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
                        int stride, int32_t* rounds_out);
 
+/* Random numbers of this batch: 0 = MT19937 + polar method, the stream of numpy's RandomState(seed).standard_normal that
+ * sklearn_gpr.py:460-464 draws from (default; every parity statement is made on it); 1 = Philox4x32-10 + Box-Muller, a
+ * counter-based generator (normal (s, j) of an iteration is a pure function of seed, s, j): NOT the reference's numbers, an
+ * opt-in mode with its own oracle (oracle.philox_standard_normal); the per-iteration seed rule (gpet.py:839) is the same. */
+int gpet_batch_set_rng(gpet_batch* b, int mode);
+
 /* Storage type of the posterior samples of this batch: 0 = f64 (default: the reference's sample_y, sklearn_gpr.py:440-473,
  * every parity statement is made on it), 1 = f32 -- BASELINE config 2's "fp32 posterior samples": the sample GEMM rounds
  * each sample to f32 when it stores it, scorer / KDE / pixel kernels widen it again, all arithmetic stays f64; GPET_BUF_SAMPLES

@@ -434,3 +434,45 @@ def test_topk_sort_and_rank_counting_agree_with_stable_argsort(amd, ctx, monkeyp
             assert np.array_equal(got_idx, want), (S, env)
             assert np.array_equal(got_cost, costs[want])
         monkeypatch.delenv("GPET_TOPK_RANK", raising=False)
+
+
+def test_philox_normals_equal_the_oracle_generator(amd, ctx, golden):
+    """gpet_batch_set_rng(1): the device's Philox4x32-10 + Box-Muller normals against oracle.philox_standard_normal (the
+    integer part is exact; log / sincospi differ from numpy's by ulps), through the stage API, for the stored columns;
+    switching back gives numpy's RandomState stream again."""
+    L = amd._lib
+    g = golden("stage_rbf64")
+    tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR["stage_rbf64"], _ctx=ctx, rng="philox")
+    b = tr._batch
+    b.set_obs(0, g["in_obs"])
+    b.fit_predict(want_cov=True)
+    b.factor()
+    b.normals([77])
+    Z = b.read(L.BUF_NORMALS)
+    want = orc.philox_standard_normal(77, Z.shape[0], Z.shape[1])
+    np.testing.assert_allclose(Z, want, rtol=0, atol=1e-13)
+    b.set_rng("mt19937")
+    b.normals([77])
+    Zm = b.read(L.BUF_NORMALS)
+    ref = orc.legacy_standard_normal(77, Z.shape[0] * tr.x_grid.size).reshape(Z.shape[0], -1)[:, :Z.shape[1]]
+    np.testing.assert_allclose(Zm, ref, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["trace_rbf64", "trace_mat128", "trace_rbf500"])
+def test_full_trace_philox_mode_vs_oracle(amd, ctx, golden, name):
+    """rng="philox" end to end: the device loop with the counter-based generator against the oracle fed with the same
+    normals (oracle.trace(rng="philox")): observation sets per iteration, iteration count and edge trace bit-exact --
+    the same tier as the default mode, on the other generator (whose numbers are NOT the reference's)."""
+    from tests.test_oracle_vs_golden import TRACES
+    g = golden(name)
+    stage = TRACES[name]
+    grad = golden(stage)["ref_grad"]
+    kw = dict(CTOR[stage])
+    rec = []
+    et_o, ci_o, info = orc.trace(g["in_init"], grad, record=rec, sign_convention="harmonic", rng="philox", **kw)
+    tr = amd.GP_Edge_Tracing(g["in_init"], grad, **kw, rng="philox", _ctx=ctx)
+    et, (all_samples, all_obs, curves) = tr(return_lines=True)
+    assert tr._n_iter == info["n_iter"]
+    for i, r in enumerate(rec):
+        assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
+    assert np.array_equal(et, et_o)

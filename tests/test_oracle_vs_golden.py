@@ -171,3 +171,26 @@ def test_full_trace_readme_500(golden):
         assert np.array_equal(r["obs_out"], g["ref_obs_%02d" % (i + 1)])
     assert np.array_equal(et, g["ref_edge_trace"])
     np.testing.assert_allclose(ci[0], g["ref_ci_lower"], rtol=1e-6, atol=1e-6)
+
+
+def test_philox_known_answers_and_moments():
+    """The opt-in generator's building block against the Random123 known-answer vectors of Philox4x32-10, and the
+    first moments / tails of the Box-Muller normals built on it (oracle.philox_standard_normal = what the device's
+    k_philox_normals is tested against)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = orc.philox4x32_10(*ctr, *key)
+        assert tuple(int(v) for v in got) == want
+    Z = orc.philox_standard_normal(12345, 4000, 500)
+    n = Z.size
+    assert Z.shape == (4000, 500) and np.all(np.isfinite(Z))
+    assert abs(Z.mean()) < 4.0 / np.sqrt(n) and abs(Z.var() - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(np.mean(Z ** 3)) < 4.0 * np.sqrt(15.0 / n) and abs(np.mean(Z ** 4) - 3.0) < 4.0 * np.sqrt(96.0 / n)
+    from scipy import stats
+    assert stats.kstest(Z[::7, ::3].ravel(), "norm").pvalue > 1e-3
+    # rows and columns are uncorrelated; a different seed gives different numbers; an odd column count keeps the pairs' first halves
+    assert abs(np.corrcoef(Z[:, 0], Z[:, 1])[0, 1]) < 0.08 and abs(np.corrcoef(Z[0], Z[1])[0, 1]) < 0.2
+    assert not np.array_equal(orc.philox_standard_normal(12346, 8, 10), Z[:8, :10])
+    assert np.array_equal(orc.philox_standard_normal(12345, 8, 9), Z[:8, :9])
