@@ -202,6 +202,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.pcx_cand = cv.take<double>(16 * ((size_t)E.N / 32 + 2));  // (indexed with the widest edge of the batch)
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
   E.jb_norm = cv.take<double>(2);
+  E.jlog = cv.take<double>(E.jlog_cap > 0 ? (size_t)E.jlog_cap * 2 * rc * (rc / 2 + 1) : 2);
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
   E.Y = cv.take<double>(S * Lg);
@@ -616,6 +617,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     // instead of 16 -- at 1024 edges of the bench shape 2.4 GB instead of 9.4 GB of an 18 GB arena.  Full-stream mode
     // (z_cols == Lg: full-rank covariances, tests) holds whole 8 MB streams per slot: 2.
     E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 4);
+    // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
+    // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
+    E.jlog_cap = (B <= 16 && E.r_cap <= 96) ? 40 : 0;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
     E.nu_gen = p.nu;
@@ -640,6 +644,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     if (E.obs_cap > bd.obs_cap) bd.obs_cap = E.obs_cap;
     if (E.a_rows_cap > bd.a_rows_cap) bd.a_rows_cap = E.a_rows_cap;
     if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
+    bd.jlog = E.jlog_cap > 0 ? 1 : 0;
   }
   b->bd = bd;
   // measure, allocate, carve
@@ -692,7 +697,15 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   HIPCHK(c, hipMalloc(&b->d_edges, sizeof(EdgeDev) * B));
   HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
   HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
-  HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  {
+    // GPET_RNG_PRIORITY = normal (default) | low | high: priority of the stream the normals run ahead of the loop on
+    int pl = 0, pg = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pl, &pg));
+    const char* rp = getenv("GPET_RNG_PRIORITY");
+    if (rp && strcmp(rp, "low") == 0) HIPCHK(c, hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, pl));
+    else if (rp && strcmp(rp, "high") == 0) HIPCHK(c, hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, pg));
+    else HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+  }
   {
     int pr_least = 0, pr_greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));

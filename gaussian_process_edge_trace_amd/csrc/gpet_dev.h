@@ -57,6 +57,8 @@ struct EdgeDev {
   int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
+  double* jlog;          // [JS_LOG_SWEEPS][m - 1][m / 2][2] rotations (c, s) of the LDS Jacobi, round by round (small batches only, else 1 entry)
+  int jlog_cap;          // sweeps the log holds (0: none)
   EigState* eig;         // state of the any-rank factorisation
   double* Gt;            // [Lg][r_cap] transposed copy of G kept by the multi-workgroup pivoted Cholesky (ranks > 96 only)
   double* pcx_d;         // [Lg] remaining diagonal of the multi-workgroup pivoted Cholesky (-1: pivoted)

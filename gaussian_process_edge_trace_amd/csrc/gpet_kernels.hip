@@ -714,7 +714,9 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int w
       for (int u = 0; u < 8; ++u) {
         const int j = (j0 + u < CB) ? j0 + u : CB - 1;
         const double ljk = lj[u] * r;
-        s[i][j] = fma(-lik, ljk, sv[u]);
+        // (the next pivot's entry itself is not written: slower waves may still be reading it for their own copy of the
+        //  next pivot, and nobody needs it again -- the pivot travels in d)
+        if (!(i == j && j == k + 1)) s[i][j] = fma(-lik, ljk, sv[u]);
         sx[j][i] = fma(-ljk, xk, xv[u]);
       }
     }
@@ -1503,7 +1505,11 @@ __device__ __forceinline__ void seat_block_of(int e, int& a_, int& b_) {  // e =
 }
 
 #define JS_NT 512
-template <int NU>  // blocks per thread: half (half + 1) / 2 <= 1024 up to m = 88, 1176 at m = 96
+#define JS_LOG_SWEEPS 40  // sweeps a rotation log holds (= the sweep limit of the kernel)
+// LOGW (small batches, where the chain of rounds IS the time): the eigenvectors are not accumulated here -- 41 KB of LDS
+// stores a round, 1 200-1 600 of its 2 650 cycles -- but the round's rotations (c, s) go to a log in global memory, and
+// k_jacobi_wpass applies them to the rows of W afterwards, one wave per row in registers, on as many CUs as there are rows.
+template <int NU, bool LOGW>  // NU blocks per thread: half (half + 1) / 2 <= 1024 up to m = 88, 1176 at m = 96
 __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scaled_out) {
   constexpr int NT = JS_NT;
   const EdgeDev E = edges[blockIdx.y];
@@ -1535,10 +1541,12 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
       A0[q * nblk + e] = (hi < r) ? E.C[(size_t)lo * ldg + hi] : 0.0;
     }
   }
-  for (int e = tid; e < half * m; e += NT) {
-    const int ip = e / m, pl = e - ip * m;
-    W2[e] = make_double2(pl == 2 * ip ? 1.0 : 0.0, pl == 2 * ip + 1 ? 1.0 : 0.0);
-  }
+  if (!LOGW)
+    for (int e = tid; e < half * m; e += NT) {
+      const int ip = e / m, pl = e - ip * m;
+      W2[e] = make_double2(pl == 2 * ip ? 1.0 : 0.0, pl == 2 * ip + 1 ? 1.0 : 0.0);
+    }
+  double2* jlog = reinterpret_cast<double2*>(E.jlog);
   // fixed roles: blocks tid, tid + NT, ... with the places of their four entries in the next round's layout
   int ba[NU], bb[NU], dst[NU][4];
 #pragma unroll
@@ -1563,7 +1571,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
 #ifdef GPET_JAC_TRACE
   double trace_rel = 0.0;
 #endif
-  auto params = [&](int nxt) {
+  auto params = [&](int nxt, int log_round) {
     if (pk >= 0 && pk < half) {
       double c = 1.0, s = 0.0;
       const double app = A0[dk], apq = A0[nblk + dk], aqq = A0[3 * nblk + dk];
@@ -1593,6 +1601,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
         s = t * c;
       }
       s_cs[nxt][pk] = make_double2(c, s);
+      if (LOGW) jlog[(size_t)log_round * half + pk] = make_double2(c, s);
     }
   };
   __syncthreads();
@@ -1634,7 +1643,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
       // quadratic convergence: off^2 <= 1e-24 diag^2 now means <= 1e-48 after one more sweep
       if (off <= 1e-24 * dg || off == 0.0) break;
       ++sweeps;
-      params(0);
+      params(0, (sweeps - 1) * m1);
       __syncthreads();
       int pb = wb, qb = wb == 0 ? m1 : m1 - wb;  // players of this thread's W pair in round 0
       for (int round = 0; round < m1; ++round) {
@@ -1667,7 +1676,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
         JAC_CLK(q3);
         __syncthreads();
         JAC_CLK(q4);
-        if (w_on) {  // W: rotate the eigenvector entries of players pb, qb (needs only this round's cs)
+        if (!LOGW && w_on) {  // W: rotate the eigenvector entries of players pb, qb (needs only this round's cs)
           const double2 rb = cs[wb];
           const double cb = rb.x, sb = rb.y;
           if (sb != 0.0) {
@@ -1686,14 +1695,15 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
               for (int t = 0; t < 3; ++t) {
                 const int ip = ip0 + t * ngrp;
                 if (ip < half) {
-                  W2[ip * m + pb] = make_double2(cb * wp[t].x - sb * wq[t].x, cb * wp[t].y - sb * wq[t].y);
-                  W2[ip * m + qb] = make_double2(sb * wp[t].x + cb * wq[t].x, sb * wp[t].y + cb * wq[t].y);
+                  // (spelled out: k_jacobi_wpass does exactly this arithmetic)
+                  W2[ip * m + pb] = make_double2(fma(cb, wp[t].x, -(sb * wq[t].x)), fma(cb, wp[t].y, -(sb * wq[t].y)));
+                  W2[ip * m + qb] = make_double2(fma(sb, wp[t].x, cb * wq[t].x), fma(sb, wp[t].y, cb * wq[t].y));
                 }
               }
             }
           }
         }
-        if (round + 1 < m1) params((round + 1) & 1);
+        if (round + 1 < m1) params((round + 1) & 1, (sweeps - 1) * m1 + round + 1);
         JAC_CLK(q5);
         __syncthreads();
 #ifdef GPET_JAC_PROF
@@ -1715,10 +1725,11 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
   __syncthreads();
   for (int k = tid; k < r; k += NT) E.theta[k] = s_theta[k];
   const double* Wd = reinterpret_cast<const double*>(W2);  // W[j][i] = Wd[((i >> 1) * m + j) * 2 + (i & 1)]
-  for (int e = tid; e < r * r; e += NT) {
-    const int i = e / r, j = e - i * r;
-    E.W[(size_t)i * ldg + j] = Wd[((i >> 1) * m + j) * 2 + (i & 1)];
-  }
+  if (!LOGW)
+    for (int e = tid; e < r * r; e += NT) {
+      const int i = e / r, j = e - i * r;
+      E.W[(size_t)i * ldg + j] = Wd[((i >> 1) * m + j) * 2 + (i & 1)];
+    }
   for (int k = tid; k < r; k += NT) {
     const double v = s_theta[k];
     int pos = 0;
@@ -1732,7 +1743,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
   __syncthreads();
   // structured path (scaled_out): G (unused there) <- eigenvectors in descending eigenvalue order, scaled by
   // y_std sqrt(theta): column pos of row t is the coefficient of basis vector t in factor row pos
-  if (scaled_out) {
+  if (scaled_out && !LOGW) {
     for (int e = tid; e < r * r; e += NT) {
       const int i = e / r, j = e - i * r;
       const double th = s_theta[j];
@@ -1748,6 +1759,79 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
   }
 #endif
 #undef JAC_CLK
+}
+
+// The eigenvectors from the rotation log of k_jacobi_seat<.., LOGW>: wave = component i (row i of W over the players), lane
+// k = pair k of the seating: x = the entry of the player in slot 2k, y = of the player in slot 2k + 1.  A round rotates
+// (x, y) by the pair's (c, s) -- the arithmetic of the LDS form, W[.][p] = c p - s q, W[.][q] = s p + c q -- and then moves
+// every player of the circle one seat on: x one lane down, y one lane up, the two ends handed over (slot 0's player goes to
+// slot 3, the last odd slot's player to the last even slot; the pivot in slot 1 stays), by whole-wave DPP shifts.  The log
+// is read eight rounds at a time, the next eight requested before these are applied.  After whole sweeps everybody is
+// back in the seats of round 0.
+__device__ __forceinline__ double wp_lane_from_above(double v, double keep) {  // lane k <- lane k + 1 (the last lane keeps `keep`)
+  const long long b = __double_as_longlong(v), o = __double_as_longlong(keep);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)b, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), 0x130, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wp_lane_from_below(double v, double keep) {  // lane k <- lane k - 1 (lane 0 keeps `keep`)
+  const long long b = __double_as_longlong(v), o = __double_as_longlong(keep);
+  const int lo = __builtin_amdgcn_update_dpp((int)o, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), 0x138, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ void __launch_bounds__(256) k_jacobi_wpass(EdgeDev* edges, int scaled_out) {
+  const EdgeDev E = edges[blockIdx.y];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK || E.factor_injected) return;
+  const int r = sc->rank, ldg = E.r_cap;
+  const int m = (r + 1) & ~1, half = m >> 1, m1 = m - 1;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int s_pos[96];
+  for (int k = threadIdx.x; k < r; k += 256) s_pos[E.order[k]] = k;  // player -> place in descending order (k_jacobi_seat wrote E.order)
+  __syncthreads();
+  if (i >= r || r < 1) return;
+  const int total = (int)sc->lml * m1;  // (sweeps of this factorisation x rounds)
+  const double2* jlog = reinterpret_cast<const double2*>(E.jlog);
+  const bool on = lane < half;
+  const int pe = seat_player(2 * lane, 0, m1), po = seat_player(2 * lane + 1, 0, m1);
+  double x = (on && pe == i) ? 1.0 : 0.0, y = (on && po == i) ? 1.0 : 0.0;
+  const bool lane0 = lane == 0, lane_last = lane == half - 1;
+  constexpr int PF = 8;
+  double2 cur[PF], nxt[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) cur[u] = (on && u < total) ? jlog[(size_t)u * half + lane] : make_double2(1.0, 0.0);
+  for (int r0 = 0; r0 < total; r0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) nxt[u] = (on && r0 + PF + u < total) ? jlog[(size_t)(r0 + PF + u) * half + lane] : make_double2(1.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (r0 + u < total) {  // (uniform)
+        const double c = cur[u].x, sn = cur[u].y;
+        const double xr = fma(c, x, -(sn * y)), yr = fma(sn, x, c * y);
+        const double xd = wp_lane_from_above(xr, xr);
+        const double yu = wp_lane_from_below(lane0 ? xr : yr, yr);
+        x = lane_last ? yr : xd;
+        y = yu;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) cur[u] = nxt[u];
+  }
+  if (!on) return;
+  // lane k holds component i of the eigenvectors of players pe and po
+  if (pe < r) E.W[(size_t)i * ldg + pe] = x;
+  if (po < r) E.W[(size_t)i * ldg + po] = y;
+  if (scaled_out) {
+    if (pe < r) {
+      const double th = E.theta[pe];
+      E.G[(size_t)i * ldg + s_pos[pe]] = x * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+    }
+    if (po < r) {
+      const double th = E.theta[po];
+      E.G[(size_t)i * ldg + s_pos[po]] = y * (sc->y_std * sqrt(th > 0.0 ? th : 0.0));
+    }
+  }
 }
 
 // ---- structured loop path (training points on the pixel grid, rank(rho) <= 96) ---------------
@@ -5537,13 +5621,20 @@ int& gpet_opt_jacobi_variant() {
   static int v = getenv("GPET_JACOBI_VARIANT") ? atoi(getenv("GPET_JACOBI_VARIANT")) : 1;
   return v;
 }
-static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int rank_max, int scaled_out) {
+// rotation log + separate eigenvector pass for batches that have a log (gpet_batch_create: up to 16 edges): 1 = on (default)
+int& gpet_opt_jacobi_logw() {
+  static int v = getenv("GPET_JACOBI_LOGW") ? atoi(getenv("GPET_JACOBI_LOGW")) : 1;
+  return v;
+}
+static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int rank_max, int scaled_out, bool logw) {
   const int mm = (rank_max + 1) & ~1;
   static PerDeviceOnce once;
   if (once.first()) {
     (void)hipFuncSetAttribute((const void*)k_jacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi_seat<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   }
   if (gpet_opt_jacobi_variant() == 0) {
     hipLaunchKernelGGL(k_jacobi_lds, dim3(1, B), dim3(1024), ((size_t)mm * (mm | 1) + (size_t)mm * (mm + 2)) * sizeof(double), st,
@@ -5551,8 +5642,16 @@ static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int ran
   } else {
     const size_t nblk = (size_t)(mm / 2) * (mm / 2 + 1) / 2;
     const size_t lds = (4 * ((nblk + 1) & ~(size_t)1) + (size_t)mm * mm) * sizeof(double);
-    if (nblk <= 2 * JS_NT) hipLaunchKernelGGL(k_jacobi_seat<2>, dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
-    else hipLaunchKernelGGL(k_jacobi_seat<3>, dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+    if (logw) {
+      // small batch: rotations logged, eigenvectors by a second kernel (one wave per row of W)
+      if (nblk <= 2 * JS_NT) hipLaunchKernelGGL((k_jacobi_seat<2, true>), dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+      else hipLaunchKernelGGL((k_jacobi_seat<3, true>), dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+      hipLaunchKernelGGL(k_jacobi_wpass, dim3((rank_max + 3) / 4, B), dim3(256), 0, st, d_edges, scaled_out);
+    } else if (nblk <= 2 * JS_NT) {
+      hipLaunchKernelGGL((k_jacobi_seat<2, false>), dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+    } else {
+      hipLaunchKernelGGL((k_jacobi_seat<3, false>), dim3(1, B), dim3(JS_NT), lds, st, d_edges, scaled_out);
+    }
   }
 }
 
@@ -5596,7 +5695,7 @@ hipError_t launch_factor(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   }
   const int t = cdiv(bd.r_cap, 16);
   if (parts & 2u) hipLaunchKernelGGL(k_gram, dim3(t, t, B), dim3(256), 0, st, d_edges);
-  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r_cap, 0);
+  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r_cap, 0, bd.jlog != 0 && gpet_opt_jacobi_logw() != 0);
   if (parts & 8u)
     hipLaunchKernelGGL(k_factor_rows, dim3(bd.r_cap, B), dim3(256), (size_t)bd.r_cap * sizeof(double), st, d_edges);
   return hipGetLastError();
@@ -5634,7 +5733,7 @@ hipError_t launch_struct_iteration(hipStream_t st, EdgeDev* d_edges, int B, cons
     const int l_in_lds = full <= (size_t)STRUCT_H_LDS_MAX ? 1 : 0;  // (gpet_batch_create checked that `rowm` fits)
     hipLaunchKernelGGL(k_struct_H, dim3(1, B), dim3(1024), l_in_lds ? full : rowm, st, d_edges, l_in_lds);
   }
-  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r0_max > 0 ? bd.r0_max : bd.r_cap, 1);
+  if (parts & 4u) launch_jacobi_small(st, d_edges, B, bd.r0_max > 0 ? bd.r0_max : bd.r_cap, 1, bd.jlog != 0 && gpet_opt_jacobi_logw() != 0);
   if (parts & 8u) {
     // the variant k_struct_rows picks for r0_max: [4 KS][16 MT + 1] eigenvector tile, reused as [r][64] products
     const int rm = bd.r0_max;
@@ -5667,7 +5766,7 @@ hipError_t launch_struct_basis(hipStream_t st, EdgeDev* d_edges, int B, const Ba
 // key = (seed, "Phlx"); its four words give two 53-bit uniforms u1, u2 in (0, 1) and the pair
 // sqrt(-2 ln u1) (cos 2 pi u2, sin 2 pi u2) for columns j, j + 1.  No stream to walk: every thread writes its own pair, and
 // only the columns the factor multiplies are generated at all.  NOT the reference's numbers (sklearn_gpr.py:464 draws from
-// RandomState(seed)): a mode of its own with its own oracle (oracle.philox_standard_normal), never the default.
+// RandomState(seed)): a mode of its own with its own CPU twin in the tests (philox_standard_normal), never the default.
 __device__ __forceinline__ void philox4x32_10(unsigned int c[4], unsigned int k0, unsigned int k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
