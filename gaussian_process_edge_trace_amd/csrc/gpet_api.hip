@@ -337,6 +337,12 @@ int gpet_set_option(const char* name, int value) {
     v = value < 0 ? -1 : (value > 0 ? 1 : 0);
     return old < 0 ? 2 : old;  // (2 = "by the number of problems")
   }
+  if (name && strcmp(name, "jacobi_logw") == 0) {
+    int& v = gpet_opt_jacobi_logw();
+    const int old = v;
+    v = value != 0 ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "lml_mfma") == 0) {
     int& v = gpet_opt_lml_mfma();
     const int old = v;

@@ -476,3 +476,34 @@ def test_full_trace_philox_mode_vs_oracle(amd, ctx, golden, name):
     for i, r in enumerate(rec):
         assert np.array_equal(all_obs[i + 1], r["obs_out"]), "iteration %d" % i
     assert np.array_equal(et, et_o)
+
+
+def test_jacobi_rotation_log_form_equals_lds_form(amd, ctx, golden):
+    """Batches of up to 16 edges log the rotations of the LDS Jacobi and form the eigenvectors in a second kernel
+    (k_jacobi_wpass: one wave per row of W in registers, seats moved by DPP shifts) instead of accumulating them in LDS
+    inside the rounds: the same rotations applied with the same arithmetic -- eigenvalues, factor rows and the
+    structured loop's scaled eigenvectors are IDENTICAL, on the generic path (stage API) and on the loop path."""
+    L = amd._lib
+    for name in ("stage_rbf64", "stage_rbf500"):
+        g = golden(name)
+        out = {}
+        old = L.set_option("jacobi_logw", 1)
+        try:
+            for mode in (0, 1):
+                L.set_option("jacobi_logw", mode)
+                tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx)
+                b = tr._batch
+                b.set_obs(0, g["in_obs"])
+                b.fit_predict(want_cov=True)
+                b.factor()
+                gen = (b.read(L.BUF_FACTOR).copy(), b.read(L.BUF_EIGVALS).copy())
+                b.set_obs(0, g["in_obs"])
+                for stage in (120, 121, 122, 123):
+                    b.profile_stage(stage, 1)
+                out[mode] = gen + (b.read(L.BUF_FACTOR).copy(), b.read(L.BUF_EIGVALS).copy())
+                tr2 = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **CTOR[name], _ctx=ctx)
+                out[mode] += (tr2(),)
+        finally:
+            L.set_option("jacobi_logw", old)
+        for k in range(5):
+            assert np.array_equal(out[0][k], out[1][k]), (name, k)
