@@ -1766,7 +1766,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
 // (x, y) by the pair's (c, s) -- the arithmetic of the LDS form, W[.][p] = c p - s q, W[.][q] = s p + c q -- and then moves
 // every player of the circle one seat on: x one lane down, y one lane up, the two ends handed over (slot 0's player goes to
 // slot 3, the last odd slot's player to the last even slot; the pivot in slot 1 stays), by whole-wave DPP shifts.  The log
-// is read eight rounds at a time, the next eight requested before these are applied.  After whole sweeps everybody is
+// is read sixteen rounds at a time, the next sixteen requested before these are applied.  After whole sweeps everybody is
 // back in the seats of round 0.
 __device__ __forceinline__ double wp_lane_from_above(double v, double keep) {  // lane k <- lane k + 1 (the last lane keeps `keep`)
   const long long b = __double_as_longlong(v), o = __double_as_longlong(keep);
@@ -1797,7 +1797,7 @@ __global__ void __launch_bounds__(256) k_jacobi_wpass(EdgeDev* edges, int scaled
   const int pe = seat_player(2 * lane, 0, m1), po = seat_player(2 * lane + 1, 0, m1);
   double x = (on && pe == i) ? 1.0 : 0.0, y = (on && po == i) ? 1.0 : 0.0;
   const bool lane0 = lane == 0, lane_last = lane == half - 1;
-  constexpr int PF = 8;
+  constexpr int PF = 16;  // (rounds per block: ~1 800 cycles of work cover the round trip of the next block's loads)
   double2 cur[PF], nxt[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) cur[u] = (on && u < total) ? jlog[(size_t)u * half + lane] : make_double2(1.0, 0.0);
