@@ -714,9 +714,11 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int w
       for (int u = 0; u < 8; ++u) {
         const int j = (j0 + u < CB) ? j0 + u : CB - 1;
         const double ljk = lj[u] * r;
-        // (the next pivot's entry itself is not written: slower waves may still be reading it for their own copy of the
-        //  next pivot, and nobody needs it again -- the pivot travels in d)
-        if (!(i == j && j == k + 1)) s[i][j] = fma(-lik, ljk, sv[u]);
+        // (the next pivot's entry itself keeps its value -- rewritten with the bits it has: slower waves may still be reading
+        //  it for their own copy of the next pivot, and nobody needs it again, the pivot travels in d.  It is column k + 1
+        //  of lane k + 1: the first column of wave 0's first batch, so only u = 0 carries the select.)
+        const double nv = fma(-lik, ljk, sv[u]);
+        s[i][j] = (u == 0 && j0 == k + 1 && i == j) ? sv[u] : nv;
         sx[j][i] = fma(-ljk, xk, xv[u]);
       }
     }
