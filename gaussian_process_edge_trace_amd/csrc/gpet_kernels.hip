@@ -3326,12 +3326,14 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
 #define SC_THREADS 1024
 // cross-lane moves of a double inside rows of 16 lanes by DPP (two v_mov_b32_dpp; __shfl_xor / __shfl_down with width 16
 // go through ds_bpermute and recompute the lane index every time): CTRL = row_ror:8 / row_ror:4 / quad_perm for the
-// butterfly, row_shl:1 for "the lane above" (lane 15 of a row keeps its own value, as __shfl_down does)
+// butterfly, row_shl:1 for "the lane above" (lane 15 of a row has no source and reads 0: its callers replace the value)
 template <int CTRL>
 __device__ __forceinline__ double dpp_row(double v) {
   const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  // (no "old" operand: a lane without a source -- lane 15 of a row under row_shl:1 -- reads 0 and its callers do not use
+  //  the value; with old = the source the compiler copies every operand into the destination first: 24 moves per pair)
+  const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // sum over the 16 lanes of a row, in every lane; the operands of every addition are those of the xor-8, 4, 2, 1 butterfly
