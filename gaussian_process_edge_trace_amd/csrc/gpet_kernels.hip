@@ -3043,15 +3043,31 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // with four 4-wave workgroups per CU (+8 %), a half-tile phase offset between the workgroups of a CU (+-0).
 #define GEMM_KMAX 96
 #define GEMM_LDS_MAX (150 * 1024)
+// A pointer the compiler knows to be GLOBAL memory.  The buffers of an edge are pointers read from its EdgeDev record, which the
+// compiler can only treat as generic: every access becomes a FLAT instruction, and a FLAT instruction counts in BOTH wait
+// counters (it might be an LDS access), so a wait for an LDS operand (lgkmcnt) can end up waiting for global stores issued
+// before it.  Tried on the sample GEMM as the explanation of its store cost: global_store / global_load instead of flat_*
+// take 0-5 % (1.92 -> 1.82-1.91 ms per 1 024 edges) -- kept, but not the explanation.
+#define GPET_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ GPET_GLOBAL T* as_global(T* p) {
+  return (GPET_GLOBAL T*)p;
+}
+template <typename T>
+__device__ __forceinline__ const GPET_GLOBAL T* as_global(const T* p) {
+  return (const GPET_GLOBAL T*)p;
+}
 template <int KS, bool F32>
 __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part, bool mu_lds) {
   typedef typename YT<F32>::type yt;
-  yt* __restrict__ Yo = reinterpret_cast<yt*>(E.Y);
+  GPET_GLOBAL yt* __restrict__ Yo = as_global(reinterpret_cast<yt*>(E.Y));
+  const GPET_GLOBAL double* __restrict__ Ag = as_global(E.A);
+  const GPET_GLOBAL double* __restrict__ meang = as_global(E.mean);
   constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = part * 128;
   const int rows = sc->rank;
-  const double* __restrict__ Zs = E.Z + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  const GPET_GLOBAL double* __restrict__ Zs = as_global(E.Z) + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int srow = s0 + 16 * w + li;
@@ -3066,14 +3082,14 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
   // wait (vmcnt counts in order) for ALL the stores issued before it
   double* s_mu = s_fa + 4 * KS * 65;
   if (mu_lds)
-    for (int j = tid; j < Lg; j += 512) s_mu[j] = E.mean[j];
+    for (int j = tid; j < Lg; j += 512) s_mu[j] = meang[j];
   double pf[PF];
   // element e = tid + 512 * u of the [4 KS][64] chunk: row kk = e >> 6, column jj = e & 63 (zero beyond the rank)
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int e = tid + 512 * u;
     const int kk = e >> 6, j = e & 63;
-    pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
+    pf[u] = (kk < rows && j < Lg) ? Ag[(size_t)kk * Lg + j] : 0.0;
   }
   for (int j0 = 0; j0 < Lg; j0 += 64) {
     __syncthreads();  // previous tile's LDS reads are done
@@ -3088,11 +3104,34 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
       for (int u = 0; u < PF; ++u) {
         const int e = tid + 512 * u;
         const int kk = e >> 6, j = j0 + 64 + (e & 63);
-        pf[u] = (kk < rows && j < Lg) ? E.A[(size_t)kk * Lg + j] : 0.0;
+        pf[u] = (kk < rows && j < Lg) ? Ag[(size_t)kk * Lg + j] : 0.0;
       }
     }
     // one 16-column group at a time: its 4 stores go out while the matrix pipe works on the next group (and the
     // accumulators take 8 registers instead of 32)
+#if defined(GPET_GEMM_EXP) && GPET_GEMM_EXP == 2  // experiment: two column groups at a time (two independent accumulator chains)
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      if (j0 + 32 * tp >= Lg) continue;
+      v4f64 acc0 = (v4f64){0.0, 0.0, 0.0, 0.0}, acc1 = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 32 * tp], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 32 * tp + 16], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = j0 + 32 * tp + 16 * h + li;
+        if (j >= Lg) continue;
+        const double mu = mu_lds ? s_mu[j] : meang[j];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int sidx = s0 + 16 * w + lq + 4 * g;
+          if (sidx < S) Yo[(size_t)sidx * Lg + j] = (yt)(((h ? acc1[g] : acc0[g]) + mu) * y_s);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (j0 + 16 * t >= Lg) continue;  // (an empty group: uniform over the workgroup)
@@ -3102,7 +3141,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 16 * t], acc, 0, 0, 0);
       const int j = j0 + 16 * t + li;
       if (j >= Lg) continue;
-      const double mu = mu_lds ? s_mu[j] : E.mean[j];
+      const double mu = mu_lds ? s_mu[j] : meang[j];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int sidx = s0 + 16 * w + lq + 4 * g;
@@ -3113,6 +3152,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 #endif
       }
     }
+#endif
   }
 }
 
