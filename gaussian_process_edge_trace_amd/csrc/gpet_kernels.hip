@@ -3418,7 +3418,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   for (int e = tid; e < ncol * M; e += SC_THREADS) {
     const int y = e / ncol, c = e - y * ncol;
     const int x = c0 + c;
-    s_img[c * ldm + y] = (x < N) ? E.grad[(size_t)y * N + x] : 0.f;
+    s_img[c * ldm + y] = (x < N) ? as_global(E.grad)[(size_t)y * N + x] : 0.f;
   }
   __syncthreads();
   const int pl = tid & 15;  // pair within the tile
@@ -3426,13 +3426,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const int k = 2 * i;
   const int s_lo = byy * SC_CURVES;
   const int s_hi = (s_lo + SC_CURVES < S) ? (s_lo + SC_CURVES) : S;
-  double* __restrict__ cpart = E.cost_part + ((size_t)bx * S) * 2;
+  GPET_GLOBAL double* __restrict__ cpart = as_global(E.cost_part) + ((size_t)bx * S) * 2;
   // the samples of the NEXT group of curves are requested before this group is worked on: the loop is bound by the
   // latency of these loads (8 waves per SIMD do not cover an HBM round trip per 600 cycles of work on their own)
   const bool edge_lane = (pl == 15);  // its successor pair belongs to the next tile
   auto fetch = [&](int s0, double& a0, double& a1, double& a2, double& a3) {
     const int s = s0 + (tid >> 4);
-    const yt* __restrict__ row = reinterpret_cast<const yt*>(E.Y) + (size_t)(s < s_hi ? s : s_lo) * Lg;
+    const GPET_GLOBAL yt* __restrict__ row = as_global(reinterpret_cast<const yt*>(E.Y)) + (size_t)(s < s_hi ? s : s_lo) * Lg;
     a0 = a1 = a2 = a3 = 0.0;
     if (k + 1 < Lg) {
       a0 = (double)row[k];
