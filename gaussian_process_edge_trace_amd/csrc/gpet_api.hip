@@ -207,7 +207,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
   E.Y = cv.take<double>(S * Lg);
   E.costs = cv.take<double>(S);
-  E.cost_part = cv.take<double>(S * 2 * (Lg / 32 + 2));
+  E.cost_part = cv.take<double>(S * 2 * (Lg / 30 + 2));  // (15 Simpson pairs = 30 columns per tile of the scorer)
   E.best_costs = cv.take<double>((size_t)E.n_keep + 1);
   E.best_idx = cv.take<int>((size_t)E.n_keep + 1);
   E.bins = cv.take<double>(gpx);

@@ -3355,13 +3355,13 @@ __global__ void __launch_bounds__(256) k_score(EdgeDev* edges) {
   }
 }
 
-// a7, tiled variant (M <= 1100): a workgroup owns 16 Simpson pairs (33 image columns) of up to 512
-// curves.  The 33 x M slab of the gradient image is staged in LDS (column-major, odd stride), so the
+// a7, tiled variant (M <= 1100): a workgroup owns 15 Simpson pairs (32 image columns with the next pair's first) of up to 1024
+// curves.  The 32 x M slab of the gradient image is staged in LDS (column-major, odd stride), so the
 // 4-tap bilinear gathers -- the L1/TA-bound part of the wave-per-curve kernel -- become LDS reads.
 // 16 consecutive lanes share a curve: one coalesced 256-byte read of its samples, successor data
 // by shuffle inside the group, group reduction by shuffle, and one (arc, integral) partial per
 // (tile, curve); k_score_combine adds the partials in tile order (deterministic) and divides.
-#define SC_PAIRS 16
+#define SC_PAIRS 15  // Simpson pairs per tile: lanes 0..14 of a 16-lane row; lane 15 only supplies the next pair's data
 #define SC_CURVES 1024
 #define SC_THREADS 1024
 // cross-lane moves of a double inside rows of 16 lanes by DPP (two v_mov_b32_dpp; __shfl_xor / __shfl_down with width 16
@@ -3406,13 +3406,13 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  extern __shared__ float s_img[];  // [2*SC_PAIRS + 1][ldm]
+  extern __shared__ float s_img[];  // [2 * SC_PAIRS + 2][ldm]
   const int M = E.M, N = E.N, Lg = E.Lg, S = E.S;
   const int npair = (Lg - 2) / 2;
   const int p0 = bx * SC_PAIRS;
   if (p0 >= npair) return;
   const int c0 = E.x_st + 2 * p0;   // first image column of the slab
-  const int ncol = 2 * SC_PAIRS + 1;
+  const int ncol = 2 * SC_PAIRS + 2;
   const int ldm = M | 1;
   const int tid = threadIdx.x;
   for (int e = tid; e < ncol * M; e += SC_THREADS) {
@@ -3421,7 +3421,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     s_img[c * ldm + y] = (x < N) ? as_global(E.grad)[(size_t)y * N + x] : 0.f;
   }
   __syncthreads();
-  const int pl = tid & 15;  // pair within the tile
+  const int pl = tid & 15;  // pair within the tile (15: the first pair of the next tile, as a source of data only)
   const int i = p0 + pl;
   const int k = 2 * i;
   const int s_lo = byy * SC_CURVES;
@@ -3429,27 +3429,25 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   GPET_GLOBAL double* __restrict__ cpart = as_global(E.cost_part) + ((size_t)bx * S) * 2;
   // the samples of the NEXT group of curves are requested before this group is worked on: the loop is bound by the
   // latency of these loads (8 waves per SIMD do not cover an HBM round trip per 600 cycles of work on their own)
-  const bool edge_lane = (pl == 15);  // its successor pair belongs to the next tile
-  auto fetch = [&](int s0, double& a0, double& a1, double& a2, double& a3) {
+  // (Round 2 had 16 pairs per tile and let lane 15 fetch and evaluate its successor itself: a divergent path of ~40
+  //  instructions that every wave executed for one lane in sixteen -- a fifth of the loop.  A sixteenth lane that computes
+  //  the next pair's first point like everybody else costs 1/15 more lanes and no extra path.)
+  auto fetch = [&](int s0, double& a0, double& a1) {
     const int s = s0 + (tid >> 4);
     const GPET_GLOBAL yt* __restrict__ row = as_global(reinterpret_cast<const yt*>(E.Y)) + (size_t)(s < s_hi ? s : s_lo) * Lg;
-    a0 = a1 = a2 = a3 = 0.0;
+    a0 = a1 = 0.0;
     if (k + 1 < Lg) {
       a0 = (double)row[k];
       a1 = (double)row[k + 1];
     }
-    if (edge_lane && i < npair) {
-      a2 = (double)row[k + 2];
-      a3 = (double)row[k + 3];
-    }
   };
-  double y0, y1, ye2, ye3;
-  fetch(s_lo, y0, y1, ye2, ye3);
+  double y0, y1;
+  fetch(s_lo, y0, y1);
   for (int s0 = s_lo; s0 < s_hi; s0 += SC_THREADS / 16) {
     const int s = s0 + (tid >> 4);
     const bool live = s < s_hi;
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-    if (s0 + SC_THREADS / 16 < s_hi) fetch(s0 + SC_THREADS / 16, n0, n1, n2, n3);
+    double n0 = 0.0, n1 = 0.0;
+    if (s0 + SC_THREADS / 16 < s_hi) fetch(s0 + SC_THREADS / 16, n0, n1);
     const double d0 = y1 - y0;
     const double q0 = 1.0 + d0 * d0;
     const double r0 = rsqrt(q0), l0 = q0 * r0;
@@ -3458,15 +3456,7 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     double y2 = dpp_row<0x101>(y0), l2 = dpp_row<0x101>(l0), r2 = dpp_row<0x101>(r0);  // row_shl:1: the pair above
     double g2 = dpp_row<0x101>(g0);
     double al = 0.0, li = 0.0;
-    if (i < npair) {
-      if (edge_lane) {
-        y2 = ye2;
-        const double d2 = ye3 - y2;
-        const double q2 = 1.0 + d2 * d2;
-        r2 = rsqrt(q2);
-        l2 = q2 * r2;
-        g2 = grad_lds(s_img + (2 * pl + 2) * ldm, M, y2) + 1e-3;
-      }
+    if (pl < SC_PAIRS && i < npair) {
       const double d1 = y2 - y1;
       const double q1 = 1.0 + d1 * d1;
       const double r1 = rsqrt(q1), l1 = q1 * r1;
@@ -3483,8 +3473,6 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     }
     y0 = n0;
     y1 = n1;
-    ye2 = n2;
-    ye3 = n3;
   }
 }
 
@@ -6002,7 +5990,7 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, unsigned parts) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
   if (parts & 1u) {
-    const size_t lds = (size_t)(2 * SC_PAIRS + 1) * (bd.M | 1) * sizeof(float);
+    const size_t lds = (size_t)(2 * SC_PAIRS + 2) * (bd.M | 1) * sizeof(float);
     if (lds <= 150 * 1024 && B * 1 > 0 && bd.S >= 64) {
       static PerDeviceOnce once;
       if (once.first())
