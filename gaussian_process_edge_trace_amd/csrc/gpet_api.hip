@@ -623,6 +623,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     // instead of 16 -- at 1024 edges of the bench shape 2.4 GB instead of 9.4 GB of an 18 GB arena.  Full-stream mode
     // (z_cols == Lg: full-rank covariances, tests) holds whole 8 MB streams per slot: 2.
     E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 4);
+    if (getenv("GPET_Z_RING") && atoi(getenv("GPET_Z_RING")) >= 2 && atoi(getenv("GPET_Z_RING")) <= 16) E.z_ring = atoi(getenv("GPET_Z_RING"));  // (experiments)
     // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
     // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
     E.jlog_cap = (B <= 16 && E.r_cap <= 96) ? 40 : 0;
@@ -1813,7 +1814,14 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     for (int it = 0; it < n_it; ++it) {
       // every kernel skips edges whose `done` flag is set, so edges that finish inside a group cost little.
       const int cur = first + it;
-      if (deep && b->norm_issued - cur <= look / 2) {
+      static const int rng_inline = getenv("GPET_RNG_INLINE") ? atoi(getenv("GPET_RNG_INLINE")) : 0;
+      if (rng_inline) {  // experiment: the normals of this iteration on the loop's own stream, overlapping nothing
+        int rcn = normals_auto(b, c->stream, edges_l, B_l, seeds_l, 1, cur, 1, loop_z_store(b));
+        if (rcn) return rcn;
+        HIPCHK(c, hipEventRecord(b->ev_norm[cur % 16], c->stream));
+        b->norm_issued = cur + 1;
+      }
+      if (!rng_inline && deep && b->norm_issued - cur <= look / 2) {
         // small batch: the streams of the next `n` iterations in ONE launch (blockIdx.x = iteration), side by side.
         // Their ring slots were last read by the sample GEMMs of iterations <= cur - 1 (outstanding + n <= ring).
         const int j = b->norm_issued;
@@ -1827,7 +1835,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
         b->norm_issued = j + n;
       }
-      while (!deep && b->norm_issued <= cur + look && b->norm_issued < horizon) {
+      while (!rng_inline && !deep && b->norm_issued <= cur + look && b->norm_issued < horizon) {
         const int j = b->norm_issued;
         if (look == 0) {
           if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));
