@@ -13,7 +13,8 @@ struct EigState {
   unsigned long long maxrel_bits;  // bits of the largest squared relative row coupling met in the current sweep
   int stopped, rank;               // pivoted Cholesky finished; rows of G
   int converged, sweeps;           // Jacobi: every pair orthogonal to the tolerance; sweeps done
-  int cand_half, pad;              // blocked pivoting: which half of pcx_cand holds the latest candidates
+  int cand_half;                   // blocked pivoting: which half of pcx_cand holds the latest candidates
+  unsigned int bar;                // arrivals at the barrier of the persistent Jacobi kernel (k_oj_persist), monotonic
   int t_slot[2], stop_slot[2];     // blocked pivoting: rows so far / finished, as block (blk & 1) must see them -- a block
                                    // writes the OTHER slot, so workgroups of one launch never read what it writes
 };

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) k_pcx_init(EdgeDev* edges, int nw_max) {
     st->maxrel_bits = 0ull;
     st->converged = 0;
     st->sweeps = 0;
+    st->bar = 0u;
   }
   if (j0 >= Lg) return;
   const int lane = tid & 63, w = tid >> 6;
@@ -484,6 +485,7 @@ __global__ void __launch_bounds__(64) k_pcb_init(EdgeDev* edges, int nw_max) {
     st->maxrel_bits = 0ull;
     st->converged = 0;
     st->sweeps = 0;
+    st->bar = 0u;
     st->cand_half = 0;
     st->t_slot[0] = 0;
     st->stop_slot[0] = 0;
@@ -858,6 +860,206 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
   }
 }
 
+// ---- the rounds and sweeps of one factorisation in ONE launch (batches whose pair-workgroups are all resident) ---------
+// A round launch costs ~25 us of which ~12 are the round: the rest is start, drain and cold state.
+// Here the workgroup of pair slot k loops over the rounds and sweeps itself; between rounds the workgroups OF ONE EDGE
+// meet at a barrier in global memory (arrival counter in the edge's EigState, monotonic: target = workgroups x barriers
+// so far).  The rows a workgroup needs next were written by two other workgroups, possibly on another XCD whose L2 is
+// not coherent with this one: the rows are therefore read and written with agent-scope accesses (sc1: write-through to
+// and read from the level all XCDs share) instead of a cache-wide write-back + invalidate at every barrier (a
+// __threadfence() per barrier, what a cooperative grid sync does, made a round 29 us: slower than a launch).  The waiting thread gives up after
+// ~1 s (a workgroup that never became resident: more workgroups than the GPU holds) and fails the edge instead of
+// hanging the device.  Same pairs, same rotations, same arithmetic as k_oj_round<STAGED>: bit-identical rows.
+__device__ __forceinline__ bool oj_edge_barrier(unsigned int* ctr, unsigned int target, int* s_flag) {
+  __syncthreads();  // (every wave's stores are out: hipcc's barrier waits for vmcnt(0))
+  if (threadIdx.x == 0) {
+    atomicAdd(ctr, 1u);
+    int ok = 1;
+    long long spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1ll << 23)) {
+        ok = 0;
+        break;
+      }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+template <bool ARGS>
+__global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges, int nblk, int max_sweeps, double tol2) {
+  OjEdge D;
+  if (ARGS) {
+    D = args.e[blockIdx.y];
+  } else {
+    const EdgeDev& Et = edges[blockIdx.y];
+    D.G = Et.G;
+    D.st = Et.eig;
+    D.sc = Et.sc;
+    D.Lg = Et.Lg;
+    D.r_cap = Et.r_cap;
+    D.injected = Et.factor_injected;
+  }
+  EigState* st = D.st;
+  // (the same for every workgroup of the edge: they leave together or stay together)
+  if ((D.sc->done && !D.sc->force) || D.sc->status != GPET_OK || D.injected || st->converged) return;
+  const int rank = st->rank, Lg = D.Lg;
+  extern __shared__ double s_X[];  // [16][ldx]
+  __shared__ double s_part[4][OJ_M][OJ_M + 1];
+  __shared__ double s_C[OJ_M][OJ_M + 1];
+  __shared__ double s_R[OJ_M][OJ_M + 1];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int nch = (Lg + 15) >> 4;
+  const int ldx = ((Lg + 31) & ~31) + 2;
+  const int kmax = nch * 16;
+  const unsigned int nwg = gridDim.x;
+  unsigned int nbar = 0;
+#ifdef GPET_OJ_PROF
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+#define OJ_T(i) { const long long t_ = clock64(); pt[i] += t_ - tl; tl = t_; }
+  long long tl = clock64();
+#else
+#define OJ_T(i)
+#endif
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    for (int round = 0; round < nblk - 1; ++round) {
+      int bI, bJ;
+      oj_rr_pair(nblk - 1, round, blockIdx.x, bI, bJ);
+      if (bI * OJ_B < rank) {  // (bI < bJ: otherwise both blocks are empty)
+        // -- stage: thread t takes columns t, t + 256, ... of every row
+        {
+          double v[16][4];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int gi = oj_row(bI, bJ, r);
+            const bool live = gi < rank;
+            gi = gi < D.r_cap ? gi : D.r_cap - 1;
+            const double* __restrict__ xrow = D.G + (size_t)gi * Lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = tid + 256 * i;
+              v[r][i] = (live && k < Lg) ? __hip_atomic_load(xrow + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = tid + 256 * i;
+              if (k < kmax) s_X[r * ldx + k] = v[r][i];
+            }
+        }
+        __syncthreads();
+        OJ_T(0)
+        // -- Gram matrix
+        {
+          v4f64e acc[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[jj] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+          const double* xr = s_X + lr * ldx + lg;
+          for (int ch0 = w; ch0 < nch; ch0 += 16) {
+            double x[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < nch) ? xr[(ch0 + 4 * u) * 16 + 4 * jj] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][jj], x[u][jj], acc[jj], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s_part[w][lg + 4 * i][lr] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        }
+        {
+          const int i = tid >> 4, j = tid & 15;
+          s_R[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        {
+          const int i = tid >> 4, j = tid & 15;
+          s_C[i][j] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);
+        }
+        __syncthreads();
+        OJ_T(1)
+        if (w == 0) oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+        __syncthreads();
+        OJ_T(2)
+        // -- rows <- R^T rows
+        {
+          double ra[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_krow(jj, lg)][lr];
+          double* xo[4];
+          bool vo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ga = oj_row(bI, bJ, lg + 4 * i);
+            vo[i] = ga < rank;
+            xo[i] = D.G + (size_t)ga * Lg;
+          }
+          const double* xs[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) xs[jj] = s_X + oj_krow(jj, lg) * ldx + lr;
+          for (int ct0 = w; ct0 < nch; ct0 += 16) {
+            double xv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) xv[u][jj] = (ct0 + 4 * u < nch) ? xs[jj][(ct0 + 4 * u) * 16] : 0.0;
+            v4f64e acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv[u][jj], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int c = (ct0 + 4 * u) * 16 + lr;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (vo[i] && ct0 + 4 * u < nch && c < Lg) __hip_atomic_store(xo[i] + c, acc[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      }
+      OJ_T(3)
+      if (!oj_edge_barrier(&st->bar, nwg * ++nbar, &s_flag)) {
+        if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
+        return;
+      }
+      OJ_T(4)
+    }
+    // the sweep's verdict (k_oj_check): one thread of the edge decides, everybody reads it after one more barrier
+    if (blockIdx.x == 0 && tid == 0) {
+      const unsigned long long bits = __hip_atomic_load(&st->maxrel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double mr2 = __longlong_as_double((long long)bits);
+      const int sw = st->sweeps + 1;
+      st->sweeps = sw;
+      const_cast<gpet_scalars*>(D.sc)->lml = (double)sw;
+      __hip_atomic_store(&st->maxrel_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&st->converged, mr2 <= tol2 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!oj_edge_barrier(&st->bar, nwg * ++nbar, &s_flag)) {
+      if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
+      return;
+    }
+    if (__hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+  }
+#ifdef GPET_OJ_PROF
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37) && blockIdx.y == 0 && nbar > 0)
+    printf("oj persist wg %d: per barrier: stage %lld | gram %lld | inner sweep %lld | update + stores %lld | barrier %lld cycles (%u barriers)\n", (int)blockIdx.x,
+           pt[0] / nbar, pt[1] / nbar, pt[2] / nbar, pt[3] / nbar, pt[4] / nbar, nbar);
+#endif
+#undef OJ_T
+}
+
 // after every sweep: converged when the largest relative coupling met during it was below the tolerance (the
 // rotations of that sweep then took it to ~its square)
 __global__ void __launch_bounds__(64) k_oj_check(EdgeDev* edges, double tol2) {
@@ -997,6 +1199,21 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     }
   }
   const double tol2 = pow(10.0, -2.0 * (double)gpet_opt_oj_tol_exp());
+  // staged AND every pair-workgroup of the batch resident at once (one per CU: 131 KB of LDS each): the rounds and sweeps in
+  // one launch, the workgroups of an edge meeting at a barrier in global memory (k_oj_persist); GPET_OJ_PERSIST=0: launches
+  static const int oj_persist = getenv("GPET_OJ_PERSIST") ? atoi(getenv("GPET_OJ_PERSIST")) : 1;
+  if (staged && oj_persist && (long long)(nblk / 2) * B <= 240) {
+    static int attr_done2[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_done2[dev]) {
+      (void)hipFuncSetAttribute((const void*)k_oj_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_oj_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      attr_done2[dev] = 1;
+    }
+    if (use_args) hipLaunchKernelGGL((k_oj_persist<true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
+    else hipLaunchKernelGGL((k_oj_persist<false>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
+  } else
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int round = 0; round < nblk - 1; ++round) {
       if (staged && use_args)
