@@ -3042,6 +3042,12 @@ __global__ void __launch_bounds__(256) k_sample_gemm_mfma(EdgeDev* edges) {
 // instruction).  Measured slower or equal, and dropped: streaming (nontemporal) stores (+35 %), the chunk by LDS-DMA
 // with four 4-wave workgroups per CU (+8 %), a half-tile phase offset between the workgroups of a CU (+-0).
 #define GEMM_KMAX 96
+// row stride of the factor chunk in LDS (doubles): the operand read of a matrix instruction takes 16 consecutive columns of
+// FOUR rows (k = 4 q + lq); with 80 (= 32 dwords mod 64) the rows of each half-wave fall on disjoint bank halves -- 65 put
+// rows 2 banks apart and every read was a 2-way conflict
+#ifndef GEMM_LDA
+#define GEMM_LDA 80
+#endif
 #define GEMM_LDS_MAX (150 * 1024)
 // A pointer the compiler knows to be GLOBAL memory.  The buffers of an edge are pointers read from its EdgeDev record, which the
 // compiler can only treat as generic: every access becomes a FLAT instruction, and a FLAT instruction counts in BOTH wait
@@ -3080,7 +3086,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
   const double y_s = sc->y_s;
   // the posterior mean sits in LDS behind the chunk: a global load in the epilogue would make every 16-column group
   // wait (vmcnt counts in order) for ALL the stores issued before it
-  double* s_mu = s_fa + 4 * KS * 65;
+  double* s_mu = s_fa + 4 * KS * GEMM_LDA;
   if (mu_lds)
     for (int j = tid; j < Lg; j += 512) s_mu[j] = meang[j];
   double pf[PF];
@@ -3096,7 +3102,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int e = tid + 512 * u;
-      s_fa[(e >> 6) * 65 + (e & 63)] = pf[u];
+      s_fa[(e >> 6) * GEMM_LDA + (e & 63)] = pf[u];
     }
     __syncthreads();
     if (j0 + 64 < Lg) {  // next tile's chunk: loads stay in flight during the MFMAs below
@@ -3116,8 +3122,8 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
       v4f64 acc0 = (v4f64){0.0, 0.0, 0.0, 0.0}, acc1 = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < KS; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 32 * tp], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 32 * tp + 16], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * GEMM_LDA + li + 32 * tp], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * GEMM_LDA + li + 32 * tp + 16], acc1, 0, 0, 0);
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -3138,7 +3144,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
       v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < KS; ++q)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * 65 + li + 16 * t], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * GEMM_LDA + li + 16 * t], acc, 0, 0, 0);
       const int j = j0 + 16 * t + li;
       if (j >= Lg) continue;
       const double mu = mu_lds ? s_mu[j] : meang[j];
@@ -3167,7 +3173,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
-  extern __shared__ double s_fa[];  // [4 KS][65]
+  extern __shared__ double s_fa[];  // [4 KS][GEMM_LDA]
   sample_gemm_body<KS, F32>(E, sc, s_fa, part, mu_in_lds != 0);
 }
 template <int KS, bool F32>
@@ -5967,10 +5973,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
       }
     }
     // (an edge too wide for its posterior mean to sit behind the chunk reads it from global memory in the epilogue)
-    const int mu_in_lds = ((size_t)4 * 24 * 65 + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
+    const int mu_in_lds = ((size_t)4 * 24 * GEMM_LDA + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
 #define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
   do {                                                                                                                                 \
-    const size_t lds_ = ((size_t)4 * KS_ * 65 + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
+    const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
     if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true>), grid, block, lds_, st, d_edges, mu_in_lds);                                 \
     else hipLaunchKernelGGL((KERNEL<KS_, false>), grid, block, lds_, st, d_edges, mu_in_lds);                                         \
   } while (0)
