@@ -471,11 +471,13 @@ def main():
     tracer._batch.iterate(seeds, 7)
     sc_mid = tracer._batch.scalars(0)
     n_mid, rank_mid, sweeps_mid = sc_mid.n, sc_mid.rank, max(1, int(sc_mid.lml))
-    ring = 16  # the normals stage fills a ring of 16 upcoming iterations per launch: report per iteration
-    def per_iter(d):
-        d["normals"] = d["normals"] / ring
+    # the normals stage fills the batch's whole ring of upcoming iterations per launch (gpet_batch_info: 4 slots at 1024
+    # edges, 16 up to 64 edges): report per iteration
+    ring = int(tracer._batch.info().get("z_ring", 16))
+    def per_iter(d, ring_):
+        d["normals"] = d["normals"] / ring_
         return d
-    stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
+    stage_ms = per_iter({name: tracer._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}, ring)
     info0 = tracer._batch.info()
     structured = bool(info0.get("structured", 0))
     kernel_ids = dict(KERNEL_IDS_STRUCT if structured else KERNEL_IDS_GENERIC)
@@ -486,7 +488,7 @@ def main():
     one(); one.reset()
     ts = time.time(); one(); single_s = time.time() - ts
     one.reset(); one._batch.iterate([1], 7)
-    one_ms = per_iter({name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)})
+    one_ms = per_iter({name: one._batch.profile_stage(i, 20) for i, name in enumerate(STAGES)}, int(one._batch.info().get("z_ring", 16)))
 
     # ---- roofline of the dominant kernel: algorithmic bytes / flops per edge per launch
     S, Lg, M_ = README_KW["N_samples"], N, N
@@ -515,7 +517,11 @@ def main():
     # (a structured batch stores only the r0 leading normals of a row, rounded up to 4: its factors have no more rows)
     zc = ((info0["r0"] + 3) & ~3) if structured and info0.get("r0", 0) > 0 else info0["z_cols"]
     kernel_ms["k_mt_normals"] = stage_ms["normals"] * ring
-    alg["k_mt_normals"] = dict(flops=40.0 * S * zc * ring, bytes=8.0 * S * zc * ring)
+    # algorithmic work of the generator: numpy's stream must be WALKED (every polar attempt decided) although only zc of Lg
+    # columns are stored: S Lg / 2 accepted pairs at an acceptance of pi / 4, four MT19937 words per attempt, ~15 32-bit vector
+    # operations per word (twist 7, tempering of the two words the accept test needs 5, the test itself 3); bytes = what it stores
+    mt_words = 4.0 * (S * Lg / 2.0) / (np.pi / 4.0)
+    alg["k_mt_normals"] = dict(flops=15.0 * mt_words * ring, bytes=8.0 * S * zc * ring)
     per_iter = {k: (v / ring if k == "k_mt_normals" else v) for k, v in kernel_ms.items()}
     # dominant kernel of a step = largest device time per step of E traces, kernels timed alone: a loop kernel runs
     # once per iteration of the trace, the LML kernel of the converged fits ~80 times per step (one launch per
@@ -541,10 +547,15 @@ def main():
         prof = json.load(open(tp))
         if prof.get("edges") == E and prof.get("image") == [N, N] and dom in prof.get("kernels", {}):
             traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
-    roofline = dict(kernel=dom, bound="mfma" if use_flops else "hbm",
-                    achieved=tfl if use_flops else gbs, peak=FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS,
-                    unit="TFLOP/s" if use_flops else "GB/s",
-                    frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
+    # the generator is neither HBM- nor MFMA-shaped: integer work on the vector ALUs (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
+    VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+    is_valu = dom == "k_mt_normals"
+    roofline = dict(kernel=dom, bound="valu" if is_valu else ("mfma" if use_flops else "hbm"),
+                    achieved=tfl if (use_flops or is_valu) else gbs,
+                    peak=VALU_PEAK_TOPS if is_valu else (FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS),
+                    unit="Top/s (32-bit vector operations)" if is_valu else ("TFLOP/s" if use_flops else "GB/s"),
+                    frac=(tfl / VALU_PEAK_TOPS) if is_valu else ((tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS)),
+                    traffic=traffic, hbm_algorithmic_GBps=gbs,
                     launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
                     launches_per_step=(lml["launches"] if dom == "k_lml" else iters_per_trace),
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
@@ -552,10 +563,15 @@ def main():
                           "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_seat" else
                           ("bound by the samples it stores (8 S Lg bytes per edge: 2.7-2.85 TB/s is what a store-only kernel of this "
                            "shape reaches, tools/ubench/gemm_pipe.hip), see DESIGN.md section 6" if dom == "k_sample_gemm_mfma_r" else
+                          ("numpy's RandomState(seed).standard_normal stream, bit for bit: MT19937 + polar method, every attempt of the "
+                           "S x Lg stream decided, zc of Lg columns stored; vector-ALU bound (integer), not HBM or MFMA: "
+                           "DESIGN.md section 6b; the sample GEMM (next in device time) is at %.2f of the f64 MFMA peak"
+                           % (alg["k_sample_gemm_mfma_r"]["flops"] * E / (kernel_ms["k_sample_gemm_mfma_r"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+                           if dom == "k_mt_normals" else
                           ("objective of the converged fits: %d evaluations of ~%.0f-point problems in %d launches per step; "
                            "f64 peak (vector = matrix on MI355X); k_lml16: block-4 sweep on v_mfma_f64_16x16x4, two waves per problem -- MFMA "
                            "cycles and VALU issue share the vector unit's FMA lanes, DESIGN.md section 6b"
-                           % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None))),
+                           % (lml["evaluations"], n_fit, lml["launches"]) if dom == "k_lml" else None)))),
                     state=dict(n_train=n_mid, factor_rank=rank_mid, jacobi_sweeps=sweeps_mid,
                                loop_path="structured" if structured else "generic", iterations_per_trace=iters_per_trace,
                                n_train_final_fit=n_fit),

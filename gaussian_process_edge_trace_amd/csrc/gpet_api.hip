@@ -1815,11 +1815,20 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       // every kernel skips edges whose `done` flag is set, so edges that finish inside a group cost little.
       const int cur = first + it;
       static const int rng_inline = getenv("GPET_RNG_INLINE") ? atoi(getenv("GPET_RNG_INLINE")) : 0;
-      if (rng_inline) {  // experiment: the normals of this iteration on the loop's own stream, overlapping nothing
+      if (rng_inline == 1) {  // experiment: the normals of this iteration on the loop's own stream, overlapping nothing
         int rcn = normals_auto(b, c->stream, edges_l, B_l, seeds_l, 1, cur, 1, loop_z_store(b));
         if (rcn) return rcn;
         HIPCHK(c, hipEventRecord(b->ev_norm[cur % 16], c->stream));
         b->norm_issued = cur + 1;
+      } else if (rng_inline == 2 && b->norm_issued <= cur) {
+        // experiment: the streams of ALL the iterations of this group (up to ring - 1) in one launch on the loop's own stream:
+        // nothing beside it, and enough workgroups to fill the GPU
+        int n = horizon - cur;
+        if (n > ring - 1) n = ring - 1;
+        int rcn = normals_auto(b, c->stream, edges_l, B_l, seeds_l, 1, cur, n, loop_z_store(b));
+        if (rcn) return rcn;
+        for (int q = cur; q < cur + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], c->stream));
+        b->norm_issued = cur + n;
       }
       if (!rng_inline && deep && b->norm_issued - cur <= look / 2) {
         // small batch: the streams of the next `n` iterations in ONE launch (blockIdx.x = iteration), side by side.
@@ -1835,7 +1844,9 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
         b->norm_issued = j + n;
       }
-      while (!rng_inline && !deep && b->norm_issued <= cur + look && b->norm_issued < horizon) {
+      static const int rng_after_gemm = getenv("GPET_RNG_AFTER_GEMM") ? atoi(getenv("GPET_RNG_AFTER_GEMM")) : 0;
+      const int look_now = (rng_after_gemm && !deep) ? 0 : look;  // (this iteration's own stream only, if it is not there yet)
+      while (!rng_inline && !deep && b->norm_issued <= cur + look_now && b->norm_issued < horizon) {
         const int j = b->norm_issued;
         if (look == 0) {
           if (j - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_pix[(j - 1) % 16], 0));
@@ -1858,6 +1869,15 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
       HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, b->structured ? b->bd.r0_max : 0));
       HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
+      if (rng_after_gemm && !rng_inline && !deep && b->norm_issued == cur + 1 && cur + 1 < horizon) {
+        // the next iteration's stream starts when this iteration's GEMM is through: it then runs beside the scorer and the
+        // KDE instead of beside the eigen-solver and the GEMM, whose speed hangs on two workgroups per CU
+        HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[cur % 16], 0));
+        int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, cur + 1, 1, loop_z_store(b));
+        if (rcn) return rcn;
+        HIPCHK(c, hipEventRecord(b->ev_norm[(cur + 1) % 16], b->side));
+        b->norm_issued = cur + 2;
+      }
       HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
       // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
       HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
