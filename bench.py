@@ -550,12 +550,15 @@ def main():
     # the generator is neither HBM- nor MFMA-shaped: integer work on the vector ALUs (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
     VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
     is_valu = dom == "k_mt_normals"
-    roofline = dict(kernel=dom, bound="valu" if is_valu else ("mfma" if use_flops else "hbm"),
-                    achieved=tfl if (use_flops or is_valu) else gbs,
-                    peak=VALU_PEAK_TOPS if is_valu else (FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS),
-                    unit="Top/s (32-bit vector operations)" if is_valu else ("TFLOP/s" if use_flops else "GB/s"),
-                    frac=(tfl / VALU_PEAK_TOPS) if is_valu else ((tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS)),
-                    traffic=traffic, hbm_algorithmic_GBps=gbs,
+    if is_valu:
+        use_flops = False  # (the contract's two roofs: of them HBM -- the bytes it must store -- is the one that applies)
+    roofline = dict(kernel=dom, bound="mfma" if use_flops else "hbm",
+                    achieved=tfl if use_flops else gbs, peak=FP64_PEAK_TFLOPS if use_flops else HBM_PEAK_GBS,
+                    unit="TFLOP/s" if use_flops else "GB/s",
+                    frac=(tfl / FP64_PEAK_TFLOPS) if use_flops else (gbs / HBM_PEAK_GBS), traffic=traffic,
+                    valu=(dict(achieved=tfl, peak=VALU_PEAK_TOPS, unit="Top/s (32-bit vector operations)", frac=tfl / VALU_PEAK_TOPS,
+                               note="the roof that binds this kernel: integer work on the vector ALUs, ~15 operations per MT19937 "
+                                    "word of the stream it has to walk") if is_valu else None),
                     launch_ms=d_ms, edges_per_launch=E, algorithmic_bytes=a_bytes, algorithmic_flops=a_flops,
                     launches_per_step=(lml["launches"] if dom == "k_lml" else iters_per_trace),
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
@@ -564,7 +567,7 @@ def main():
                           ("bound by the samples it stores (8 S Lg bytes per edge: 2.7-2.85 TB/s is what a store-only kernel of this "
                            "shape reaches, tools/ubench/gemm_pipe.hip), see DESIGN.md section 6" if dom == "k_sample_gemm_mfma_r" else
                           ("numpy's RandomState(seed).standard_normal stream, bit for bit: MT19937 + polar method, every attempt of the "
-                           "S x Lg stream decided, zc of Lg columns stored; vector-ALU bound (integer), not HBM or MFMA: "
+                           "S x Lg stream decided, zc of Lg columns stored; vector-ALU bound (integer; the `valu` entry), not HBM or MFMA: "
                            "DESIGN.md section 6b; the sample GEMM (next in device time) is at %.2f of the f64 MFMA peak"
                            % (alg["k_sample_gemm_mfma_r"]["flops"] * E / (kernel_ms["k_sample_gemm_mfma_r"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
                            if dom == "k_mt_normals" else

@@ -2557,10 +2557,14 @@ struct MtjWork {
 // CHUNKED = true: blockIdx = (chunk, iterations ahead, edge): the workgroup starts from the state of its chunk (k_mtj_*
 // below found it by jumping ahead) at the stream position the chunks before it have filled, and stops after MTJ_CB
 // blocks -- except the last chunk, which runs until the stream is complete (the chunk count is an estimate).
-template <bool CHUNKED>
-__global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
-                                                    int iter_abs, int z_store, MtjWork wk) {
+// NW = waves per workgroup: 4 (round 1-2: 227 lanes twist in three single passes, the fourth wave drains the queue during
+// the attempts) or 3: the twist's first two phases then take two passes on wave 0 only (lanes 192..226 of a phase), the
+// last wave makes its 28 attempts and drains the queue afterwards -- fewer waves executing each block's instructions.
+template <bool CHUNKED, int NW>
+__global__ void __launch_bounds__(64 * NW) k_mt_normals(EdgeDev* edges, const unsigned int* seeds, int add_iter,
+                                                       int iter_abs, int z_store, MtjWork wk) {
 #pragma clang fp contract(off)
+  constexpr int NT = 64 * NW;
   const int e_idx = CHUNKED ? (int)blockIdx.z : (int)blockIdx.y, ahead = CHUNKED ? (int)blockIdx.y : (int)blockIdx.x;
   const EdgeDev E = edges[e_idx];
   const gpet_scalars* sc = E.sc;
@@ -2572,15 +2576,16 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   const int chunk = CHUNKED ? (int)blockIdx.x : 0;
   const size_t stream = CHUNKED ? (size_t)e_idx * gridDim.y + blockIdx.y : 0;
   __shared__ unsigned int s_mt[2][624];
-  __shared__ int s_cnt[2][4];
+  __shared__ int s_cnt[2][4];  // (accepted attempts per wave; NW = 3: the fourth entry stays 0)
   __shared__ int s_qtail;  // records queued so far (monotonic; slots are taken with one LDS atomic per wave)
   __shared__ double q_r2[MTQ_CAP], q_x1[MTQ_CAP], q_x2[MTQ_CAP];
   __shared__ int q_d0[MTQ_CAP], q_d1[MTQ_CAP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) s_qtail = 0;
+  if (tid < 8) (&s_cnt[0][0])[tid] = 0;
   if (CHUNKED) {
     const unsigned int* st0 = wk.T + (stream * wk.nc + chunk) * 624;
-    for (int i = tid; i < 624; i += 256) s_mt[0][i] = st0[i];
+    for (int i = tid; i < 624; i += NT) s_mt[0][i] = st0[i];
   } else if (tid == 0) {
     // seed of iteration k (0-based) = base + k + 1 (gpet.py:839)
     unsigned int p = seeds[e_idx] + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);
@@ -2616,14 +2621,16 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
   while (done_pairs < need_pairs && (last_chunk || it < MTJ_CB)) {
     unsigned int* o = s_mt[cur];
     unsigned int* nw = s_mt[cur ^ 1];
-    if (tid < 227) nw[tid] = mt_mix(o[tid], o[tid + 1], o[tid + 397]);
+#pragma unroll
+    for (int i = tid; i < 227; i += NT) nw[i] = mt_mix(o[i], o[i + 1], o[i + 397]);
     __syncthreads();
-    if (tid < 227) nw[227 + tid] = mt_mix(o[227 + tid], o[228 + tid], nw[tid]);
+#pragma unroll
+    for (int i = tid; i < 227; i += NT) nw[227 + i] = mt_mix(o[227 + i], o[228 + i], nw[i]);
     __syncthreads();
     if (tid < 169) nw[454 + tid] = mt_mix(o[454 + tid], o[455 + tid], nw[227 + tid]);
-    if (tid == 255) nw[623] = mt_mix(o[623], nw[0], nw[396]);
+    if (tid == NT - 1) nw[623] = mt_mix(o[623], nw[0], nw[396]);
     __syncthreads();
-    // 156 polar attempts on waves 0-2; wave 3 drains the queue of the previous blocks meanwhile.
+    // 156 polar attempts on waves 0-2; the last wave drains the queue of the previous blocks (NW = 4: meanwhile).
     // Accept / reject needs r2 = x1^2 + x2^2 against 1 -- in double, as numpy decides it -- but only 1 pair in 7 is
     // stored and needs the doubles themselves.  x1 = (a - 2^26) / 2^26 + b / 2^52 with a the 27 high bits: a float32
     // estimate from a and c alone is within 4e-7 of r2, so an estimate farther than 1e-5 from the boundary (and from 0)
@@ -2656,7 +2663,7 @@ __global__ void __launch_bounds__(256) k_mt_normals(EdgeDev* edges, const unsign
     if (queued) {
       // (s_qtail is only written after the barrier below, so every thread reads the same value here)
       const int pops = (s_qtail - q_popped) >> 6;  // whole groups of 64 pending records
-      if (w == 3) {
+      if (w == NW - 1) {
         for (int g = 0; g < pops; ++g) {
           const int i = (q_popped + 64 * g + lane) & (MTQ_CAP - 1);
           emit(q_r2[i], q_x1[i], q_x2[i], q_d0[i], q_d1[i]);
@@ -2942,7 +2949,7 @@ hipError_t launch_normals_chunked(hipStream_t st, EdgeDev* d_edges, int B, const
   }
   hipLaunchKernelGGL(k_mtj_count, dim3(nc, streams), dim3(256), 0, st, wk);
   hipLaunchKernelGGL(k_mtj_scan, dim3(streams), dim3(64), 0, st, wk);
-  hipLaunchKernelGGL(k_mt_normals<true>, dim3(nc, n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, wk);
+  hipLaunchKernelGGL((k_mt_normals<true, 4>), dim3(nc, n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, wk);
   return hipGetLastError();
 }
 
@@ -5855,7 +5862,10 @@ hipError_t launch_normals_philox(hipStream_t st, EdgeDev* d_edges, int B, const 
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead, int z_store) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  hipLaunchKernelGGL(k_mt_normals<false>, dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
+  // GPET_RNG_WAVES = 3 | 4 (default 3): waves per workgroup of the generator
+  static const int rng_waves = getenv("GPET_RNG_WAVES") ? atoi(getenv("GPET_RNG_WAVES")) : 3;
+  if (rng_waves == 4) hipLaunchKernelGGL((k_mt_normals<false, 4>), dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
+  else hipLaunchKernelGGL((k_mt_normals<false, 3>), dim3(n_ahead, B), dim3(192), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
   return hipGetLastError();
 }
 
