@@ -622,7 +622,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     // 8 iterations ahead (gpet_trace_iterate); a batch that fills the GPU draws 1 ahead (up to 3 by option): 4 slots
     // instead of 16 -- at 1024 edges of the bench shape 2.4 GB instead of 9.4 GB of an 18 GB arena.  Full-stream mode
     // (z_cols == Lg: full-rank covariances, tests) holds whole 8 MB streams per slot: 2.
-    E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 4);
+    // slots of the normals ring: 16 for small batches (eight iterations ahead on the side stream), 9 above 64 edges (the
+    // eight iterations of a group are generated by one launch), 2 when a row holds the whole grid (config 3)
+    E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 9);
     if (getenv("GPET_Z_RING") && atoi(getenv("GPET_Z_RING")) >= 2 && atoi(getenv("GPET_Z_RING")) <= 16) E.z_ring = atoi(getenv("GPET_Z_RING"));  // (experiments)
     // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
     // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
@@ -1814,7 +1816,12 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     for (int it = 0; it < n_it; ++it) {
       // every kernel skips edges whose `done` flag is set, so edges that finish inside a group cost little.
       const int cur = first + it;
-      static const int rng_inline = getenv("GPET_RNG_INLINE") ? atoi(getenv("GPET_RNG_INLINE")) : 0;
+      // GPET_RNG_INLINE: 0 = the generator runs ahead of the loop on its own stream (small batches: always); 2 = the streams
+      // of ALL the iterations of a group in one launch on the loop's own stream (batches above 64 edges: the default -- the
+      // launch fills the GPU and runs beside nothing, 157-159 instead of 161-162 ms per step of 1 024 traces); 1 = one
+      // iteration per launch on the loop's stream (an experiment: 179 ms)
+      static const int rng_inline_env = getenv("GPET_RNG_INLINE") ? atoi(getenv("GPET_RNG_INLINE")) : -1;
+      const int rng_inline = rng_inline_env >= 0 ? rng_inline_env : (deep ? 0 : 2);
       if (rng_inline == 1) {  // experiment: the normals of this iteration on the loop's own stream, overlapping nothing
         int rcn = normals_auto(b, c->stream, edges_l, B_l, seeds_l, 1, cur, 1, loop_z_store(b));
         if (rcn) return rcn;
