@@ -225,12 +225,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--edges", type=int, default=1024,
+    ap.add_argument("--edges", type=int, default=2048,
                     help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges; "
-                         "the loop's kernels are latency-bound below ~4 workgroups per CU, so the default fills the GPU; "
+                         "the loop's kernels are latency-bound below ~4 workgroups per CU and every kernel has a tail of partly filled CUs, so the "
+                         "default is 8 edges per CU: 6.6 k traces/s at 1024, 6.9 k at 2048, 7.1 k at 4096 (100 GB per batch object); "
                          "the 256-edge figure of config 4 is reported next to it)")
     ap.add_argument("--size", type=int, default=500)
-    ap.add_argument("--pipeline-depth", type=int, default=3,
+    ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1; 0 = none)")
     ap.add_argument("--cpu-traces", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -471,7 +472,7 @@ def main():
     tracer._batch.iterate(seeds, 7)
     sc_mid = tracer._batch.scalars(0)
     n_mid, rank_mid, sweeps_mid = sc_mid.n, sc_mid.rank, max(1, int(sc_mid.lml))
-    # the normals stage fills the batch's whole ring of upcoming iterations per launch (gpet_batch_info: 4 slots at 1024
+    # the normals stage fills the batch's whole ring of upcoming iterations per launch (gpet_batch_info: 9 slots above 64
     # edges, 16 up to 64 edges): report per iteration
     ring = int(tracer._batch.info().get("z_ring", 16))
     def per_iter(d, ring_):
