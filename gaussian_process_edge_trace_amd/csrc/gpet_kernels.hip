@@ -641,14 +641,13 @@ __global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
 
 // diagonal block k0: Cholesky, written back in place, and -- with_inv -- its INVERSE to E.chol_inv: every triangular
 // solve against this block (the rows of L below it, V = L^-1 K_*^T) then becomes a 64x64x64 product on the matrix cores.
-// RIGHT-looking, four waves, one workgroup barrier per pivot: every wave forms column k (lane i: l_ik = a_ik / sqrt(a_kk),
-// through a refined reciprocal square root -- the square root + division chain was half of a pivot's time) and row k of
-// the inverse (lane j: x_kj = b_kj / l_kk, the column sweep of L X = I), then the waves share the columns j > k:
-//   a_ij -= l_ik l_jk      (lane i, its row: stride 65, conflict-free; l_jk: one address for the wave, a broadcast)
-//   b_jc -= l_jk x_kc      (lane c, column c of the inverse)
-// in batches of eight columns whose 24 LDS reads are in flight together.  Finished columns and rows go straight to HBM.
-// (Left-looking with one wave -- a dot product of length k per pivot, a chain of LDS round trips -- took 101 us per block,
-// 2.4 of the 6.1 ms of config 3's fit; with three workgroup barriers per pivot before that, 85 us for the factor alone.)
+// RIGHT-looking, four waves, one LDS barrier per pivot: every wave forms column k (lane i: l_ik = a_ik / sqrt(a_kk),
+// through a refined reciprocal square root formed one step ahead) and row k of the inverse (lane c: x_kc = b_kc / l_kk, the
+// column sweep of L X = I), then updates its own sixteen columns / rows:
+//   a_ij -= l_ik l_jk      (lane i, column j of the wave)          b_jc -= l_jk x_kc      (lane c, row j of the wave)
+// History: left-looking with one wave, a dot product of length k per pivot as a chain of LDS round trips: 101 us per block
+// (2.4 of the 6.1 ms of config 3's fit); the block in LDS, right-looking on four waves in batches of eight columns: 54 us,
+// two thirds of it LDS traffic; the block in registers (below).
 __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
   const EdgeDev E = edges[blockIdx.y];
   gpet_scalars* sc = E.sc;
@@ -656,81 +655,122 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int w
   const int n = sc->n, ld = E.n_cap;
   if (k0 >= n) return;
   const int nb = (n - k0) < CB ? (n - k0) : CB;
-  __shared__ double s[CB][CB + 1];
-  __shared__ double sx[CB][CB + 1];
+  // The block lives in REGISTERS: lane i = row i, wave w = columns 16 w .. 16 w + 15 of it (a[16]), and rows 16 w .. of the
+  // inverse for column `lane` (x[16]).  Per pivot only column k, row k of the inverse and the next pivot's entry go through
+  // LDS (published by their owners at the end of the previous step, two buffers by parity: a slow wave may still read the
+  // old one), and the 16 l_jk a wave needs are broadcast reads of that column -- a fifth of the LDS traffic of the form that
+  // kept the whole block in LDS (54 us per block, 2/3 of it LDS).
+  __shared__ double s_col[2][CB];  // column k: a_ik of the partly factorised block
+  __shared__ double s_xr[2][CB];   // row k of the inverse's right-hand side
+  __shared__ double s_dn[2];       // a_{k+1,k+1} before the update of step k
   const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+  double a[16], x[16];
   {
-    double v[CB / 4];
+    const double* __restrict__ row = E.K + (size_t)(k0 + i) * ld + k0 + 16 * w;
 #pragma unroll
-    for (int u = 0; u < CB / 4; ++u) {
-      const int r = w + 4 * u;
-      v[u] = (r < nb && i <= r) ? E.K[(size_t)(k0 + r) * ld + k0 + i] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < CB / 4; ++u) {
-      const int r = w + 4 * u;
-      s[r][i] = v[u];
-      sx[r][i] = (r == i) ? 1.0 : 0.0;
+    for (int u = 0; u < 16; ++u) {
+      const int j = 16 * w + u;
+      a[u] = (i < nb && j <= i) ? row[u] : 0.0;
+      x[u] = (j == i) ? 1.0 : 0.0;
     }
   }
+  if (w == 0) {
+    s_col[0][i] = a[0];
+    s_xr[0][i] = x[0];
+    if (i == 1) s_dn[0] = a[1];
+  }
   __syncthreads();
-  double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
-  double* kcol = E.K + (size_t)(k0 + i) * ld + k0;
-  // the pivot and its reciprocal square root are formed one step AHEAD (a_k+1,k+1 - l_k+1,k^2 is all the update does to
-  // the next pivot), so the chain rsq + three Newton steps runs under the LDS traffic of the update
-  double d = s[0][0];
+  // (global_store, not flat_store: a FLAT instruction also counts in the LDS wait counter the barrier below waits for)
+  __attribute__((address_space(1))) double* inv = (__attribute__((address_space(1))) double*)(E.chol_inv + (size_t)(k0 / CB) * CB * CB);
+  __attribute__((address_space(1))) double* kcol = (__attribute__((address_space(1))) double*)(E.K + (size_t)(k0 + i) * ld + k0);
+  // the pivot and its reciprocal square root are formed one step AHEAD (a_k+1,k+1 - l_k+1,k^2 is all the update does to the
+  // next pivot), so the chain rsq + three Newton steps runs under the update
+  double d = s_col[0][0];
   double r = __builtin_amdgcn_rsq(d);
 #pragma unroll
   for (int it = 0; it < 3; ++it) r = fma(0.5 * r, fma(-d * r, r, 1.0), r);
-  for (int k = 0; k < nb; ++k) {
-    if (!(d > 0.0)) {  // (the same value in every thread: the exit is uniform)
-      if (tid == 0) sc->status = GPET_ERR_NOT_PD;
-      return;
-    }
-    const double aik = s[i][k], bk = sx[k][i];
-    const int kn = (k + 1 < CB) ? k + 1 : k;
-    const double lnk = s[kn][k] * r;
-    const double dn = fma(-lnk, lnk, s[kn][kn]);
-    double rn = __builtin_amdgcn_rsq(dn);
-    const double dk = d * r;
-    const double lik = (i > k) ? aik * r : (i == k ? dk : 0.0);
-    const double xk = bk * r;
-    if (w == (k & 3)) {
-      if (i >= k && i < nb) kcol[k] = lik;
-      if (with_inv) inv[k * CB + i] = xk;
-    }
-    // columns j > k in batches of eight (the last batch repeats column 63: the same value written twice; rows and
-    // columns beyond a short last block are zero and stay zero)
-    for (int j0 = k + 1 + 8 * w; j0 < CB; j0 += 32) {
-      double lj[8], sv[8], xv[8];
+#ifdef GPET_CD_PROF
+  long long cp[5] = {0, 0, 0, 0, 0};
+  long long ct = clock64();
+#define CD_T(i) { const long long t_ = clock64(); cp[i] += t_ - ct; ct = t_; }
+#else
+#define CD_T(i)
+#endif
+  for (int kp = 0; kp < 4; ++kp) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = (j0 + u < CB) ? j0 + u : CB - 1;
-        lj[u] = s[j][k];
-        sv[u] = s[i][j];
-        xv[u] = sx[j][i];
+    for (int ku = 0; ku < 16; ++ku) {
+      const int k = 16 * kp + ku;
+      if (k >= nb) break;  // (uniform)
+      if (!(d > 0.0)) {    // (the same value in every thread: the exit is uniform)
+        if (tid == 0) sc->status = GPET_ERR_NOT_PD;
+        return;
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = (j0 + u < CB) ? j0 + u : CB - 1;
-        const double ljk = lj[u] * r;
-        // (the next pivot's entry itself keeps its value -- rewritten with the bits it has: slower waves may still be reading
-        //  it for their own copy of the next pivot, and nobody needs it again, the pivot travels in d.  It is column k + 1
-        //  of lane k + 1: the first column of wave 0's first batch, so only u = 0 carries the select.)
-        const double nv = fma(-lik, ljk, sv[u]);
-        s[i][j] = (u == 0 && j0 == k + 1 && i == j) ? sv[u] : nv;
-        sx[j][i] = fma(-ljk, xk, xv[u]);
+      const int pb = k & 1;
+      const double aik = s_col[pb][i], bk = s_xr[pb][i];
+      const int kn = (k + 1 < CB) ? k + 1 : k;
+      const double lnk = s_col[pb][kn] * r;
+      const double dn = fma(-lnk, lnk, s_dn[pb]);
+      double rn = __builtin_amdgcn_rsq(dn);
+      const double dk = d * r;
+      const double lik = (i > k) ? aik * r : (i == k ? dk : 0.0);
+      const double xk = bk * r;
+      CD_T(0)
+      if (w == (k & 3)) {
+        if (i >= k && i < nb) kcol[k] = lik;
+        if (with_inv) inv[k * CB + i] = xk;
       }
-    }
+      CD_T(1)
+      // this wave's columns j > k (all sixteen behind the pivot's wave, the later ones in it, none before it)
+      // (two straight-line forms, all the column reads of a form first: with the test inside the loop every column paid its
+      //  own branch and its own LDS round trip, 1 060 of a pivot's 1 990 cycles on the last wave)
+      if (w > kp) {
+        double lj[16];
 #pragma unroll
-    for (int it = 0; it < 3; ++it) rn = fma(0.5 * rn, fma(-dn * rn, rn, 1.0), rn);
-    d = dn;
-    r = rn;
-    // (LDS only: __syncthreads() would also wait for the column and the row just stored to HBM)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int u = 0; u < 16; ++u) lj[u] = s_col[pb][16 * w + u];  // (one address for the wave: a broadcast)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const double ljk = lj[u] * r;
+          a[u] = fma(-lik, ljk, a[u]);
+          x[u] = fma(-ljk, xk, x[u]);
+        }
+      } else if (w == kp) {
+        double lj[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lj[u] = (u > ku) ? s_col[pb][16 * kp + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (u > ku) {  // (a compile-time test: ku and u are unrolled)
+            const double ljk = lj[u] * r;
+            a[u] = fma(-lik, ljk, a[u]);
+            x[u] = fma(-ljk, xk, x[u]);
+          }
+        }
+      }
+      CD_T(2)
+#pragma unroll
+      for (int it = 0; it < 3; ++it) rn = fma(0.5 * rn, fma(-dn * rn, rn, 1.0), rn);
+      d = dn;
+      r = rn;
+      // what the next step reads: column k + 1, row k + 1 of the inverse, the entry of the pivot after it
+      if (k + 1 < CB && w == ((k + 1) >> 4)) {
+        s_col[pb ^ 1][i] = a[(ku + 1) & 15];
+        s_xr[pb ^ 1][i] = x[(ku + 1) & 15];
+      }
+      if (k + 2 < CB && w == ((k + 2) >> 4) && i == k + 2) s_dn[pb ^ 1] = a[(ku + 2) & 15];
+      // (LDS only: __syncthreads() would also wait for the column and the row just stored to HBM)
+      CD_T(3)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      CD_T(4)
+    }
   }
+#ifdef GPET_CD_PROF
+  if ((tid & 63) == 0 && blockIdx.y == 0 && k0 == 0)
+    printf("chol_diag wave %d: per pivot: reads + column %lld | stores %lld | update %lld | newton + publish %lld | barrier %lld cycles\n", w,
+           cp[0] / nb, cp[1] / nb, cp[2] / nb, cp[3] / nb, cp[4] / nb);
+#endif
+#undef CD_T
   if (with_inv)  // identity beyond a short last block
-    for (int r = nb + w; r < CB; r += 4) inv[r * CB + i] = (r == i) ? 1.0 : 0.0;
+    for (int rr = nb + w; rr < CB; rr += 4) inv[rr * CB + i] = (rr == i) ? 1.0 : 0.0;
 }
 
 // row blocks below the diagonal block by SUBSTITUTION (one row per lane of the first wave): the blocked objective of
