@@ -891,6 +891,12 @@ __global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
 // 64 consecutive lanes' ... per thread group of 16 (a 512-byte run per row); backward -- the 64 ROWS of the block, thread i
 // owns vector entry i and walks down the rows (every load a coalesced run).  The vector stays in LDS.
 // (One 256-thread workgroup reading the transposed block column by column took 3.2 ms at 1500 points: 5.6 GB/s.)
+// the value lane `src` (a compile-time constant at the call sites) holds, in every lane
+__device__ __forceinline__ double lane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
@@ -909,11 +915,17 @@ __global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
     }
     __syncthreads();
     if (tid < WAVE) {
+      // (the 64 dependent steps of a block: lane j's value through v_readlane -- the loop is unrolled, j a constant -- and times
+      //  the reciprocal of the diagonal formed by all lanes at once: a division and a ds_bpermute per step were 10 us per block)
       double z = (tid < nb) ? s_z[k0 + tid] : 0.0;
-      for (int j = 0; j < nb; ++j) {
-        const double zj = __shfl(z, j, WAVE) / sL[j][j];
-        if (tid == j) z = zj;
-        if (tid > j && tid < nb) z -= sL[tid][j] * zj;
+      const double rd = (tid < nb) ? 1.0 / sL[tid][tid] : 0.0;
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (j < nb) {
+          const double zj = lane_f64(z, j) * lane_f64(rd, j);
+          if (tid == j) z = zj;
+          if (tid > j && tid < nb) z -= sL[tid][j] * zj;
+        }
       }
       if (tid < nb) s_z[k0 + tid] = z;
     }
@@ -945,10 +957,14 @@ __global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
     __syncthreads();
     if (tid < WAVE) {
       double z = (tid < nb) ? s_z[k0 + tid] : 0.0;
-      for (int j = nb - 1; j >= 0; --j) {
-        const double aj = __shfl(z, j, WAVE) / sL[j][j];
-        if (tid == j) z = aj;
-        if (tid < j) z -= sL[j][tid] * aj;
+      const double rd = (tid < nb) ? 1.0 / sL[tid][tid] : 0.0;
+#pragma unroll
+      for (int j = CB - 1; j >= 0; --j) {
+        if (j < nb) {
+          const double aj = lane_f64(z, j) * lane_f64(rd, j);
+          if (tid == j) z = aj;
+          if (tid < j) z -= sL[j][tid] * aj;
+        }
       }
       if (tid < nb) s_z[k0 + tid] = z;
     }
