@@ -194,3 +194,20 @@ def test_philox_known_answers_and_moments():
     assert abs(np.corrcoef(Z[:, 0], Z[:, 1])[0, 1]) < 0.08 and abs(np.corrcoef(Z[0], Z[1])[0, 1]) < 0.2
     assert not np.array_equal(orc.philox_standard_normal(12346, 8, 10), Z[:8, :10])
     assert np.array_equal(orc.philox_standard_normal(12345, 8, 9), Z[:8, :9])
+
+
+def test_oracle_f32_sample_mode(golden):
+    """The oracle's sample_dtype="f32" mode (the checker of the library's opt-in f32 storage of the samples): the samples
+    are exactly f32-representable, differ from the f64 samples by at most half an f32 ulp, and on the small fixtures the
+    trace it produces equals the f64 trace (rounding the samples moves no pixel decision there)."""
+    g = golden("trace_rbf64")
+    grad = golden("stage_rbf64")["ref_grad"]
+    kw = dict(CTOR["stage_rbf64"])
+    p = orc.resolve_params(g["in_init"], grad, **kw)
+    Y64 = orc.fit_predict_samples(p["init"], p["obs"], p, p["seed"] + 1)
+    Y32 = orc.fit_predict_samples(p["init"], p["obs"], p, p["seed"] + 1, sample_dtype="f32")
+    assert np.array_equal(Y32, Y32.astype(np.float32).astype(np.float64))
+    assert np.max(np.abs(Y32 - Y64)) <= 0.5 * np.spacing(np.float32(np.max(np.abs(Y64)))) * 1.0001
+    et64, _, i64 = orc.trace(g["in_init"], grad, **kw)
+    et32, _, i32 = orc.trace(g["in_init"], grad, sample_dtype="f32", **kw)
+    assert i32["n_iter"] == i64["n_iter"] and np.array_equal(et32, et64)
