@@ -378,3 +378,55 @@ def test_device_pointer_images_equal_host_images(tmp_path):
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "device pointers ok" in r.stdout
+
+
+NCCL_WORKER = r"""
+import os, sys
+import torch  # FIRST (INTEGRATION.md section 4)
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import numpy as np
+import gaussian_process_edge_trace_amd as amd
+from gaussian_process_edge_trace_amd import sharding
+from oracle import gpet_oracle as orc  # (synthetic image only)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+N = 128
+img, truth = orc.synth_sinusoid_image(N, 2)
+ctx = amd._lib.Context(0)
+grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx).astype(np.float32)
+init = truth[[0, -1], :][:, [1, 0]]
+kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 20, 'length_scale': 8}, noise_y=1, N_samples=300, score_thresh=1,
+          delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+inits, seeds = [init] * 6, [3, 4, 5, 6, 7, 8]
+# the path trace_sharded takes with more than one rank: RCCL broadcast into a CUDA tensor (stream-synchronised by the helper),
+# consumed in place through data_ptr(), traces gathered over RCCL
+g = sharding.broadcast_tensor(grad, grad.shape, np.float32, dist, 0, "cuda")
+assert g.is_cuda
+b = amd.GP_Edge_Tracing_Batch(inits, None, seeds, grad_device_ptrs=[g.data_ptr()], grad_shape=grad.shape, _ctx=ctx, **kw)
+local = b()
+got = sharding.gather_traces(local, len(inits), N, dist, "cuda")
+ref = amd.GP_Edge_Tracing_Batch(inits, grad, seeds, _ctx=ctx, **kw)()
+assert np.array_equal(got, np.stack(ref))
+dist.destroy_process_group()
+print("nccl single rank ok")
+"""
+
+
+def test_broadcast_and_gather_over_nccl_single_rank(tmp_path):
+    """The helpers trace_sharded uses with more than one rank, over a one-rank NCCL (= RCCL) group on the GPU: the gradient
+    image broadcast into a CUDA tensor (broadcast_tensor synchronises torch's stream before handing the pointer to the
+    library's own stream: round-2 advisor finding), consumed in place, traces gathered on the device -- equal to the
+    host-array batch.  A fresh process that imports torch first."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER % dict(root=root))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "nccl single rank ok" in r.stdout
