@@ -100,7 +100,17 @@ def to_abi_params(p, obs_cap=None, factor_cap=0, z_cols=0):
 
 
 class GP_Edge_Tracing(object):
-    """Traces one edge with Gaussian-process regression on the GPU (gpet.py:17-35)."""
+    """Traces one edge with Gaussian-process regression on the GPU (gpet.py:17-35).
+
+    The seam methods of the reference class are device calls on ONE resident state (observation set, samples, scores,
+    KDE, score threshold).  Unlike the reference's pure functions, ``fit_predict_GP(obs)``, ``compute_new_obs(...,
+    pre_fobs)`` and ``get_best_pixels(..., pre_fobs=...)`` leave the observation set they were given on the device, and
+    ``get_best_curves(y_samples)`` the samples: a later argument-less call continues from there.  ``__call__`` starts
+    from ``self.obs`` again (it resets the device state first), so a trace is not affected by earlier seam calls.
+
+    Keywords beyond the reference's signature (keyword-only): ``device``, ``stream``, ``factor_cap``, ``z_cols``,
+    ``sample_dtype`` ("f32": samples stored in single precision) and ``rng`` ("philox": counter-based generator) --
+    the last two are opt-in modes outside the reference-parity statements."""
 
     def __init__(self, init, grad_img, kernel_options=(1, 3, 3), noise_y=1, obs=np.array([], dtype=np.int8),
                  N_samples=500, score_thresh=1, delta_x=20, keep_ratio=0.1, pixel_thresh=5, seed=42,
