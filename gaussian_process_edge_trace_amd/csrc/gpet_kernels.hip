@@ -3124,8 +3124,12 @@ template <typename T>
 __device__ __forceinline__ const GPET_GLOBAL T* as_global(const T* p) {
   return (const GPET_GLOBAL T*)p;
 }
-template <int KS, bool F32>
-__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part, bool mu_lds) {
+// MU_LDS (the posterior mean behind the chunk in LDS) is a COMPILE-TIME switch: as a run-time one the mean had two producers --
+// an LDS read and a global load into the same registers -- and at their join the compiler waits for BOTH counters: every
+// store of a column group then waited (vmcnt(0)) for all the stores before it.
+template <int KS, bool F32, bool MU_LDS>
+__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part) {
+  constexpr bool mu_lds = MU_LDS;
   typedef typename YT<F32>::type yt;
   GPET_GLOBAL yt* __restrict__ Yo = as_global(reinterpret_cast<yt*>(E.Y));
   const GPET_GLOBAL double* __restrict__ Ag = as_global(E.A);
@@ -3226,8 +3230,8 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 // One kernel per K extent (the launcher picks it from the batch's largest possible rank; an edge of smaller
 // rank multiplies a few zero rows): register allocation is per kernel, and the variants up to K = 72 fit the
 // 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
-template <int KS, bool F32>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges, int mu_in_lds) {
+template <int KS, bool F32, bool MU_LDS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges) {
   int edge, part;  // the row blocks of an edge on one XCD: its factor comes out of HBM once, not once per row block
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
@@ -3235,10 +3239,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];  // [4 KS][GEMM_LDA]
-  sample_gemm_body<KS, F32>(E, sc, s_fa, part, mu_in_lds != 0);
+  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, part);
 }
-template <int KS, bool F32>
-__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int mu_in_lds) {  // (K > 72: one workgroup per CU)
+template <int KS, bool F32, bool MU_LDS>
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  // (K > 72: one workgroup per CU)
   int edge, part;
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
@@ -3246,7 +3250,7 @@ __global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   if (part * 128 >= E.S) return;
   extern __shared__ double s_fa[];
-  sample_gemm_body<KS, F32>(E, sc, s_fa, part, mu_in_lds != 0);
+  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, part);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -6025,8 +6029,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
       static PerDeviceOnce once;
       if (once.first()) {
 #define GPET_GEMM_ATTR(KERNEL, KS_)                                                                                       \
-  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX); \
-  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX)
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX);  \
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX);   \
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX); \
+  (void)hipFuncSetAttribute((const void*)KERNEL<KS_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_MAX)
         GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 8);
         GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 12);
         GPET_GEMM_ATTR(k_sample_gemm_mfma_r, 16);
@@ -6041,8 +6047,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 #define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
   do {                                                                                                                                 \
     const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
-    if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true>), grid, block, lds_, st, d_edges, mu_in_lds);                                 \
-    else hipLaunchKernelGGL((KERNEL<KS_, false>), grid, block, lds_, st, d_edges, mu_in_lds);                                         \
+    if (bd.y_f32 && mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, true, true>), grid, block, lds_, st, d_edges);                        \
+    else if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true, false>), grid, block, lds_, st, d_edges);                               \
+    else if (mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, false, true>), grid, block, lds_, st, d_edges);                              \
+    else hipLaunchKernelGGL((KERNEL<KS_, false, false>), grid, block, lds_, st, d_edges);                                            \
   } while (0)
     if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
     else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
