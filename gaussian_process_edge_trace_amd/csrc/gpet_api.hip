@@ -46,6 +46,7 @@ struct gpet_batch {
   long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
+  int keep_samples = 0;                // gpet_batch_keep_samples: 1 = the loop leaves the whole sample matrix behind (separate GEMM + scorer)
   int rng_mode = 0;                    // 0: MT19937 + polar method = numpy's RandomState stream; 1: Philox4x32-10 + Box-Muller (opt-in)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
   double* d_fin_stage = nullptr;       // staging of the converged fits' training sets (x | y | w blocks)
@@ -349,6 +350,12 @@ int gpet_set_option(const char* name, int value) {
     v = value;
     return old;
   }
+  if (name && strcmp(name, "fused_score") == 0) {
+    int& v = gpet_opt_fused_score();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "rng_lookahead") == 0) {
     int& v = gpet_opt_rng_lookahead();
     const int old = v;
@@ -579,6 +586,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   BatchDims bd{};
   bd.M = M;
   bd.N = N;
+  bd.lg_even = 1;
   bool any_big = false, any_gen_nu = false;
   for (int e = 0; e < B; ++e) {
     const int Lg_e = params[e].x_en - params[e].x_st + 1;
@@ -644,6 +652,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     E.noise_y = p.noise_y;
     E.jitter = p.jitter;
     if (Lg > bd.Lg) bd.Lg = Lg;
+    if (Lg & 1) bd.lg_even = 0;
     if (E.S > bd.S) bd.S = E.S;
     if (E.n_keep > bd.n_keep) bd.n_keep = E.n_keep;
     if (E.z_cols > bd.z_cols) bd.z_cols = E.z_cols;
@@ -1108,6 +1117,12 @@ int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
   return GPET_OK;
 }
 
+int gpet_batch_keep_samples(gpet_batch* b, int on) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  b->keep_samples = on ? 1 : 0;
+  return GPET_OK;
+}
+
 int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
   if (!b || e < 0 || e >= b->B) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -1288,6 +1303,13 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 110: case 111: case 112: case 113:
         HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 110))); break;
       case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
+      // 131: samples scored out of the accumulators (+ the combine of the tile partials), 132: the kept rows -- the loop's form
+      case 131: case 132: {
+        const int rm = b->structured ? b->bd.r0_max : 0;
+        if (!sample_score_fused_applies(b->bd, rm)) return fail(c, GPET_ERR_UNSUPPORTED, "gpet_profile_stage: the fused sample + score kernel does not apply to this batch");
+        HIPCHK(c, launch_sample_score(c->stream, b->d_edges, b->B, b->bd, rm, stage == 131 ? 1u : 4u));
+        break;
+      }
       case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
       case 150: case 151: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150), 1)); break;
       case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 4u, 0)); break;  // (stage-API form only)
@@ -1874,7 +1896,14 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         HIPCHK(c, launch_factor(c->stream, edges_l, B_l, b->bd, ~0u, edges_l == b->d_edges ? b->h_edges.data() : b->h_edges_act.data()));
       }
       HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
-      HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, b->structured ? b->bd.r0_max : 0));
+      // samples + scores: the GEMM writes all S rows and the scorer reads them back; or (gpet_set_option "fused_score", off
+      // by default: slower at the bench shape) one kernel scores the samples out of the matrix-core accumulators and a
+      // second one stores the n_keep best rows, where that applies (even grid lengths, rank <= 72) and nobody asked for
+      // the whole sample matrix (gpet_batch_keep_samples)
+      const int rank_max = b->structured ? b->bd.r0_max : 0;
+      const bool fused = gpet_opt_fused_score() && !b->keep_samples && sample_score_fused_applies(b->bd, rank_max);
+      if (fused) HIPCHK(c, launch_sample_score(c->stream, edges_l, B_l, b->bd, rank_max));
+      else HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, rank_max));
       HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
       if (rng_after_gemm && !rng_inline && !deep && b->norm_issued == cur + 1 && cur + 1 < horizon) {
         // the next iteration's stream starts when this iteration's GEMM is through: it then runs beside the scorer and the
@@ -1885,7 +1914,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         HIPCHK(c, hipEventRecord(b->ev_norm[(cur + 1) % 16], b->side));
         b->norm_issued = cur + 2;
       }
-      HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
+      if (!fused) HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
       // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
       HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
       HIPCHK(c, launch_pixels(c->stream, edges_l, B_l, b->bd, 1));

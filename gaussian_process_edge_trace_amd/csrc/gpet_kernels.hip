@@ -3457,13 +3457,80 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
+#pragma clang fp contract(off)
   y = y < 0.0 ? 0.0 : (y > (double)(M - 1) ? (double)(M - 1) : y);
   // (0 <= y <= M - 1 from here on, M >= 2: the row below is min(floor(y), M - 2) >= 0 and the row above is always inside
   //  the column -- no further clamps; the kernel is bound by vector-ALU issue and this runs 2-3 times per curve pair)
   int iy = (int)y;  // = floor(y) for y >= 0
   iy = iy > M - 2 ? M - 2 : iy;
   const double w1 = y - (double)iy, w0 = ((double)iy + 1.0) - y;
-  return (double)col[iy] * w0 + (double)col[iy + 1] * w1;
+  return fma((double)col[iy + 1], w1, (double)col[iy] * w0);
+}
+
+// One Simpson pair of G curves, as lane `pl` of each curve's row of sixteen lanes sees it: own points (y0, y1) at the
+// slab columns col0 / col1; the third point, its gradient value and the following segment come from the lane above by
+// DPP; (arc length, line integral) summed over the row.  ONE body for k_score_tile (samples from memory, G = 1) and
+// k_sample_score (samples from the accumulators, G = 4), every fused multiply-add spelled out and contraction off: the
+// two kernels give the same bits for the same samples.  No branches: the G curves are independent chains in one basic
+// block, which the scheduler interleaves (k_sample_score runs two or three waves per SIMD and has nothing else to hide
+// the reciprocal square roots and the LDS gathers behind).
+template <int G>
+__device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const double (&y1)[G], const float* __restrict__ col0,
+                                                const float* __restrict__ col1, int M, bool on, double (&al)[G], double (&li)[G]) {
+#pragma clang fp contract(off)
+  double l0[G], r0[G], g0[G], g1[G];
+  // the 4 G taps of the bilinear lookups first (grad_lds, split: all the LDS reads are out before anything needs them),
+  // the segment lengths under their latency, then the interpolation
+  double yc0[G], yc1[G];
+  float ta0[G], tb0[G], ta1[G], tb1[G];
+  int iy0[G], iy1[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    yc0[g] = y0[g] < 0.0 ? 0.0 : (y0[g] > (double)(M - 1) ? (double)(M - 1) : y0[g]);
+    yc1[g] = y1[g] < 0.0 ? 0.0 : (y1[g] > (double)(M - 1) ? (double)(M - 1) : y1[g]);
+    iy0[g] = (int)yc0[g];
+    iy1[g] = (int)yc1[g];
+    iy0[g] = iy0[g] > M - 2 ? M - 2 : iy0[g];
+    iy1[g] = iy1[g] > M - 2 ? M - 2 : iy1[g];
+    ta0[g] = col0[iy0[g]];
+    tb0[g] = col0[iy0[g] + 1];
+    ta1[g] = col1[iy1[g]];
+    tb1[g] = col1[iy1[g] + 1];
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const double d0 = y1[g] - y0[g];
+    const double q0 = fma(d0, d0, 1.0);
+    r0[g] = rsqrt(q0);
+    l0[g] = q0 * r0[g];
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {  // (= grad_lds(col, M, y) + 1e-3)
+    const double w01 = yc0[g] - (double)iy0[g], w00 = ((double)iy0[g] + 1.0) - yc0[g];
+    const double w11 = yc1[g] - (double)iy1[g], w10 = ((double)iy1[g] + 1.0) - yc1[g];
+    g0[g] = fma((double)tb0[g], w01, (double)ta0[g] * w00) + 1e-3;
+    g1[g] = fma((double)tb1[g], w11, (double)ta1[g] * w10) + 1e-3;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const double y2 = dpp_row<0x101>(y0[g]), l2 = dpp_row<0x101>(l0[g]), r2 = dpp_row<0x101>(r0[g]);  // row_shl:1: the pair above
+    const double g2 = dpp_row<0x101>(g0[g]);
+    const double d1 = y2 - y1[g];
+    const double q1 = fma(d1, d1, 1.0);
+    const double r1 = rsqrt(q1), l1 = q1 * r1;
+    const double a_ = (2.0 / 6.0) * (fma(4.0, l1, l0[g]) + l2);
+    const double h0 = l1, h1 = l2, ih0 = r1, ih1 = r2;
+    const double hsum = h0 + h1;
+    const double t0 = g0[g] * fma(-h1, ih0, 2.0), t1 = g1[g] * ((hsum * hsum) * (ih0 * ih1)), t2 = g2 * fma(-h0, ih1, 2.0);
+    const double l_ = (hsum * (1.0 / 6.0)) * ((t0 + t1) + t2);
+    al[g] = on ? a_ : 0.0;
+    li[g] = on ? l_ : 0.0;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    al[g] = row16_sum(al[g]);
+    li[g] = row16_sum(li[g]);
+  }
 }
 
 template <bool F32>
@@ -3519,28 +3586,12 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
     const bool live = s < s_hi;
     double n0 = 0.0, n1 = 0.0;
     if (s0 + SC_THREADS / 16 < s_hi) fetch(s0 + SC_THREADS / 16, n0, n1);
-    const double d0 = y1 - y0;
-    const double q0 = 1.0 + d0 * d0;
-    const double r0 = rsqrt(q0), l0 = q0 * r0;
-    const double g0 = grad_lds(s_img + (2 * pl) * ldm, M, y0) + 1e-3;
-    const double g1 = grad_lds(s_img + (2 * pl + 1) * ldm, M, y1) + 1e-3;
-    double y2 = dpp_row<0x101>(y0), l2 = dpp_row<0x101>(l0), r2 = dpp_row<0x101>(r0);  // row_shl:1: the pair above
-    double g2 = dpp_row<0x101>(g0);
-    double al = 0.0, li = 0.0;
-    if (pl < SC_PAIRS && i < npair) {
-      const double d1 = y2 - y1;
-      const double q1 = 1.0 + d1 * d1;
-      const double r1 = rsqrt(q1), l1 = q1 * r1;
-      al = (2.0 / 6.0) * (l0 + 4.0 * l1 + l2);
-      const double h0 = l1, h1 = l2, ih0 = r1, ih1 = r2;
-      const double hsum = h0 + h1;
-      li = hsum * (1.0 / 6.0) * (g0 * (2.0 - h1 * ih0) + g1 * (hsum * hsum * (ih0 * ih1)) + g2 * (2.0 - h0 * ih1));
-    }
-    al = row16_sum(al);
-    li = row16_sum(li);
+    const double ya[1] = {y0}, yb[1] = {y1};
+    double al[1], li[1];
+    score_pairs_row<1>(ya, yb, s_img + (2 * pl) * ldm, s_img + (2 * pl + 1) * ldm, M, pl < SC_PAIRS && i < npair, al, li);
     if (pl == 0 && live) {
-      cpart[2 * s] = al;
-      cpart[2 * s + 1] = li;
+      cpart[2 * s] = al[0];
+      cpart[2 * s + 1] = li[0];
     }
     y0 = n0;
     y1 = n1;
@@ -3563,6 +3614,250 @@ __global__ void __launch_bounds__(256) k_score_combine(EdgeDev* edges, int n_til
   if (E.y_f32) simpson_tail(E, reinterpret_cast<const float*>(E.Y) + (size_t)s * E.Lg, al, li);
   else simpson_tail(E, E.Y + (size_t)s * E.Lg, al, li);
   E.costs[s] = al / li;
+}
+
+// a6 + a7 in one kernel (the device loop; sklearn_gpr.py:440-473 + gpet.py:391-408): the sample matrix of an iteration is
+// written once (8 S Lg bytes per edge, what bounds k_sample_gemm_mfma_r) and read once (k_score_tile) although only the
+// n_keep best curves are ever looked at again.  Here the workgroup of a scorer tile (15 Simpson pairs = 32 grid columns,
+// their image slab in LDS) forms the samples of its columns itself on the matrix cores and scores them out of the
+// accumulators:
+//   * B operands: the 2 x KS factor entries of a lane's two columns (even / odd point of pair `pl`) stay in registers for
+//     the whole kernel; A operands: 16 rows of Z (the normals) per wave and group, KS loads per lane, the next group's
+//     requested as soon as the last MFMA has read this group's (they arrive under the scoring);
+//   * two accumulator tiles (even points, odd points): register g of lane (pl, lq) is curve s0 + lq + 4 g at the two
+//     points of pair pl -- exactly the (y0, y1) of k_score_tile's lane, with the sixteen pairs of a curve in one DPP row;
+//     the MFMA chain runs over k in the order of k_sample_gemm_mfma_r, so a sample has the same bits in both kernels
+//     and the scoring arithmetic below is k_score_tile's: costs, best_idx and traces are identical to the unfused path.
+// The kept curves are then formed once more by k_sample_keep_rows (n_keep rows instead of S) where the KDE and the pixel
+// kernels look for them.  Needs an even grid length (an odd one has Simpson's tail correction, which reads sample rows).
+#ifndef GPET_SS_WAVES
+#define GPET_SS_WAVES 2  // waves per SIMD the register allocation aims at (experiments: 3 with 384-thread workgroups)
+#endif
+template <int KS, bool F32>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GPET_SS_WAVES, 3))) k_sample_score(EdgeDev* edges) {
+  int edge, part;
+  xcd_edge_part((int)(gridDim.x * gridDim.y), edge, part);
+  const int bx = part % (int)gridDim.x, byy = part / (int)gridDim.x;
+  const EdgeDev E = edges[edge];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  extern __shared__ float s_img[];  // [2 * SC_PAIRS + 2][ldm]
+  const int M = E.M, N = E.N, Lg = E.Lg, S = E.S, zc = E.z_cols;
+  const int npair = (Lg - 2) / 2;
+  const int p0 = bx * SC_PAIRS;
+  if (p0 >= npair) return;
+  const int c0 = E.x_st + 2 * p0;  // first image column of the slab
+  const int ncol = 2 * SC_PAIRS + 2;
+  const int ldm = M | 1;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  {  // the slab, eight loads per thread in flight (four waves stage what sixteen stage in k_score_tile)
+    const GPET_GLOBAL float* __restrict__ gimg = as_global(E.grad);
+    const int tot = ncol * M;
+    for (int e0 = tid; e0 < tot; e0 += 8 * nthr) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr;
+        const int y = e / ncol, c = e - y * ncol;
+        v[u] = (e < tot && c0 + c < N) ? gimg[(size_t)y * N + c0 + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr;
+        const int y = e / ncol, c = e - y * ncol;
+        if (e < tot) s_img[c * ldm + y] = v[u];
+      }
+    }
+  }
+  const int lane = tid & 63, w = tid >> 6, nw = nthr >> 6;
+  const int pl = lane & 15, lq = lane >> 4;
+  const int i = p0 + pl;
+  const int k = 2 * i;
+  const bool valid = k + 1 < Lg;  // (the lane after the last pair still supplies its data)
+  const int rows = sc->rank;
+  const GPET_GLOBAL double* __restrict__ Ag = as_global(E.A);
+  const GPET_GLOBAL double* __restrict__ Zs = as_global(E.Z) + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  double bE[KS], bO[KS];
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int kk = 4 * q + lq;
+    const bool in = kk < rows && valid;
+    bE[q] = in ? Ag[(size_t)kk * Lg + k] : 0.0;
+    bO[q] = in ? Ag[(size_t)kk * Lg + k + 1] : 0.0;
+  }
+  const double mu0 = valid ? as_global(E.mean)[k] : 0.0, mu1 = valid ? as_global(E.mean)[k + 1] : 0.0;
+  const double y_s = sc->y_s;
+  // curves of this workgroup: gridDim.y equal parts, rounded up to whole groups of 16
+  const int per = (((S + (int)gridDim.y - 1) / (int)gridDim.y) + 15) & ~15;
+  const int s_lo = byy * per;
+  const int s_hi = (s_lo + per < S) ? (s_lo + per) : S;
+  if (s_lo >= S) return;  // (uniform over the workgroup)
+  GPET_GLOBAL double* __restrict__ cpart = as_global(E.cost_part) + ((size_t)bx * S) * 2;
+  const float* col0 = s_img + (2 * pl) * ldm;
+  const float* col1 = col0 + ldm;
+  const bool on = pl < SC_PAIRS && i < npair;
+  double a[KS];
+  int s0 = s_lo + 16 * w;
+  // (rows of Z: every load is issued, at a clamped address where the entry does not exist, and its value used as it is --
+  //  eighteen predicated loads are eighteen branches, and a select on the loaded value makes every load wait for itself.
+  //  Beyond the rank the factor entries bE / bO are exact zeros and a clamped address holds a finite normal, so the
+  //  product is zero; a row beyond the workgroup's curves repeats row s_lo and its scores are never stored.)
+  const int kmax = rows > 0 ? rows - 1 : 0;
+  auto load_a = [&](int sbase) {
+    const int srow = sbase + pl;
+    const GPET_GLOBAL double* __restrict__ zr = Zs + (size_t)(srow < s_hi ? srow : s_lo) * zc;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int kk = 4 * q + lq;
+      a[q] = zr[kk < kmax ? kk : kmax];
+    }
+  };
+  load_a(s0);
+#ifdef GPET_SS_PROF  // cycles per phase of a group, as wave 0 of workgroup 0 sees them
+  long long pf[5] = {0, 0, 0, 0, 0};
+  const long long t_in = clock64();
+#define SS_STAMP(i) { const long long t_ = clock64(); pf[i] += t_ - tl; tl = t_; }
+#else
+#define SS_STAMP(i)
+#endif
+  __syncthreads();  // the slab is staged
+#ifdef GPET_SS_PROF
+  long long tl = clock64();
+  const long long t_loop = tl;
+  int ngroups = 0;
+#endif
+  for (; s0 < s_hi; s0 += 16 * nw) {
+    v4f64 accE = (v4f64){0.0, 0.0, 0.0, 0.0}, accO = (v4f64){0.0, 0.0, 0.0, 0.0};
+#ifdef GPET_SS_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SS_STAMP(0)
+    ++ngroups;
+#endif
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      accE = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bE[q], accE, 0, 0, 0);
+      accO = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bO[q], accO, 0, 0, 0);
+    }
+#ifdef GPET_SS_PROF
+    asm volatile("s_nop 0" ::"v"(accE[0]), "v"(accO[0]));
+    SS_STAMP(1)
+#endif
+    if (s0 + 16 * nw < s_hi) load_a(s0 + 16 * nw);  // the next group's rows of Z (wave-uniform condition)
+    SS_STAMP(2)
+    double ya[4], yb[4], al[4], li[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // (a lane beyond the grid has zero factor entries and a zero mean: its points are 0, as in k_score_tile)
+      ya[g] = (accE[g] + mu0) * y_s;
+      yb[g] = (accO[g] + mu1) * y_s;
+      if (F32) {  // (gpet_batch_set_sample_dtype: what the f32 store of the GEMM and the widening load of the scorer give)
+        ya[g] = (double)(float)ya[g];
+        yb[g] = (double)(float)yb[g];
+      }
+    }
+    score_pairs_row<4>(ya, yb, col0, col1, M, on, al, li);
+#ifdef GPET_SS_PROF
+    asm volatile("s_nop 0" ::"v"(al[3]), "v"(li[3]));
+    SS_STAMP(3)
+#endif
+    if (pl == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int s = s0 + lq + 4 * g;
+        if (s < s_hi) {
+          cpart[2 * s] = al[g];
+          cpart[2 * s + 1] = li[g];
+        }
+      }
+    }
+    SS_STAMP(4)
+  }
+#ifdef GPET_SS_PROF
+  if (blockIdx.x + blockIdx.y + blockIdx.z == 0 && tid == 0 && ngroups > 0)
+    printf("ss prof (%d threads, %d groups): staging+B %lld | per group: wait Z %lld, mfma %lld, issue loads %lld, scoring %lld, stores %lld | loop %lld cycles\n",
+           nthr, ngroups, (long long)(t_loop - t_in), pf[0] / ngroups, pf[1] / ngroups, pf[2] / ngroups, pf[3] / ngroups, pf[4] / ngroups,
+           (long long)(clock64() - t_loop));
+#endif
+#undef SS_STAMP
+}
+
+// The n_keep best curves of an iteration whose samples were scored out of the accumulators (k_sample_score): rows
+// best_idx[0 .. n_keep) of the sample matrix, formed by the MFMA chain of the sample GEMM (same bits) and stored where the
+// KDE and the pixel kernels read them.  One wave per (group of 16 kept rows, 16 columns).
+template <bool F32>
+__global__ void __launch_bounds__(256) k_sample_keep_rows(EdgeDev* edges) {
+  typedef typename YT<F32>::type yt;
+  constexpr int KS = 18;  // (the fused kernel serves ranks up to 72; steps beyond the rank multiply zeros)
+  int edge, rg;  // (the row groups of an edge on one XCD: its factor comes out of HBM once, not once per L2)
+  xcd_edge_part((int)gridDim.x, edge, rg);
+  const EdgeDev E = edges[edge];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int Lg = E.Lg, S = E.S, zc = E.z_cols, n_keep = E.n_keep;
+  if (16 * rg >= n_keep) return;
+  const int rows = sc->rank;
+  const GPET_GLOBAL double* __restrict__ Ag = as_global(E.A);
+  const GPET_GLOBAL double* __restrict__ Zs = as_global(E.Z) + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  const GPET_GLOBAL int* __restrict__ bidx = as_global(E.best_idx);
+  GPET_GLOBAL yt* __restrict__ Yo = as_global(reinterpret_cast<yt*>(E.Y));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const int nct = (Lg + 15) >> 4;
+  const double y_s = sc->y_s;
+  const int bi = 16 * rg + li;
+  int arow = bi < n_keep ? bidx[bi] : -1;
+  if (arow >= S) arow = -1;
+  double a[KS];
+  {
+    const GPET_GLOBAL double* __restrict__ zr = Zs + (size_t)(arow >= 0 ? arow : 0) * zc;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int kk = 4 * q + lq;
+      const bool in = arow >= 0 && kk < rows;
+      const double v = zr[in ? kk : 0];
+      a[q] = in ? v : 0.0;
+    }
+  }
+  int orow[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int bo = 16 * rg + lq + 4 * g;
+    orow[g] = bo < n_keep ? bidx[bo] : -1;
+    if (orow[g] >= S) orow[g] = -1;
+  }
+  // two buffers of factor entries (and the tile's posterior mean): the loads of the tile after next are in flight while
+  // this one multiplies and stores
+  const int kmax = rows > 0 ? rows - 1 : 0;
+  auto load_b = [&](double (&b)[KS], double& mu, int ct) {
+    // (clamped addresses, values used as loaded: beyond the rank the normals a[] are exact zeros, beyond the grid
+    //  nothing is stored -- a select on the loaded value would make every load wait for itself)
+    const int j = 16 * ct + li;
+    const GPET_GLOBAL double* __restrict__ ac = Ag + (j < Lg ? j : 0);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int kk = 4 * q + lq;
+      b[q] = ac[(size_t)(kk < kmax ? kk : kmax) * Lg];
+    }
+    mu = as_global(E.mean)[j < Lg ? j : 0];
+  };
+  auto tile = [&](const double (&b)[KS], double mu, int ct) {
+    v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KS; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+    const int j = 16 * ct + li;
+    if (j < Lg) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (orow[g] >= 0) Yo[(size_t)orow[g] * Lg + j] = (yt)((acc[g] + mu) * y_s);
+    }
+  };
+  double b0[KS], b1[KS], mu0 = 0.0, mu1 = 0.0;
+  if (w < nct) load_b(b0, mu0, w);
+  for (int ct = w; ct < nct; ct += 8) {  // (wave-uniform)
+    if (ct + 4 < nct) load_b(b1, mu1, ct + 4);
+    tile(b0, mu0, ct);
+    if (ct + 8 < nct) load_b(b0, mu0, ct + 8);
+    if (ct + 4 < nct) tile(b1, mu1, ct + 4);
+  }
 }
 
 // argsort(costs)[:n_keep] for S <= 1024 by a bitonic sort of (cost, index) in LDS: 55 compare-exchange steps of 512
@@ -6088,6 +6383,83 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
   if (parts & 2u) {
     if (bd.S <= 1024 && !getenv("GPET_TOPK_RANK")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
     else hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  }
+  return hipGetLastError();
+}
+
+// gpet_set_option "fused_score" (default 0; environment GPET_FUSED_SCORE): 1 = where it applies the device loop scores the
+// samples out of the matrix-core accumulators (k_sample_score) and stores only the kept rows, instead of writing the whole
+// sample matrix (k_sample_gemm_mfma_r) and scoring it from memory (k_score_tile).  Identical results; measured SLOWER at
+// the bench shape (3.2 + 0.4 ms against 1.8 + 1.25 ms per 1 024 edges: every column tile streams the edge's normals
+// through its CU's L1 again, 13 GB per launch), so it is off by default.
+int& gpet_opt_fused_score() {
+  static int v = getenv("GPET_FUSED_SCORE") != nullptr ? atoi(getenv("GPET_FUSED_SCORE")) : 0;
+  return v;
+}
+
+static int sample_score_ks(const BatchDims& bd, int rank_max) {
+  const int rm = rank_max > 0 && rank_max <= bd.r_cap ? rank_max : (bd.r_cap > bd.a_rows_cap ? bd.r_cap : bd.a_rows_cap);
+  return (rm + 3) >> 2;
+}
+
+bool sample_score_fused_applies(const BatchDims& bd, int rank_max) {
+  if (!bd.lg_even || bd.Lg < 4 || bd.S < 64) return false;
+  if (bd.r_cap > GEMM_KMAX || bd.a_rows_cap > GEMM_KMAX) return false;
+  if (sample_score_ks(bd, rank_max) > 18) return false;  // (two waves per SIMD hold 2 x 18 factor entries and 18 normals per lane)
+  if (bd.z_cols < 4) return false;
+  const size_t lds = (size_t)(2 * SC_PAIRS + 2) * (bd.M | 1) * sizeof(float);
+  return lds <= 150 * 1024;
+}
+
+// parts: 1 = samples scored out of the accumulators + the per-tile partials combined, 2 = the best n_keep, 4 = their rows
+hipError_t launch_sample_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, int rank_max, unsigned parts) {
+  (void)hipGetLastError();
+  const int ks = sample_score_ks(bd, rank_max);
+  const size_t lds = (size_t)(2 * SC_PAIRS + 2) * (bd.M | 1) * sizeof(float);
+  {
+    static PerDeviceOnce once;
+    if (once.first()) {
+#define GPET_SS_ATTR(KS_)                                                                                                  \
+  (void)hipFuncSetAttribute((const void*)k_sample_score<KS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+  (void)hipFuncSetAttribute((const void*)k_sample_score<KS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+      GPET_SS_ATTR(8);
+      GPET_SS_ATTR(12);
+      GPET_SS_ATTR(16);
+      GPET_SS_ATTR(18);
+#undef GPET_SS_ATTR
+    }
+  }
+  if (parts & 1u) {
+    const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
+    // two workgroups of four waves per CU while two slabs fit its LDS (one stages while the other works), else one of eight
+    static const int threads_env = getenv("GPET_SS_THREADS") ? atoi(getenv("GPET_SS_THREADS")) : 0;  // (experiments: 256, 384, 512)
+    const int threads = threads_env > 0 ? threads_env : (2 * lds + 4096 <= 160 * 1024 ? 256 : 512);
+    // curves split over workgroups only while the tiles alone do not fill the GPU (every part stages the slab again)
+    int ny = cdiv(768, B * n_tiles);
+    const int ny_max = cdiv(bd.S, threads / 4);
+    ny = ny > ny_max ? ny_max : (ny < 1 ? 1 : ny);
+    const dim3 grid(n_tiles, ny, B), block(threads);
+    static const size_t lds_pad = getenv("GPET_SS_LDS_PAD") ? (size_t)atoi(getenv("GPET_SS_LDS_PAD")) : 0;  // (experiments: one workgroup per CU)
+#define GPET_SS_LAUNCH(KS_)                                                                                  \
+  do {                                                                                                       \
+    if (bd.y_f32) hipLaunchKernelGGL((k_sample_score<KS_, true>), grid, block, lds + lds_pad, st, d_edges);  \
+    else hipLaunchKernelGGL((k_sample_score<KS_, false>), grid, block, lds + lds_pad, st, d_edges);          \
+  } while (0)
+    if (ks <= 8) GPET_SS_LAUNCH(8);
+    else if (ks <= 12) GPET_SS_LAUNCH(12);
+    else if (ks <= 16) GPET_SS_LAUNCH(16);
+    else GPET_SS_LAUNCH(18);
+#undef GPET_SS_LAUNCH
+    hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
+  }
+  if (parts & 2u) {
+    if (bd.S <= 1024 && !getenv("GPET_TOPK_RANK")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
+    else hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
+  }
+  if (parts & 4u) {
+    const int gx = cdiv(bd.n_keep, 16);
+    if (bd.y_f32) hipLaunchKernelGGL(k_sample_keep_rows<true>, dim3(gx, B), dim3(256), 0, st, d_edges);
+    else hipLaunchKernelGGL(k_sample_keep_rows<false>, dim3(gx, B), dim3(256), 0, st, d_edges);
   }
   return hipGetLastError();
 }
