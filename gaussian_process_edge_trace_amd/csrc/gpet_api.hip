@@ -181,6 +181,8 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.wt = cv.take<double>(nc);
   E.alpha = cv.take<double>(nc);
   E.chol_inv = cv.take<double>(nc > 128 ? (nc / 64 + 1) * 4096 : 1);
+  E.solve_z = cv.take<double>(nc > 128 ? nc : 1);
+  E.solve_flag = cv.take<int>(nc > 128 ? 2 * (nc / 64 + 1) : 2);
   E.K = cv.take<double>(nc * nc);
   E.V = cv.take<double>(nc * Lg);
   E.mean = cv.take<double>(Lg);
@@ -636,7 +638,8 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     if (getenv("GPET_Z_RING") && atoi(getenv("GPET_Z_RING")) >= 2 && atoi(getenv("GPET_Z_RING")) <= 16) E.z_ring = atoi(getenv("GPET_Z_RING"));  // (experiments)
     // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
     // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
-    E.jlog_cap = (B <= 16 && E.r_cap <= 96) ? 40 : 0;
+    static const int jlog_max_b = getenv("GPET_JLOG_MAX_B") ? atoi(getenv("GPET_JLOG_MAX_B")) : 16;  // (experiments: the rotation-log form for bigger batches)
+    E.jlog_cap = (B <= jlog_max_b && E.r_cap <= 96) ? 40 : 0;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
     E.nu_gen = p.nu;

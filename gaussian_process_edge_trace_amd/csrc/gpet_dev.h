@@ -43,6 +43,8 @@ struct EdgeDev {
   double* alpha;         // [n_cap]
   double* chol_inv;      // [n_cap / 64 + 1][64][64] inverses of L's diagonal blocks (blocked fit, n_cap > 128): the
                          // triangular solves against a panel become matrix products on the matrix cores
+  double* solve_z;       // [n_cap] z = L^-1 y of the multi-workgroup triangular solves (blocked fit, n_cap > 128)
+  int* solve_flag;       // [2][n_cap / 64 + 1] launch number at which block i of z / of alpha was published (k_chol_solve_mw)
   double* V;             // [n_cap*Lg]  L^-1 K_*^T
   double *mean, *std;    // [Lg]
   double* cov;           // [Lg*Lg]

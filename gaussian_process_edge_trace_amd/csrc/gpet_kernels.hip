@@ -3,6 +3,7 @@
 #include "gpet_kernels.h"
 #include "gpet_lbfgsb_dev.h"
 
+#include <atomic>
 #include <math.h>
 #include <stdlib.h>
 
@@ -648,10 +649,9 @@ __global__ void __launch_bounds__(256) k_fit_kbuild(EdgeDev* edges) {
 // History: left-looking with one wave, a dot product of length k per pivot as a chain of LDS round trips: 101 us per block
 // (2.4 of the 6.1 ms of config 3's fit); the block in LDS, right-looking on four waves in batches of eight columns: 54 us,
 // two thirds of it LDS traffic; the block in registers (below).
-__global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
-  const EdgeDev E = edges[blockIdx.y];
-  gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+// (the body: k_chol_diag is one launch of it; k_chol_syrk runs it on the NEXT diagonal block in the workgroup that has just
+//  updated that block -- a launch less per panel in the chain of 24 at n = 1500)
+__device__ __forceinline__ void chol_diag_body(const EdgeDev& E, gpet_scalars* sc, int k0, int with_inv) {
   const int n = sc->n, ld = E.n_cap;
   if (k0 >= n) return;
   const int nb = (n - k0) < CB ? (n - k0) : CB;
@@ -772,6 +772,12 @@ __global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int w
   if (with_inv)  // identity beyond a short last block
     for (int rr = nb + w; rr < CB; rr += 4) inv[rr * CB + i] = (rr == i) ? 1.0 : 0.0;
 }
+__global__ void __launch_bounds__(256) k_chol_diag(EdgeDev* edges, int k0, int with_inv) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  chol_diag_body(E, sc, k0, with_inv);
+}
 
 // row blocks below the diagonal block by SUBSTITUTION (one row per lane of the first wave): the blocked objective of
 // the converged fits keeps it -- the optimiser visits nearly singular matrices (noise 1e-10 of the amplitude) where a
@@ -849,9 +855,10 @@ __global__ void __launch_bounds__(256) k_chol_trsm(EdgeDev* edges, int k0) {
 }
 
 // trailing update A_ij -= X_i X_j^T for the 64x64 tiles (bj <= bi) behind panel k0, v_mfma_f64_16x16x4_f64
-__global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
+// next_diag: the workgroup of the first tile then factors it (the diagonal block of the next panel, with its inverse)
+__global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0, int next_diag) {
   const EdgeDev E = edges[blockIdx.z];
-  const gpet_scalars* sc = E.sc;
+  gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
   const int n = sc->n, ld = E.n_cap;
   const int bi = blockIdx.y, bj = blockIdx.x;
@@ -884,6 +891,10 @@ __global__ void __launch_bounds__(256) k_chol_syrk(EdgeDev* edges, int k0) {
       const int i = i0 + 16 * w + lq + 4 * g, j = j0 + 16 * t + li;
       if (i < n && j <= i) E.K[(size_t)i * ld + j] -= acc[t][g];
     }
+  if (next_diag && bi == 0 && bj == 0) {
+    __syncthreads();  // (the tile is in memory: hipcc's barrier waits for vmcnt(0))
+    chol_diag_body(E, sc, k0 + CB, 1);
+  }
 }
 
 // alpha = L^-T L^-1 y on the factor in HBM, blocked by 64: diagonal blocks through LDS (column form, one wave).  The
@@ -993,20 +1004,166 @@ __global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
   for (int i = tid; i < n; i += bs) E.alpha[i] = s_z[i];
 }
 
+// alpha = L^-T L^-1 y for many training points on one workgroup PER 64-ROW BLOCK (k_chol_solve above is one workgroup per
+// edge: its 2 x 9 MB of L at n = 1500 come through ONE CU's path to L2, 0.66 ms).  Forward (BACK = false): the workgroup
+// of block i subtracts L_ij z_j for j < i as the z_j are published (a flag per block in global memory, its value the
+// launch number: nothing to reset), runs the 64-step substitution of its diagonal block and publishes z_i.  Backward
+// (BACK = true, a second launch): workgroup x owns block nt - 1 - x and subtracts L_ji^T alpha_j for j > i.  In both a
+// workgroup waits only for workgroups with a SMALLER blockIdx.x of the same edge, which the dispatcher started before
+// it: no residency requirement.  z / alpha cross XCDs: agent-scope accesses (as k_oj_persist, gpet_eig.hip); the waiting
+// thread gives up after ~1 s and fails the edge.  The chain per block: flag + 64 values + one 64 x 64 product + the
+// substitution, ~2-3 us.
+template <bool BACK>
+__global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch) {
+  const EdgeDev E = edges[blockIdx.y];
+  gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int n = sc->n, ld = E.n_cap;
+  const int nt = (n + CB - 1) / CB;
+  if ((int)blockIdx.x >= nt) return;
+  const int ib = BACK ? nt - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int k0 = ib * CB;
+  const int nb = (n - k0) < CB ? (n - k0) : CB;
+  __shared__ double sL[CB][CB + 1];
+  __shared__ double s_y[CB], s_v[CB];
+  __shared__ double s_part[4][CB];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  int* flag_mine = E.solve_flag + (BACK ? (ld / CB + 1) : 0);
+  const double* src = BACK ? E.solve_z : E.yt;
+  double* dst = BACK ? E.alpha : E.solve_z;
+  if (tid < CB) s_y[tid] = 0.0;
+  for (int e = tid; e < nb * nb; e += 256) {
+    const int i = e / nb, j = e - i * nb;
+    if (j <= i) sL[i][j] = E.K[(size_t)(k0 + i) * ld + k0 + j];
+  }
+  // the off-diagonal blocks in the order their vectors become available; the next one is in registers before the wait
+  //   forward:  block (ib, j), thread = (row r = tid >> 2, columns 16 (tid & 3) ..): rows of 512 contiguous bytes
+  //   backward: block (j, ib)^T, thread = (column c = tid & 63, rows 16 (tid >> 6) ..): 512 contiguous bytes per row
+  const int nsteps = BACK ? nt - 1 - ib : ib;
+  double lb[16];
+  auto fetch = [&](int step) {
+    const int jb = BACK ? nt - 1 - step : step;
+    const int j0 = jb * CB;
+    const int njb = (n - j0) < CB ? (n - j0) : CB;
+    if (!BACK) {
+      const int r = tid >> 2, c0 = 16 * (tid & 3);
+      const double* row = E.K + (size_t)(k0 + (r < nb ? r : 0)) * ld + j0 + c0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) lb[u] = (r < nb) ? row[u] : 0.0;  // (j < ib: a full block of columns)
+    } else {
+      const int c = tid & 63, r0 = 16 * (tid >> 6);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) lb[u] = (r0 + u < njb && c < nb) ? E.K[(size_t)(j0 + r0 + u) * ld + k0 + c] : 0.0;
+    }
+  };
+  if (nsteps > 0) fetch(0);
+  bool ok = true;
+  for (int step = 0; step < nsteps; ++step) {
+    const int jb = BACK ? nt - 1 - step : step;
+    const int j0 = jb * CB;
+    const int njb = (n - j0) < CB ? (n - j0) : CB;
+    if (tid == 0) {
+      int good = 1;
+      long long spins = 0;
+      while (__hip_atomic_load(flag_mine + jb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1ll << 23)) {
+          good = 0;
+          break;
+        }
+      }
+      s_ok = good;
+    }
+    __syncthreads();
+    if (!s_ok) {
+      ok = false;
+      break;
+    }
+    if (tid < CB) s_v[tid] = (tid < njb) ? __hip_atomic_load(dst + j0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    if (!BACK) {
+      const int c0 = 16 * (tid & 3);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(lb[u], s_v[c0 + u], acc);
+    } else {
+      const int r0 = 16 * (tid >> 6);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fma(lb[u], s_v[r0 + u], acc);
+    }
+    if (step + 1 < nsteps) fetch(step + 1);
+    if (!BACK) {
+      acc += __shfl_xor(acc, 1, 4);
+      acc += __shfl_xor(acc, 2, 4);
+      if ((tid & 3) == 0) s_y[tid >> 2] += acc;
+    } else {
+      s_part[tid >> 6][tid & 63] = acc;
+    }
+    __syncthreads();
+    if (BACK && tid < CB) s_y[tid] += (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+    // (s_v is rewritten only after the next wait's barrier; s_y is touched by the same threads every step)
+  }
+  if (!ok) {
+    if (tid == 0) sc->status = GPET_ERR_STATE;
+    return;
+  }
+  __syncthreads();
+  if (tid < WAVE) {
+    // the 64 dependent steps of the diagonal block (k_chol_solve's: lane j's value through v_readlane, reciprocal diagonal)
+    double z = (tid < nb) ? src[k0 + tid] - s_y[tid] : 0.0;
+    const double rd = (tid < nb) ? 1.0 / sL[tid][tid] : 0.0;
+    if (!BACK) {
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        if (j < nb) {
+          const double zj = lane_f64(z, j) * lane_f64(rd, j);
+          if (tid == j) z = zj;
+          if (tid > j && tid < nb) z -= sL[tid][j] * zj;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = CB - 1; j >= 0; --j) {
+        if (j < nb) {
+          const double aj = lane_f64(z, j) * lane_f64(rd, j);
+          if (tid == j) z = aj;
+          if (tid < j) z -= sL[j][tid] * aj;
+        }
+      }
+    }
+    if (tid < nb) __hip_atomic_store(dst + k0 + tid, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();  // (the stores are out: hipcc's barrier waits for vmcnt(0))
+  if (tid == 0) __hip_atomic_store(flag_mine + ib, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // the whole fit for n_cap > 128
 static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   const int nt = cdiv(bd.n_cap, CB);
   hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(long long), st, d_edges);
   hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
+  // per panel: [diagonal block] -> rows below it -> trailing update, whose first workgroup goes on to factor the next
+  // diagonal block (GPET_DIAG_IN_SYRK=0: a launch of its own per diagonal block)
+  static const int diag_in_syrk = getenv("GPET_DIAG_IN_SYRK") ? atoi(getenv("GPET_DIAG_IN_SYRK")) : 1;
   for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, 1);
+    if (k0 == 0 || !diag_in_syrk) hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, 1);
     const int below = cdiv(bd.n_cap - k0 - CB, CB);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);
-      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0, diag_in_syrk);
     }
   }
-  hipLaunchKernelGGL(k_chol_solve, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  // alpha: one workgroup per 64-row block and direction (GPET_SOLVE_MW=0: the single-workgroup kernel)
+  static const int solve_mw = getenv("GPET_SOLVE_MW") ? atoi(getenv("GPET_SOLVE_MW")) : 1;
+  if (solve_mw) {
+    static std::atomic<int> launch_no{0};
+    const int epoch = ++launch_no;  // (flags hold the number of the launch that published them: never reset)
+    hipLaunchKernelGGL(k_chol_solve_mw<false>, dim3(nt, B), dim3(256), 0, st, d_edges, epoch);
+    hipLaunchKernelGGL(k_chol_solve_mw<true>, dim3(nt, B), dim3(256), 0, st, d_edges, epoch);
+  } else {
+    hipLaunchKernelGGL(k_chol_solve, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(double), st, d_edges);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -5758,7 +5915,7 @@ hipError_t launch_lml_big(hipStream_t st, EdgeDev* d_edges, int P, int n_max, co
     const int below = cdiv(n_max - k0 - CB, CB);
     if (below > 0) {
       hipLaunchKernelGGL(k_chol_trsm_sub, dim3(below, P), dim3(256), 0, st, ve, k0);
-      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, P), dim3(256), 0, st, ve, k0);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, P), dim3(256), 0, st, ve, k0, 0);
     }
   }
   hipLaunchKernelGGL(k_chol_solve, dim3(1, P), dim3(256), (size_t)ncap_v * sizeof(double), st, ve);
@@ -5815,7 +5972,11 @@ __global__ void __launch_bounds__(256) k_kstar_build(EdgeDev* edges) {
 //   X = K_*^T[k0.., cols] - sum_{j0 < k0} L[k0.., j0..] V[j0.., cols]   (64 x 64 by 64 x 32 products, left-looking),
 //   V[k0.., cols] = L_kk^-1 X   (the inverse of the diagonal block from k_chol_diag).
 // Wave w owns rows 16 w .. 16 w + 15 of the block and both 16-column halves.
-#define VS_COLS 32
+#ifndef VS_COLS
+#define VS_COLS 16  // grid columns per workgroup (16, 32 or 64 by -DVS_COLS=..; at n = 1500, Lg = 2048: 3.42 / 3.62 / 4.09 ms per fit + predict + covariance)
+#endif
+#define VS_NH (VS_COLS / 16)          // 16-column halves per wave
+#define VS_PU (CB * VS_COLS / 256)    // prefetch registers of the V block per thread
 __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
@@ -5827,11 +5988,12 @@ __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
   __shared__ double sL[CB][CB + 1];
   __shared__ double sU[CB][VS_COLS + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
-  v4f64c acc[2];
-  acc[0] = acc[1] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+  v4f64c acc[VS_NH];
+#pragma unroll
+  for (int h = 0; h < VS_NH; ++h) acc[h] = (v4f64c){0.0, 0.0, 0.0, 0.0};
   // the blocks of the next j0 are loaded into registers while the matrix cores work on the current ones (a launch has
   // only Lg / 32 workgroups: nothing else hides the two dependent round trips per block otherwise -- 85 -> ~25 us)
-  double pl[16], pu[8];
+  double pl[16], pu[VS_PU];
   auto fetch = [&](int j0) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -5839,8 +6001,8 @@ __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
       pl[u] = (i < nb) ? E.K[(size_t)(k0 + i) * ld + j0 + t] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = tid + 256 * u, t = e >> 5, a = e & 31;
+    for (int u = 0; u < VS_PU; ++u) {
+      const int e = tid + 256 * u, t = e / VS_COLS, a = e % VS_COLS;
       pu[u] = (a0 + a < Lg) ? E.V[(size_t)(j0 + t) * Lg + a0 + a] : 0.0;
     }
   };
@@ -5853,17 +6015,17 @@ __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
       sL[e >> 6][e & 63] = pl[u];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < VS_PU; ++u) {
       const int e = tid + 256 * u;
-      sU[e >> 5][e & 31] = pu[u];
+      sU[e / VS_COLS][e % VS_COLS] = pu[u];
     }
     __syncthreads();
     if (j0 + CB < k0) fetch(j0 + CB);
 #pragma unroll
     for (int kk = 0; kk < CB; kk += 4) {
       const double a = sL[16 * w + li][kk + lq];
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][li], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 + li], acc[1], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < VS_NH; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 * h + li], acc[h], 0, 0, 0);
     }
   }
   __syncthreads();
@@ -5871,22 +6033,23 @@ __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
   const double* inv = E.chol_inv + (size_t)(k0 / CB) * CB * CB;
   for (int e = tid; e < CB * CB; e += 256) sL[e >> 6][e & 63] = inv[e];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < VS_NH; ++h)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int i = 16 * w + lq + 4 * g, a = 16 * h + li;
       sU[i][a] = (i < nb && a0 + a < Lg) ? E.V[(size_t)(k0 + i) * Lg + a0 + a] - acc[h][g] : 0.0;
     }
   __syncthreads();
-  acc[0] = acc[1] = (v4f64c){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < VS_NH; ++h) acc[h] = (v4f64c){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kk = 0; kk < CB; kk += 4) {
     const double a = sL[16 * w + li][kk + lq];
-    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][li], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 + li], acc[1], 0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < VS_NH; ++h) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sU[kk + lq][16 * h + li], acc[h], 0, 0, 0);
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < VS_NH; ++h)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int i = 16 * w + lq + 4 * g, a = 16 * h + li;
@@ -5894,34 +6057,47 @@ __global__ void __launch_bounds__(256) k_vsolve_mfma(EdgeDev* edges, int k0) {
     }
 }
 
-// mean_j = y_std * sum_i K_*[i][j] alpha_i + y_mean   (sklearn_gpr.py:381-385; before V is overwritten)
-__global__ void __launch_bounds__(256) k_pred_mean_big(EdgeDev* edges) {
+// Column sums over the n rows of V for many training points: a workgroup owns 16 grid columns, its 16 row-lanes take every
+// sixteenth row each (independent loads, a wave reads four rows of 128 contiguous bytes per instruction) and their
+// partial sums are added in row-lane order.  (One thread per column walking all n rows -- Lg / 256 workgroups on the
+// whole GPU -- took 0.39 + 0.36 ms at n = 1500, Lg = 2048.)
+//   STD = false: mean_j = y_std * sum_i K_*[i][j] alpha_i + y_mean   (sklearn_gpr.py:381-385; before V is overwritten)
+//   STD = true:  std_j = sqrt(max(amp - sum_i V[i][j]^2, 0) * y_std^2)   (sklearn_gpr.py:414-436)
+#define PB_COLS 16
+#define PB_LANES 16
+template <bool STD>
+__global__ void __launch_bounds__(PB_COLS * PB_LANES) k_pred_colsum_big(EdgeDev* edges) {
   const EdgeDev E = edges[blockIdx.y];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  __shared__ double s_part[PB_LANES][PB_COLS + 1];
   const int n = sc->n, Lg = E.Lg;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Lg) return;
-  double msum = 0.0;
-  for (int i = 0; i < n; ++i) msum += E.V[(size_t)i * Lg + j] * E.alpha[i];
-  E.mean[j] = sc->y_std * msum + sc->y_mean;
-}
-// std_j = sqrt(max(amp - sum_i V[i][j]^2, 0) * y_std^2)   (sklearn_gpr.py:414-436)
-__global__ void __launch_bounds__(256) k_pred_std_big(EdgeDev* edges) {
-  const EdgeDev E = edges[blockIdx.y];
-  const gpet_scalars* sc = E.sc;
-  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  const int n = sc->n, Lg = E.Lg;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Lg) return;
-  double vsum = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double v = E.V[(size_t)i * Lg + j];
-    vsum += v * v;
+  const int c = threadIdx.x & (PB_COLS - 1), r = threadIdx.x / PB_COLS;
+  const int j = blockIdx.x * PB_COLS + c;
+  const GPET_GLOBAL double* __restrict__ Vg = as_global(E.V);
+  const GPET_GLOBAL double* __restrict__ al = as_global(E.alpha);
+  double sum = 0.0;
+  if (j < Lg) {
+#pragma unroll 8
+    for (int i = r; i < n; i += PB_LANES) {
+      const double v = Vg[(size_t)i * Lg + j];
+      sum += STD ? v * v : v * al[i];
+    }
   }
-  double var = sc->amp - vsum;
-  if (var < 0.0) var = 0.0;
-  E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
+  s_part[r][c] = sum;
+  __syncthreads();
+  if (r == 0 && j < Lg) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < PB_LANES; ++q) t += s_part[q][c];
+    if (STD) {
+      double var = sc->amp - t;
+      if (var < 0.0) var = 0.0;
+      E.std[j] = sqrt(var * (sc->y_std * sc->y_std));
+    } else {
+      E.mean[j] = sc->y_std * t + sc->y_mean;
+    }
+  }
 }
 
 // hipFuncSetAttribute applies to the CURRENT device: remember per device what has been raised, so that one process
@@ -5960,10 +6136,10 @@ hipError_t launch_fit_predict(hipStream_t st, EdgeDev* d_edges, int B, const Bat
   } else if (bd.n_cap > 128 && plds > 150 * 1024) {
     // many training points: V through HBM, blocked substitution with the panel kernel of the structured path
     hipLaunchKernelGGL(k_kstar_build, dim3(cdiv(bd.Lg, 64), 64, B), dim3(256), 0, st, d_edges);
-    hipLaunchKernelGGL(k_pred_mean_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_pred_colsum_big<false>, dim3(cdiv(bd.Lg, PB_COLS), B), dim3(PB_COLS * PB_LANES), 0, st, d_edges);
     for (int k0 = 0; k0 < bd.n_cap; k0 += CB)
       hipLaunchKernelGGL(k_vsolve_mfma, dim3(cdiv(bd.Lg, VS_COLS), B), dim3(256), 0, st, d_edges, k0);
-    hipLaunchKernelGGL(k_pred_std_big, dim3(cdiv(bd.Lg, 256), B), dim3(256), 0, st, d_edges);
+    hipLaunchKernelGGL(k_pred_colsum_big<true>, dim3(cdiv(bd.Lg, PB_COLS), B), dim3(PB_COLS * PB_LANES), 0, st, d_edges);
   } else if (plds <= 150 * 1024)
     hipLaunchKernelGGL((k_predict<true, false>), dim3(cdiv(bd.Lg, 64), B), dim3(64), plds, st, d_edges, 0);
   else
