@@ -3285,7 +3285,7 @@ __device__ __forceinline__ const GPET_GLOBAL T* as_global(const T* p) {
 // an LDS read and a global load into the same registers -- and at their join the compiler waits for BOTH counters: every
 // store of a column group then waited (vmcnt(0)) for all the stores before it.
 template <int KS, bool F32, bool MU_LDS>
-__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part) {
+__device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_scalars* sc, double* s_fa, int part, int cpart, int ncs) {
   constexpr bool mu_lds = MU_LDS;
   typedef typename YT<F32>::type yt;
   GPET_GLOBAL yt* __restrict__ Yo = as_global(reinterpret_cast<yt*>(E.Y));
@@ -3294,6 +3294,12 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
   constexpr int PF = (KS * 4 * 64) / 512;  // prefetch registers per thread (KS even)
   const int Lg = E.Lg, S = E.S, zc = E.z_cols;
   const int s0 = part * 128;
+  // the 64-column tiles [jlo, jhi) of this workgroup: all of them, or one of ncs runs of tiles when few edges leave the
+  // GPU empty (a single edge: 8 row blocks x 8 column runs instead of 8 workgroups sweeping 500 columns each)
+  const int tpc = ((Lg + 63) / 64 + ncs - 1) / ncs;
+  const int jlo = cpart * tpc * 64;
+  const int jhi = (jlo + tpc * 64 < Lg) ? (jlo + tpc * 64) : Lg;
+  if (jlo >= Lg) return;
   const int rows = sc->rank;
   const GPET_GLOBAL double* __restrict__ Zs = as_global(E.Z) + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -3316,10 +3322,10 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int e = tid + 512 * u;
-    const int kk = e >> 6, j = e & 63;
+    const int kk = e >> 6, j = jlo + (e & 63);
     pf[u] = (kk < rows && j < Lg) ? Ag[(size_t)kk * Lg + j] : 0.0;
   }
-  for (int j0 = 0; j0 < Lg; j0 += 64) {
+  for (int j0 = jlo; j0 < jhi; j0 += 64) {
     __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -3327,7 +3333,7 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
       s_fa[(e >> 6) * GEMM_LDA + (e & 63)] = pf[u];
     }
     __syncthreads();
-    if (j0 + 64 < Lg) {  // next tile's chunk: loads stay in flight during the MFMAs below
+    if (j0 + 64 < jhi) {  // next tile's chunk: loads stay in flight during the MFMAs below
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int e = tid + 512 * u;
@@ -3388,26 +3394,28 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 // rank multiplies a few zero rows): register allocation is per kernel, and the variants up to K = 72 fit the
 // 128 VGPRs that let two workgroups share a CU, so one's staging and stores overlap the other's MFMAs.
 template <int KS, bool F32, bool MU_LDS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_gemm_mfma_r(EdgeDev* edges, int ncs) {
   int edge, part;  // the row blocks of an edge on one XCD: its factor comes out of HBM once, not once per row block
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  if (part * 128 >= E.S) return;
+  const int rparts = (int)gridDim.x / ncs, rp = part % rparts, cp = part / rparts;
+  if (rp * 128 >= E.S) return;
   extern __shared__ double s_fa[];  // [4 KS][GEMM_LDA]
-  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, part);
+  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, rp, cp, ncs);
 }
 template <int KS, bool F32, bool MU_LDS>
-__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges) {  // (K > 72: one workgroup per CU)
+__global__ void __launch_bounds__(512) k_sample_gemm_mfma_rl(EdgeDev* edges, int ncs) {  // (K > 72: one workgroup per CU)
   int edge, part;
   xcd_edge_part((int)gridDim.x, edge, part);
   const EdgeDev E = edges[edge];
   const gpet_scalars* sc = E.sc;
   if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
-  if (part * 128 >= E.S) return;
+  const int rparts = (int)gridDim.x / ncs, rp = part % rparts, cp = part / rparts;
+  if (rp * 128 >= E.S) return;
   extern __shared__ double s_fa[];
-  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, part);
+  sample_gemm_body<KS, F32, MU_LDS>(E, sc, s_fa, rp, cp, ncs);
 }
 
 // cov = (amp*rho(x*,x*) - V^T V) * y_std^2 on the matrix cores (same tiling as k_sample_gemm_mfma):
@@ -3691,7 +3699,7 @@ __device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const dou
 }
 
 template <bool F32>
-__global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
+__global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges, int curves_per_wg) {
   typedef typename YT<F32>::type yt;
   // the tiles of an edge on one XCD: neighbouring tiles split cache lines of the sample rows (a tile's 256-byte runs
   // start on 32-byte boundaries), which then come out of HBM once instead of once per L2
@@ -3719,8 +3727,10 @@ __global__ void __launch_bounds__(SC_THREADS) k_score_tile(EdgeDev* edges) {
   const int pl = tid & 15;  // pair within the tile (15: the first pair of the next tile, as a source of data only)
   const int i = p0 + pl;
   const int k = 2 * i;
-  const int s_lo = byy * SC_CURVES;
-  const int s_hi = (s_lo + SC_CURVES < S) ? (s_lo + SC_CURVES) : S;
+  // (curves_per_wg: SC_CURVES, or fewer when few edges leave the GPU empty -- a multiple of the 64 curves of a pass)
+  const int s_lo = byy * curves_per_wg;
+  const int s_hi = (s_lo + curves_per_wg < S) ? (s_lo + curves_per_wg) : S;
+  if (s_lo >= S) return;
   GPET_GLOBAL double* __restrict__ cpart = as_global(E.cost_part) + ((size_t)bx * S) * 2;
   // the samples of the NEXT group of curves are requested before this group is worked on: the loop is bound by the
   // latency of these loads (8 waves per SIMD do not cover an HBM round trip per 600 cycles of work on their own)
@@ -6495,7 +6505,12 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
   if (bd.r_cap <= GEMM_KMAX && bd.a_rows_cap <= GEMM_KMAX) {
     const int rm = rank_max > 0 && rank_max <= bd.r_cap ? rank_max : (bd.r_cap > bd.a_rows_cap ? bd.r_cap : bd.a_rows_cap);
     const int ks = (rm + 3) >> 2;
-    const dim3 grid(cdiv(bd.S, 128), B), block(512);
+    // column runs per row block: while the row blocks alone leave CUs empty (small batches are latency chains)
+    const int rparts = cdiv(bd.S, 128), ctiles = cdiv(bd.Lg, 64);
+    int ncs = cdiv(256, B * rparts);
+    ncs = ncs > ctiles ? ctiles : (ncs < 1 ? 1 : ncs);
+    if (ncs > 8) ncs = 8;
+    const dim3 grid(rparts * ncs, B), block(512);
     {  // (the chunk plus the posterior mean of a wide edge exceed the 64 KB a kernel gets without asking: 66 KB at K = 96, Lg = 2048)
       static PerDeviceOnce once;
       if (once.first()) {
@@ -6518,10 +6533,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
 #define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
   do {                                                                                                                                 \
     const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
-    if (bd.y_f32 && mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, true, true>), grid, block, lds_, st, d_edges);                        \
-    else if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true, false>), grid, block, lds_, st, d_edges);                               \
-    else if (mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, false, true>), grid, block, lds_, st, d_edges);                              \
-    else hipLaunchKernelGGL((KERNEL<KS_, false, false>), grid, block, lds_, st, d_edges);                                            \
+    if (bd.y_f32 && mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, true, true>), grid, block, lds_, st, d_edges, ncs);                        \
+    else if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true, false>), grid, block, lds_, st, d_edges, ncs);                               \
+    else if (mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, false, true>), grid, block, lds_, st, d_edges, ncs);                              \
+    else hipLaunchKernelGGL((KERNEL<KS_, false, false>), grid, block, lds_, st, d_edges, ncs);                                            \
   } while (0)
     if (ks <= 8) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 8);
     else if (ks <= 12) GPET_GEMM_LAUNCH(k_sample_gemm_mfma_r, 12);
@@ -6548,8 +6563,11 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
         (void)hipFuncSetAttribute((const void*)k_score_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       }
       const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
-      if (bd.y_f32) hipLaunchKernelGGL(k_score_tile<true>, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
-      else hipLaunchKernelGGL(k_score_tile<false>, dim3(n_tiles, cdiv(bd.S, SC_CURVES), B), dim3(SC_THREADS), lds, st, d_edges);
+      // curves per workgroup: 1024, or down to 128 while the tiles alone leave CUs empty (every part stages the slab again)
+      int cpw = SC_CURVES;
+      while (cpw > 128 && B * n_tiles * cdiv(bd.S, cpw) < 256) cpw >>= 1;
+      if (bd.y_f32) hipLaunchKernelGGL(k_score_tile<true>, dim3(n_tiles, cdiv(bd.S, cpw), B), dim3(SC_THREADS), lds, st, d_edges, cpw);
+      else hipLaunchKernelGGL(k_score_tile<false>, dim3(n_tiles, cdiv(bd.S, cpw), B), dim3(SC_THREADS), lds, st, d_edges, cpw);
       hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
     } else {
       if (bd.y_f32) hipLaunchKernelGGL(k_score<true>, dim3(cdiv(bd.S, 4), B), dim3(256), 0, st, d_edges);
