@@ -352,6 +352,12 @@ int gpet_set_option(const char* name, int value) {
     v = value;
     return old;
   }
+  if (name && (strcmp(name, "solve_mw") == 0 || strcmp(name, "diag_in_syrk") == 0)) {
+    int& v = name[0] == 's' ? gpet_opt_solve_mw() : gpet_opt_diag_in_syrk();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "fused_score") == 0) {
     int& v = gpet_opt_fused_score();
     const int old = v;

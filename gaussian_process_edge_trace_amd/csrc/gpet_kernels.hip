@@ -1138,6 +1138,17 @@ __global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch
   if (tid == 0) __hip_atomic_store(flag_mine + ib, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// gpet_set_option "solve_mw" (default 1; environment GPET_SOLVE_MW): 0 = alpha of the blocked fit by the single-workgroup
+// kernel; "diag_in_syrk" (default 1; GPET_DIAG_IN_SYRK): 0 = a launch of its own for every diagonal block
+int& gpet_opt_solve_mw() {
+  static int v = getenv("GPET_SOLVE_MW") ? atoi(getenv("GPET_SOLVE_MW")) : 1;
+  return v;
+}
+int& gpet_opt_diag_in_syrk() {
+  static int v = getenv("GPET_DIAG_IN_SYRK") ? atoi(getenv("GPET_DIAG_IN_SYRK")) : 1;
+  return v;
+}
+
 // the whole fit for n_cap > 128
 static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
   const int nt = cdiv(bd.n_cap, CB);
@@ -1145,7 +1156,7 @@ static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
   // per panel: [diagonal block] -> rows below it -> trailing update, whose first workgroup goes on to factor the next
   // diagonal block (GPET_DIAG_IN_SYRK=0: a launch of its own per diagonal block)
-  static const int diag_in_syrk = getenv("GPET_DIAG_IN_SYRK") ? atoi(getenv("GPET_DIAG_IN_SYRK")) : 1;
+  const int diag_in_syrk = gpet_opt_diag_in_syrk() ? 1 : 0;
   for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
     if (k0 == 0 || !diag_in_syrk) hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, 1);
     const int below = cdiv(bd.n_cap - k0 - CB, CB);
@@ -1155,8 +1166,7 @@ static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const Ba
     }
   }
   // alpha: one workgroup per 64-row block and direction (GPET_SOLVE_MW=0: the single-workgroup kernel)
-  static const int solve_mw = getenv("GPET_SOLVE_MW") ? atoi(getenv("GPET_SOLVE_MW")) : 1;
-  if (solve_mw) {
+  if (gpet_opt_solve_mw()) {
     static std::atomic<int> launch_no{0};
     const int epoch = ++launch_no;  // (flags hold the number of the launch that published them: never reset)
     hipLaunchKernelGGL(k_chol_solve_mw<false>, dim3(nt, B), dim3(256), 0, st, d_edges, epoch);

@@ -65,6 +65,43 @@ def test_config3_large_n_gp_iteration(amd, ctx):
     assert np.array_equal(b.read(L.BUF_BEST_IDX), np.argsort(oc, kind="stable")[:400])
 
 
+def test_blocked_fit_variants_agree(amd, ctx):
+    """More than 128 training points: alpha by one workgroup per 64-row block (k_chol_solve_mw, published blocks) against the
+    single-workgroup solve, and the diagonal blocks factored inside the trailing update against a launch of their own --
+    the same factor bit for bit, alpha / mean / std to rounding (sklearn_gpr.py:304-320, 381-436)."""
+    L = amd._lib
+    N = 1024
+    img, truth = orc.synth_sinusoid_image(N, 2)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    rng = np.random.default_rng(1)
+    cols = np.sort(rng.choice(np.arange(1, N - 1), size=437, replace=False))  # 439 training points: 7 blocks, a short last one
+    obs = np.stack([cols, truth[cols, 0] + rng.integers(-2, 3, size=cols.size)], axis=1).astype(np.int64)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 150, 'length_scale': 40}, noise_y=1, N_samples=256,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, obs=obs, **kw, _ctx=ctx)
+    b = tr._batch
+    res = {}
+    for mw, dis in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        old = (L.set_option("solve_mw", mw), L.set_option("diag_in_syrk", dis))
+        try:
+            b.set_obs(0, obs)
+            b.fit_predict(want_cov=False)
+            n = b.scalars().n
+            res[(mw, dis)] = (b.read(L.BUF_CHOL), b.read(L.BUF_ALPHA), b.read(L.BUF_MEAN), b.read(L.BUF_STD))
+        finally:
+            L.set_option("solve_mw", old[0])
+            L.set_option("diag_in_syrk", old[1])
+    assert n == 439
+    ref = res[(0, 0)]
+    for key, (chol, alpha, mean, std) in res.items():
+        assert np.array_equal(np.tril(chol), np.tril(ref[0])), key
+        np.testing.assert_allclose(alpha, ref[1], rtol=1e-9, atol=1e-11 * np.abs(ref[1]).max(), err_msg=str(key))
+        np.testing.assert_allclose(mean, ref[2], rtol=1e-10, err_msg=str(key))
+        np.testing.assert_allclose(std, ref[3], rtol=1e-9, atol=1e-12, err_msg=str(key))
+    assert np.array_equal(res[(1, 1)][1], res[(1, 0)][1]) and np.array_equal(res[(0, 1)][1], res[(0, 0)][1])
+
+
 def test_config5_matern_frame_with_warm_start(amd, ctx):
     """1024^2 frame, Matern-5/2 (sigma_f ~ 154, l ~ 41), warm start from every 16th pixel of a
     previous trace (fewer than algo_thresh points): the whole device trace vs the oracle run with
