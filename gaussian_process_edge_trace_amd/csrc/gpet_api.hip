@@ -218,6 +218,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.kde = cv.take<float>(px);
   E.kde_band = cv.take<int>(2 * ((size_t)E.N / 16 + 2));
   E.colsum = cv.take<double>((size_t)E.N);
+  E.kde_wsum = cv.take<double>(2);
   E.colbest = cv.take<double>((size_t)E.N);
   E.colbest_y = cv.take<int>((size_t)E.N);
   E.mm = cv.take<unsigned int>(4);

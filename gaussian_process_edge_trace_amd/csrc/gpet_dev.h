@@ -79,6 +79,7 @@ struct EdgeDev {
   double* tmpk;          // [(N+2)*(M+2)] separable-convolution scratch
   float* kde;            // [M*N] normalised curve KDE (stage API); inside gpet_trace_iterate: raw density, band rows only
   int* kde_band;         // [N/16 + 1][2] first / last image row with density, per 16-column tile of the fused KDE
+  double* kde_wsum;      // [1] total weight of the gradient KDE's points (sum of colsum in index order; k_kde_wsum)
   double* colsum;        // [N] kept weight per column
   double* colbest;       // [N] best new-pixel score per column
   int* colbest_y;        // [N] row of that pixel
