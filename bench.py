@@ -103,39 +103,54 @@ def usable_cpus():
     return max(2, n)
 
 
-def timed_steps(tracers, n_steps, depth, executor, fit_walls):
-    """n_steps passes of the hot path over the batch objects in `tracers` (round robin).  Pipelined (depth > 0): while the
-    converged fits of step k run -- device-resident L-BFGS-B, ~80 rounds of small launches on the batch's fit stream,
-    driven by a host thread that only enqueues and waits -- the device loop of step k+1 runs on another batch object /
-    HIP stream.  Returns (seconds in device loops, seconds of fits nothing overlapped, iterations, traces of the last step)."""
-    loop_s = fit_s = 0.0
-    iters_, traces_, pending = [], None, []
-    for k in range(n_steps):
-        tr_ = tracers[k % len(tracers)]
-        while len(pending) > depth:  # a batch object is reused only after its previous fits were collected
-            traces_ = pending.pop(0).result()
-        t_a = time.time()
-        tr_.reset()
-        iters_ = tr_.run_loop()
-        t_b2 = time.time()
-        loop_s += t_b2 - t_a
-        if depth > 0:
-            def timed_finish(tr__=tr_, it__=iters_):
-                t_f = time.time()
-                out_ = tr__.finish(it__)
-                fit_walls.append(time.time() - t_f)
-                return out_
-            pending.append(executor.submit(timed_finish))
-        else:
+def timed_steps(tracers, n_steps, depth, executor, fit_walls, loop_walls=None):
+    """n_steps passes of the hot path over the batch objects in `tracers`.  depth > 0: len(tracers) WHOLE traces in flight
+    -- one host thread per batch object runs reset -> device loop -> converged fits for its share of the steps (step k on
+    object k mod W), every object on its own HIP stream.  The GPU then always has the loop of one batch, the fits of
+    another (device-resident L-BFGS-B, ~80 rounds of small launches) and the thinly populated last iterations of a third
+    to choose from: 7.2-7.4 k edge-traces/s with three objects against 6.8-6.9 k when only one device loop ran at a time
+    beside the previous steps' fits (tools/time_concurrent_loops.py).  depth = 0: one object, loop then fits, nothing
+    overlapped.  Returns (loop wall time per worker, fit wall time per worker -- sums over its steps, averaged over the
+    workers --, iterations and traces of the last step)."""
+    if loop_walls is None:
+        loop_walls = []
+    if depth <= 0 or len(tracers) == 1:
+        loop_s = fit_s = 0.0
+        iters_, traces_ = [], None
+        tr_ = tracers[0]
+        for k in range(n_steps):
+            t_a = time.time()
+            tr_.reset()
+            iters_ = tr_.run_loop()
+            t_b = time.time()
             traces_ = tr_.finish(iters_)
-            fit_walls.append(time.time() - t_b2)
-            fit_s += time.time() - t_b2
-    t_c = time.time()
-    while pending:
-        traces_ = pending.pop(0).result()
-    if depth > 0:
-        fit_s += time.time() - t_c
-    return loop_s, fit_s, iters_, traces_
+            t_c = time.time()
+            loop_walls.append(t_b - t_a)
+            fit_walls.append(t_c - t_b)
+            loop_s += t_b - t_a
+            fit_s += t_c - t_b
+        return loop_s, fit_s, iters_, traces_
+    W = min(len(tracers), n_steps)
+    lw, fw = [[] for _ in range(W)], [[] for _ in range(W)]
+
+    def worker(w):
+        tr_, its, out = tracers[w], [], None
+        for k in range(w, n_steps, W):  # (a batch object is only ever used by its own thread)
+            t_a = time.time()
+            tr_.reset()
+            its = tr_.run_loop()
+            t_b = time.time()
+            out = tr_.finish(its)
+            lw[w].append(t_b - t_a)
+            fw[w].append(time.time() - t_b)
+        return its, out
+
+    res = list(executor.map(worker, range(W)))
+    for w in range(W):
+        loop_walls.extend(lw[w])
+        fit_walls.extend(fw[w])
+    iters_, traces_ = res[(n_steps - 1) % W]
+    return sum(map(sum, lw)) / W, sum(map(sum, fw)) / W, iters_, traces_
 
 
 def secondary_config3(pkg, ctx):
@@ -223,7 +238,7 @@ def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--edges", type=int, default=2048,
                     help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges; "
@@ -232,7 +247,7 @@ def main():
                          "the 256-edge figure of config 4 is reported next to it)")
     ap.add_argument("--size", type=int, default=500)
     ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="how many steps' converged fits may be in flight behind the device loops (batch objects = depth+1; 0 = none)")
+                    help="whole traces in flight = depth + 1 batch objects, each driven by its own host thread on its own HIP stream (0 = one object, nothing overlapped)")
     ap.add_argument("--cpu-traces", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ctor included, 256 edges, "
@@ -318,14 +333,15 @@ def main():
             dist.barrier()
 
     from concurrent.futures import ThreadPoolExecutor
-    executor = ThreadPoolExecutor(max_workers=max(1, depth))
-    fit_walls = []  # wall time of every step's converged fits (they run concurrently with later device loops)
+    executor = ThreadPoolExecutor(max_workers=depth + 1)
+    fit_walls, loop_walls = [], []  # wall time of every step's converged fits / device loop (other steps' run beside them)
 
     def run_steps(n_steps, timed):
         fit_walls.clear()
-        loop_s, fit_s, iters_, traces_ = timed_steps(tracers, n_steps, depth, executor, fit_walls)
+        loop_walls.clear()
+        loop_s, fit_s, iters_, traces_ = timed_steps(tracers, n_steps, depth, executor, fit_walls, loop_walls)
         if timed:
-            log("%d step(s): device loops %.3fs, fits %s" % (n_steps, loop_s, ("%.3fs" % fit_s) if not pipeline else "overlapped (tail %.3fs)" % fit_s))
+            log("%d step(s), %d in flight: per host thread %.3fs in device loops, %.3fs in converged fits" % (n_steps, len(tracers), loop_s, fit_s))
         return loop_s, fit_s, iters_, traces_
 
     log("rank %d: batch of %d edges ready%s" % (rank, E, " (pipelined, %d batch objects)" % len(tracers) if pipeline else ""))
@@ -604,14 +620,17 @@ def main():
                    "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
                                 "all on the GPU (gpet_final_fit_all); no host workers"},
         "host": {"cpus_usable": usable_cpus(), "cpus_machine": os.cpu_count(), "lbfgs_workers": 0,
-                 "host_threads": 1 + max(1, depth), "note": "the host only enqueues launches and waits: one driver thread for the "
-                 "device loops plus one per converged fit in flight"},
+                 "host_threads": depth + 1, "note": "the host only enqueues launches and waits: one driver thread per batch object "
+                 "in flight (its device loop, then its converged fits)"},
         "secondary": secondary,
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},
         "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
-        "time_split_s": {"device_loop": loop_s, "final_fit_not_overlapped": fit_s, "elapsed": elapsed, "pipelined": pipeline, "pipeline_depth": depth,
-                         "fit_wall_mean": (sum(fit_walls) / len(fit_walls)) if fit_walls else None},
+        "time_split_s": {"elapsed": elapsed, "steps_in_flight": len(tracers), "pipelined": pipeline, "pipeline_depth": depth,
+                         "loop_wall_per_thread": loop_s, "fit_wall_per_thread": fit_s,
+                         "loop_wall_mean": (sum(loop_walls) / len(loop_walls)) if loop_walls else None,
+                         "fit_wall_mean": (sum(fit_walls) / len(fit_walls)) if fit_walls else None,
+                         "note": "wall times of a step's device loop and converged fits while the other objects' steps run beside them"},
         "single_edge": {"traces_per_s": 1.0 / single_s, "ms_per_trace": 1e3 * single_s,
                         "runs_ms": [round(1e3 * v, 3) for v in single_runs], "note": "median of five traces of one edge"},
         "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b,
