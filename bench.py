@@ -240,13 +240,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--edges", type=int, default=2048,
-                    help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges; "
-                         "the loop's kernels are latency-bound below ~4 workgroups per CU and every kernel has a tail of partly filled CUs, so the "
-                         "default is 8 edges per CU: 6.6 k traces/s at 1024, 6.9 k at 2048, 7.1 k at 4096 (100 GB per batch object); "
-                         "the 256-edge figure of config 4 is reported next to it)")
+    ap.add_argument("--edges", type=int, default=1024,
+                    help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges).  With "
+                         "several steps in flight (--pipeline-depth) the throughput no longer depends on the batch size: 7.3-7.4 k "
+                         "traces/s at 1024 x 6, 2048 x 3 or 4096 x 3 objects; one step at a time it was 6.6 k at 1024, 6.9 k at 2048, "
+                         "7.1 k at 4096.  The 256-edge figure of config 4 is reported next to it")
     ap.add_argument("--size", type=int, default=500)
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--pipeline-depth", type=int, default=5,
                     help="whole traces in flight = depth + 1 batch objects, each driven by its own host thread on its own HIP stream (0 = one object, nothing overlapped)")
     ap.add_argument("--cpu-traces", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -400,13 +400,14 @@ def main():
         for tr_ in tracers:
             tr_._ctx.sync()
         t1 = time.time()
-        _, _, it_f32, tr_f32 = timed_steps(tracers, 4, depth, executor, [])
+        n_sec = 2 * len(tracers)  # steps of a secondary run: two per batch object in flight
+        _, _, it_f32, tr_f32 = timed_steps(tracers, n_sec, depth, executor, [])
         for tr_ in tracers:
             tr_._ctx.sync()
         dt_f32 = time.time() - t1
         for tr_ in tracers:
             tr_._batch.set_sample_dtype("f64")
-        secondary["f32_samples"] = dict(traces_per_s=4 * E / dt_f32, ms_per_step=1e3 * dt_f32 / 4, edges=E,
+        secondary["f32_samples"] = dict(traces_per_s=n_sec * E / dt_f32, ms_per_step=1e3 * dt_f32 / n_sec, edges=E,
                                         trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_f32])),
                                         note="sample GEMM stores f32, scorer/KDE widen; all arithmetic f64; opt-in, "
                                              "tests/test_gpu_trace.py::test_full_trace_f32_samples_vs_oracle")
@@ -419,14 +420,14 @@ def main():
         for tr_ in tracers:
             tr_._ctx.sync()
         t1 = time.time()
-        _, _, it_px, tr_px = timed_steps(tracers, 4, depth, executor, [])
+        _, _, it_px, tr_px = timed_steps(tracers, n_sec, depth, executor, [])
         for tr_ in tracers:
             tr_._ctx.sync()
         dt_px = time.time() - t1
         px_normals_ms = tracer._batch.profile_stage(2, 5)
         for tr_ in tracers:
             tr_._batch.set_rng("mt19937")
-        secondary["philox_rng"] = dict(traces_per_s=4 * E / dt_px, ms_per_step=1e3 * dt_px / 4, edges=E,
+        secondary["philox_rng"] = dict(traces_per_s=n_sec * E / dt_px, ms_per_step=1e3 * dt_px / n_sec, edges=E,
                                        normals_ms_per_ring=px_normals_ms,
                                        trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_px])),
                                        note="gpet_batch_set_rng(1): not the reference's random numbers; "
@@ -437,11 +438,12 @@ def main():
         for tr_ in small:
             tr_._ctx.sync()
         t1 = time.time()
-        l2, f2, it2, _ = timed_steps(small, 8, depth, executor, [])
+        l2, f2, it2, _ = timed_steps(small, 2 * n_sec, depth, executor, [])
         for tr_ in small:
             tr_._ctx.sync()
         dt2 = time.time() - t1
-        secondary["edges_256"] = dict(traces_per_s=8 * 256 / dt2, ms_per_step=1e3 * dt2 / 8, iterations=sorted(set(it2)))
+        secondary["edges_256"] = dict(traces_per_s=2 * n_sec * 256 / dt2, ms_per_step=1e3 * dt2 / (2 * n_sec), iterations=sorted(set(it2)),
+                                      in_flight=len(small))
         for tr_ in small:
             tr_._batch.close()
         del small

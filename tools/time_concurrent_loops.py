@@ -16,8 +16,9 @@ img, truth = synth_image(500, 3)
 init = truth[[0, -1], :][:, [1, 0]]
 grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx0)
 seeds = list(range(1, E + 1))
-objs = [amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=(ctx0 if k == 0 else L.Context(0))) for k in range(4)]
-print("4 batch objects of %d edges, arena %d MiB each" % (E, objs[0]._batch.info()["arena_mib"]), flush=True)
+NOBJ = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+objs = [amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=(ctx0 if k == 0 else L.Context(0))) for k in range(NOBJ)]
+print("%d batch objects of %d edges, arena %d MiB each" % (NOBJ, E, objs[0]._batch.info()["arena_mib"]), flush=True)
 
 def sync_all():
     for o in objs:
@@ -38,7 +39,7 @@ for rep in range(2):
     sync_all()
     dt = time.time() - t0
     print("bench pipeline (one loop at a time, 2 steps' fits beside it): %.0f traces/s (%.1f ms per step)" % (STEPS * E / dt, 1e3 * dt / STEPS), flush=True)
-for workers in (2, 3, 4):
+for workers in [w for w in (2, 3, 4, 6, 8) if w <= NOBJ]:
     exw = ThreadPoolExecutor(max_workers=workers)
     list(exw.map(whole, objs[:workers]))
     sync_all()
@@ -51,7 +52,7 @@ for workers in (2, 3, 4):
         def worker(o, n):
             for _ in range(n):
                 whole(o)
-        per = STEPS // workers
+        per = max(1, STEPS // workers)
         list(exw.map(lambda o: worker(o, per), objs[:workers]))
         sync_all()
         dt = time.time() - t0
