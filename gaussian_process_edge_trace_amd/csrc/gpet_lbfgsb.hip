@@ -166,27 +166,57 @@ __global__ void __launch_bounds__(256) k_lb_init(LbProb* probs, int P, const dou
   for (int c = 0; c < 3; ++c) slot_theta[(size_t)i * 3 + c] = p.xe[c];
 }
 
-// slot k of the round just evaluated -> its problem advances; problems still running claim a slot of the next round
+// slot k of the round just evaluated -> its problem advances; problems still running claim a slot of the next round.
+// The 848-byte records of a wave's 64 problems go through LDS: read and written back by all lanes together (two 512-byte
+// runs per record) and advanced in place there -- one thread copying its own record field by field made every access of
+// the wave 64 cache lines, and the private copy was 1 200 bytes of scratch per thread.
+static_assert(sizeof(LbProb) % 8 == 0, "LbProb is copied as doubles");
 __global__ void __launch_bounds__(64) k_lb_advance(LbProb* probs, const int* cur_count, const int* slot_src, const double* f,
                                                    const double* g, int* next_count, int* next_edge, double* next_theta,
                                                    int* next_src, LbCfg cfg) {
 #pragma clang fp contract(off)
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NW = (int)(sizeof(LbProb) / 8);  // doubles per record
+  __shared__ LbProb s_p[64];
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x * blockDim.x + lane;
   // the launch is sized by the host's last KNOWN count (it reads the counter only every few rounds); the true number of
   // running problems is on the device
-  if (k >= *cur_count) return;
-  const int pid = slot_src[k];
-  LbProb p = probs[pid];
-  double lo[3] = {cfg.lo[0], cfg.lo[1], cfg.lo[2]}, hi[3] = {cfg.hi[0], cfg.hi[1], cfg.hi[2]};
-  const double gk[3] = {g[(size_t)k * 3], g[(size_t)k * 3 + 1], g[(size_t)k * 3 + 2]};
-  lb_advance(p, f[k], gk, lo, hi);
-  if (p.task != LB_TASK_DONE) {
-    const int pos = atomicAdd(next_count, 1);
-    next_edge[pos] = p.edge;
-    next_src[pos] = pid;
-    for (int c = 0; c < 3; ++c) next_theta[(size_t)pos * 3 + c] = p.xe[c];
+  const int count = *cur_count;
+  if ((int)(blockIdx.x * blockDim.x) >= count) return;  // (the whole wave)
+  const bool active = k < count;
+  const int pid = active ? slot_src[k] : -1;
+#pragma unroll 4
+  for (int t = 0; t < 64; ++t) {
+    const int pt = __shfl(pid, t, 64);
+    if (pt < 0) continue;  // (uniform)
+    const double* src = reinterpret_cast<const double*>(probs + pt);
+    double* dst = reinterpret_cast<double*>(&s_p[t]);
+    dst[lane] = src[lane];
+    if (lane + 64 < NW) dst[lane + 64] = src[lane + 64];
   }
-  probs[pid] = p;
+  __syncthreads();
+  if (active) {
+    LbProb& p = s_p[lane];
+    double lo[3] = {cfg.lo[0], cfg.lo[1], cfg.lo[2]}, hi[3] = {cfg.hi[0], cfg.hi[1], cfg.hi[2]};
+    const double gk[3] = {g[(size_t)k * 3], g[(size_t)k * 3 + 1], g[(size_t)k * 3 + 2]};
+    lb_advance(p, f[k], gk, lo, hi);
+    if (p.task != LB_TASK_DONE) {
+      const int pos = atomicAdd(next_count, 1);
+      next_edge[pos] = p.edge;
+      next_src[pos] = pid;
+      for (int c = 0; c < 3; ++c) next_theta[(size_t)pos * 3 + c] = p.xe[c];
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int t = 0; t < 64; ++t) {
+    const int pt = __shfl(pid, t, 64);
+    if (pt < 0) continue;
+    double* dstg = reinterpret_cast<double*>(probs + pt);
+    const double* srcl = reinterpret_cast<const double*>(&s_p[t]);
+    dstg[lane] = srcl[lane];
+    if (lane + 64 < NW) dstg[lane + 64] = srcl[lane + 64];
+  }
 }
 
 // best restart of every edge (first minimum, np.argmin in sklearn_gpr.py:292) -> fin_par[0..2] = exp(theta)
