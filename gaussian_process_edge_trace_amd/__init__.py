@@ -7,6 +7,7 @@ from .sklearn_gpr import GaussianProcessRegressor
 from . import gpet_utils
 from . import _lib
 from .sequence import SequenceTracer, trace_sequence
+from .pipeline import run_in_flight
 
 __all__ = ["GP_Edge_Tracing", "GaussianProcessRegressor", "gpet_utils", "GP_Edge_Tracing_Batch", "SequenceTracer",
-           "trace_sequence"]
+           "trace_sequence", "run_in_flight"]

@@ -101,3 +101,47 @@ def test_committed_bench_line_keeps_the_driver_contract():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 50 * c["value"]  # north_star target: >= 50x the CPU path on one GPU
+
+
+def test_run_in_flight_schedules_every_step_once_and_in_order():
+    """pipeline.run_in_flight: step k on object k mod W, every step exactly once, results in step order, an object only
+    ever inside one call at a time, a worker's exception re-raised (host logic only: fake tracers)."""
+    import threading
+    import time as _t
+    from gaussian_process_edge_trace_amd.pipeline import run_in_flight, step_owner
+
+    assert step_owner(10, 3) == [[0, 3, 6, 9], [1, 4, 7], [2, 5, 8]]
+    assert step_owner(2, 6) == [[0], [1]]
+
+    class Fake:
+        def __init__(self, name):
+            self.name, self.busy, self.calls, self.lock = name, 0, [], threading.Lock()
+
+        def reset(self):
+            self.calls.append("reset")
+
+        def __call__(self):
+            with self.lock:
+                self.busy += 1
+                assert self.busy == 1
+            _t.sleep(0.002)
+            with self.lock:
+                self.busy -= 1
+            self.calls.append("trace")
+            return self.name
+
+    objs = [Fake("a"), Fake("b"), Fake("c")]
+    out = run_in_flight(objs, 8)
+    assert out == ["a", "b", "c", "a", "b", "c", "a", "b"]
+    assert [o.calls.count("trace") for o in objs] == [3, 3, 2] and all(o.calls[0] == "reset" for o in objs)
+    seen = []
+    out = run_in_flight(objs[:2], 3, prepare=lambda tr, k: seen.append((tr.name, k)))
+    assert out == ["a", "b", "a"] and sorted(seen) == [("a", 0), ("a", 2), ("b", 1)]
+
+    class Bad(Fake):
+        def __call__(self):
+            raise RuntimeError("boom")
+
+    import pytest
+    with pytest.raises(RuntimeError):
+        run_in_flight([Fake("a"), Bad("b")], 4)
