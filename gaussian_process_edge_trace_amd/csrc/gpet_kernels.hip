@@ -3662,6 +3662,15 @@ __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M,
 // two kernels give the same bits for the same samples.  No branches: the G curves are independent chains in one basic
 // block, which the scheduler interleaves (k_sample_score runs two or three waves per SIMD and has nothing else to hide
 // the reciprocal square roots and the LDS gathers behind).
+// 1 / sqrt(x) for x >= 1 (a segment's 1 + d^2): the arithmetic of the device library's rsqrt -- hardware estimate, then
+// y + y e (0.5 + 0.375 e) with e = 1 - x y^2 -- without its test for zero / infinite arguments (a v_cmp_class and two
+// selects per call in a kernel bound by vector-ALU issue); the same bits for every finite x > 0.
+__device__ __forceinline__ double sc_rsqrt(double x) {
+#pragma clang fp contract(off)
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-y0 * x, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
 template <int G>
 __device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const double (&y1)[G], const float* __restrict__ col0,
                                                 const float* __restrict__ col1, int M, bool on, double (&al)[G], double (&li)[G]) {
@@ -3674,8 +3683,9 @@ __device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const dou
   int iy0[G], iy1[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    yc0[g] = y0[g] < 0.0 ? 0.0 : (y0[g] > (double)(M - 1) ? (double)(M - 1) : y0[g]);
-    yc1[g] = y1[g] < 0.0 ? 0.0 : (y1[g] > (double)(M - 1) ? (double)(M - 1) : y1[g]);
+    // (v_max_f64 / v_min_f64 instead of two compares and four selects per clamp)
+    yc0[g] = fmin(fmax(y0[g], 0.0), (double)(M - 1));
+    yc1[g] = fmin(fmax(y1[g], 0.0), (double)(M - 1));
     iy0[g] = (int)yc0[g];
     iy1[g] = (int)yc1[g];
     iy0[g] = iy0[g] > M - 2 ? M - 2 : iy0[g];
@@ -3689,7 +3699,7 @@ __device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const dou
   for (int g = 0; g < G; ++g) {
     const double d0 = y1[g] - y0[g];
     const double q0 = fma(d0, d0, 1.0);
-    r0[g] = rsqrt(q0);
+    r0[g] = sc_rsqrt(q0);
     l0[g] = q0 * r0[g];
   }
 #pragma unroll
@@ -3705,7 +3715,7 @@ __device__ __forceinline__ void score_pairs_row(const double (&y0)[G], const dou
     const double g2 = dpp_row<0x101>(g0[g]);
     const double d1 = y2 - y1[g];
     const double q1 = fma(d1, d1, 1.0);
-    const double r1 = rsqrt(q1), l1 = q1 * r1;
+    const double r1 = sc_rsqrt(q1), l1 = q1 * r1;
     const double a_ = (2.0 / 6.0) * (fma(4.0, l1, l0[g]) + l2);
     const double h0 = l1, h1 = l2, ih0 = r1, ih1 = r2;
     const double hsum = h0 + h1;
