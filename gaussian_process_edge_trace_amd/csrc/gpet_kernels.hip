@@ -3636,12 +3636,25 @@ __device__ __forceinline__ double dpp_row(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // sum over the 16 lanes of a row, in every lane; the operands of every addition are those of the xor-8, 4, 2, 1 butterfly
-// (after the first step lanes i and i ^ 8 hold the same value, so a rotation by 4 brings what xor 4 would)
+// (after the first step lanes i and i ^ 8 hold the same value, so a rotation by 4 brings what xor 4 would).
+// GPET_ROWSUM_SWZ (bit s set: step s by ds_swizzle): the exchange through the LDS crossbar (no memory access) instead of
+// two v_mov_b32_dpp -- the scorer is bound by vector-ALU issue and its LDS pipe is nearly idle.
+#ifndef GPET_ROWSUM_SWZ
+#define GPET_ROWSUM_SWZ 0
+#endif
+template <int XOR>
+__device__ __forceinline__ double swz_xor(double v) {
+  const long long b = __double_as_longlong(v);
+  constexpr int pat = (XOR << 10) | 0x1F;  // bit mode: and 0x1f, or 0, xor XOR (within 32 lanes)
+  const int lo = __builtin_amdgcn_ds_swizzle((int)b, pat);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), pat);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_row<0x128>(v);  // row_ror:8
-  v += dpp_row<0x124>(v);  // row_ror:4
-  v += dpp_row<0x4E>(v);   // quad_perm:[2,3,0,1]
-  v += dpp_row<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += (GPET_ROWSUM_SWZ & 1) ? swz_xor<8>(v) : dpp_row<0x128>(v);  // row_ror:8
+  v += (GPET_ROWSUM_SWZ & 2) ? swz_xor<4>(v) : dpp_row<0x124>(v);  // row_ror:4
+  v += (GPET_ROWSUM_SWZ & 4) ? swz_xor<2>(v) : dpp_row<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += (GPET_ROWSUM_SWZ & 8) ? swz_xor<1>(v) : dpp_row<0xB1>(v);   // quad_perm:[1,0,3,2]
   return v;
 }
 __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
