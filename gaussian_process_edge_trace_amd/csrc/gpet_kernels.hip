@@ -1742,6 +1742,42 @@ __device__ __forceinline__ void seat_block_of(int e, int& a_, int& b_) {  // e =
   a_ = e - b_ * (b_ + 1) / 2;
 }
 
+// the four entries of the 2 x 2 block (pair a, pair b) after this round's rotations (c_a, s_a) and (c_b, s_b); ONE body
+// for every kernel that forms them (contraction off)
+__device__ __forceinline__ void jac_rot_block(double b00, double b01, double b10, double b11, double ca, double sa, double cb,
+                                              double sb, double (&nv)[4]) {
+#pragma clang fp contract(off)
+  const double t00 = fma(cb, b00, -(sb * b01)), t01 = fma(sb, b00, cb * b01);
+  const double t10 = fma(cb, b10, -(sb * b11)), t11 = fma(sb, b10, cb * b11);
+  nv[0] = fma(ca, t00, -(sa * t10));
+  nv[2] = fma(sa, t00, ca * t10);
+  nv[1] = fma(ca, t01, -(sa * t11));
+  nv[3] = fma(sa, t01, ca * t11);
+}
+// rotation (c, s) that annihilates a_pq of [[app, apq], [apq, aqq]]
+__device__ __forceinline__ void jac_params(double app, double apq, double aqq, double& c, double& s) {
+  c = 1.0;
+  s = 0.0;
+  if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
+    // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
+    // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
+    // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
+    const double d = aqq - app, hh = 2.0 * apq;
+    const double rho2 = d * d + hh * hh;
+    double y = __builtin_amdgcn_rsq(rho2);
+    y = y * (1.5 - 0.5 * rho2 * y * y);
+    const double den = fabs(d) + rho2 * y;
+    double iv = __builtin_amdgcn_rcp(den);
+    iv = iv * (2.0 - den * iv);
+    const double t = (d >= 0.0 ? hh : -hh) * iv;
+    const double u = 1.0 + t * t;
+    c = __builtin_amdgcn_rsq(u);
+    c = c * (1.5 - 0.5 * u * c * c);
+    c = c * (1.5 - 0.5 * u * c * c);
+    s = t * c;
+  }
+}
+
 #define JS_NT 512
 #define JS_LOG_SWEEPS 40  // sweeps a rotation log holds (= the sweep limit of the kernel)
 // LOGW (small batches, where the chain of rounds IS the time): the eigenvectors are not accumulated here -- 41 KB of LDS
@@ -1820,24 +1856,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
         trace_rel = rel2 > trace_rel ? rel2 : trace_rel;
       }
 #endif
-      if (fabs(apq) > 1e-300 && apq * apq > 1e-36 * fabs(app * aqq)) {
-        // t = sgn(d) h / (|d| + sqrt(d^2 + h^2)): hardware rsqrt / reciprocal + one Newton step (an inexact
-        // angle only leaves a ~1e-10 relative residue in a_pq); c = rsqrt(1 + t^2) gets two steps and
-        // s = t c, so c^2 + s^2 = 1 to rounding whatever t is
-        const double d = aqq - app, hh = 2.0 * apq;
-        const double rho2 = d * d + hh * hh;
-        double y = __builtin_amdgcn_rsq(rho2);
-        y = y * (1.5 - 0.5 * rho2 * y * y);
-        const double den = fabs(d) + rho2 * y;
-        double iv = __builtin_amdgcn_rcp(den);
-        iv = iv * (2.0 - den * iv);
-        const double t = (d >= 0.0 ? hh : -hh) * iv;
-        const double u = 1.0 + t * t;
-        c = __builtin_amdgcn_rsq(u);
-        c = c * (1.5 - 0.5 * u * c * c);
-        c = c * (1.5 - 0.5 * u * c * c);
-        s = t * c;
-      }
+      jac_params(app, apq, aqq, c, s);
       s_cs[nxt][pk] = make_double2(c, s);
       if (LOGW) jlog[(size_t)log_round * half + pk] = make_double2(c, s);
     }
@@ -1896,12 +1915,7 @@ __global__ void __launch_bounds__(JS_NT) k_jacobi_seat(EdgeDev* edges, int scale
           const double ca = ra.x, sa = ra.y, cb = rb.x, sb = rb.y;
           const double b00 = A0[e], b01 = A0[nblk + e], b11 = A0[3 * nblk + e];
           const double b10 = (ba[u] == bb[u]) ? b01 : A0[2 * nblk + e];
-          const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
-          const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-          nv[u][0] = ca * t00 - sa * t10;
-          nv[u][2] = sa * t00 + ca * t10;
-          nv[u][1] = ca * t01 - sa * t11;
-          nv[u][3] = sa * t01 + ca * t11;
+          jac_rot_block(b00, b01, b10, b11, ca, sa, cb, sb, nv[u]);
         }
         JAC_CLK(q1);
         __syncthreads();  // every block has been read
