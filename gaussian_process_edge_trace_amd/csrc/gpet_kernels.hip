@@ -6613,9 +6613,10 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     }
     // (an edge too wide for its posterior mean to sit behind the chunk reads it from global memory in the epilogue)
     const int mu_in_lds = ((size_t)4 * 24 * GEMM_LDA + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
+    static const size_t gemm_lds_pad = getenv("GPET_GEMM_LDS_PAD") ? (size_t)atoi(getenv("GPET_GEMM_LDS_PAD")) : 0;  // (experiments: one workgroup per CU)
 #define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
   do {                                                                                                                                 \
-    const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
+    const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double) + gemm_lds_pad;                             \
     if (bd.y_f32 && mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, true, true>), grid, block, lds_, st, d_edges, ncs);                        \
     else if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true, false>), grid, block, lds_, st, d_edges, ncs);                               \
     else if (mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, false, true>), grid, block, lds_, st, d_edges, ncs);                              \
