@@ -4,7 +4,7 @@
 # Every rocprofv3 pass is its own run (PMC passes never share a run with a trace), program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-E=${1:-2048}
+E=${1:-1024}
 O=gpurun_out/prof
 rm -rf $O gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 mkdir -p $O
