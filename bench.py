@@ -618,7 +618,7 @@ def main():
         "config": {"workload": "BASELINE config 2 edge (500x500 sinusoidal image, RBF sigma_f=75 l=20, N_samples=1000, "
                                "delta_x=5, pixel_thresh=5) x %d independent edges per GPU and step (config 4's batch of independent edges, sized to fill the GPU), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
-                   "edges_per_gpu": E, "image": [N, N], "iterations_per_trace": iters[:4],
+                   "edges_per_gpu": E, "steps_in_flight_per_gpu": len(tracers), "image": [N, N], "iterations_per_trace": iters[:4],
                    "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
                                 "all on the GPU (gpet_final_fit_all); no host workers"},
         "host": {"cpus_usable": usable_cpus(), "cpus_machine": os.cpu_count(), "lbfgs_workers": 0,
