@@ -153,45 +153,51 @@ def timed_steps(tracers, n_steps, depth, executor, fit_walls, loop_walls=None):
     return sum(map(sum, lw)) / W, sum(map(sum, fw)) / W, iters_, traces_
 
 
-def secondary_config3(pkg, ctx):
+def secondary_config3(pkg, ctx, n_edges=1):
     """BASELINE config 3's shape: 2048x2048 image, 1498 observations (+2 inits = 1500 training points), N_samples=4000:
-    ms of one GP iteration (fit + predict + covariance, factor, sample GEMM) and of the scoring, per stage."""
+    ms of one GP iteration (fit + predict + covariance, factor, sample GEMM) and of the scoring, per stage, timed with
+    hipEvents on the library's stream (gpet_timer_*).  n_edges > 1: the same edge n_edges times in one batch (different
+    observation noise and seeds) -- a single edge of this size is a latency chain of ~100 launches, a batch is what shows
+    the blocked f64-MFMA path's rate."""
     N = 2048
     img, truth = synth_image(N, 0)
     grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
     init = truth[[0, -1], :][:, [1, 0]]
-    rng = np.random.default_rng(0)
-    cols = np.sort(rng.choice(np.arange(1, N - 1), size=1498, replace=False))
-    obs = np.stack([cols, np.clip(truth[cols, 0] + rng.integers(-2, 3, size=cols.size), 0, N - 1)], axis=1).astype(np.int64)
     kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=4000,
-              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True)
-    tr = pkg.GP_Edge_Tracing(init, grad, obs=obs, **kw, _ctx=ctx)
-    b = tr._batch
-    b.set_obs(0, obs)
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    obs_all = []
+    for e in range(n_edges):
+        rng = np.random.default_rng(e)
+        cols = np.sort(rng.choice(np.arange(1, N - 1), size=1498, replace=False))
+        obs_all.append(np.stack([cols, np.clip(truth[cols, 0] + rng.integers(-2, 3, size=cols.size), 0, N - 1)], axis=1).astype(np.int64))
+    bt = pkg.GP_Edge_Tracing_Batch([init] * n_edges, grad, [1 + 97 * e for e in range(n_edges)], obs=obs_all, _ctx=ctx, **kw)
+    b = bt._batch
 
     def timed(fn, reps=3):
-        """host wall time of a per-stage entry point (they enqueue on the context's stream; synchronised here)"""
+        """device time of a per-stage entry point: hipEvents around `reps` calls on the context's stream"""
         fn()
         ctx.sync()
-        t0 = time.time()
+        ctx.timer_start()
         for _ in range(reps):
             fn()
-        ctx.sync()
-        return 1e3 * (time.time() - t0) / reps
+        return ctx.timer_stop_ms() / reps
     ms = dict(fit_predict_cov=timed(lambda: b.fit_predict(True)), factor=timed(b.factor))
-    ms["normals"] = timed(lambda: b.normals([7]))  # the whole RandomState(seed).standard_normal((4000, 2048)) stream of ONE edge
+    ms["normals"] = timed(lambda: b.normals([7 + e for e in range(n_edges)]))  # RandomState(seed).standard_normal((4000, 2048)) per edge
     ms["sample_gemm"] = timed(b.sample)
     ms["score_topk"] = timed(b.score)
     s_ = b.scalars()
     n, Lg = int(s_.n), N
-    gflop = (n ** 3 / 3.0 + n * n * Lg + Lg * Lg * n) * 1e-9  # Cholesky + V = L^-1 K*^T + K** - V^T V (SURVEY 8d)
-    return dict(config="2048x2048, n=1500 training points, N_samples=4000, RBF sigma_f=300 l=80; per-stage entry points "
-                       "(1498 observations exceed algo_thresh, so the loop itself would not iterate: SURVEY 8d C3)",
-                gp_iter_ms=ms["fit_predict_cov"] + ms["factor"] + ms["normals"] + ms["sample_gemm"],
-                gp_iter_ms_note="fit + predict + covariance, factor, the 8.2 M normals of the iteration, sample GEMM (round 2 "
-                                "left the normals out of this sum)",
-                scoring_ms=ms["score_topk"], stage_ms=ms, fit_predict_cov_tflops=gflop / ms["fit_predict_cov"],
-                n_train=n, factor_rank=int(s_.rank), timing="host wall clock around the entry points, 3 repetitions")
+    gflop = n_edges * (n ** 3 / 3.0 + n * n * Lg + Lg * Lg * n) * 1e-9  # Cholesky + V = L^-1 K*^T + K** - V^T V (SURVEY 8d)
+    out = dict(config="2048x2048, n=1500 training points, N_samples=4000, RBF sigma_f=300 l=80; per-stage entry points "
+                      "(1498 observations exceed algo_thresh, so the loop itself would not iterate: SURVEY 8d C3); %d edge(s) per launch" % n_edges,
+               edges=n_edges, gp_iter_ms=ms["fit_predict_cov"] + ms["factor"] + ms["normals"] + ms["sample_gemm"],
+               gp_iter_ms_note="fit + predict + covariance, factor, the 8.2 M normals per edge of the iteration, sample GEMM",
+               scoring_ms=ms["score_topk"], stage_ms=ms, fit_predict_cov_tflops=gflop / ms["fit_predict_cov"],
+               fit_predict_cov_frac_of_f64_peak=gflop / ms["fit_predict_cov"] / FP64_PEAK_TFLOPS,
+               sample_gemm_tflops=n_edges * 2.0 * 4000 * Lg * int(s_.rank) * 1e-9 / ms["sample_gemm"],
+               n_train=n, factor_rank=int(s_.rank), timing="hipEvents on the library's stream, 3 repetitions")
+    b.close()
+    return out
 
 
 def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
@@ -228,10 +234,29 @@ def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
     t1 = time.time()
     one()
     dt1 = time.time() - t1
+    # the literal per-GPU shares of config 5 on 8 GPUs, each timed alone on this one: (a) 8 chains x 8 frames = ONE chain per
+    # GPU (a chain is serial: frame t warm-starts frame t + 1); (b) 16 chains x 4 frames = TWO chains per GPU (more cold starts,
+    # but the any-rank factor of two edges costs little more than that of one)
+    sh_a = pkg.SequenceTracer(frames[:frames_per_chain], init, n_chains=1, warm_every=16, seed=3, _ctx=ctx, **kw)
+    t2 = time.time()
+    sh_a()
+    dt_a = time.time() - t2
+    half = max(1, frames_per_chain // 2)
+    sh_b = pkg.SequenceTracer(frames[:2 * half], init, n_chains=2, warm_every=16, seed=3, _ctx=ctx, **kw)
+    t3 = time.time()
+    sh_b()
+    dt_b = time.time() - t3
     return dict(config="1024x1024, Matern-5/2 sigma_f=154 l=41, N_samples=1000, delta_x=8; %d frames = %d chains x %d "
                        "(cold first frame, warm-started later ones), one GPU, constructor of the batch included" % (T, n_chains, frames_per_chain),
                 frames_per_s=T / dt, seconds_total=dt, iterations_per_frame=st.iterations,
                 single_chain_s_per_frame=dt1 / 2, single_chain_iterations=one.iterations,
+                one_chain_per_gpu_s=dt_a, one_chain_per_gpu_iterations=sh_a.iterations,
+                predicted_speedup_8_gpus_one_chain_each=dt / dt_a,
+                two_chains_per_gpu_s=dt_b, two_chains_per_gpu_iterations=sh_b.iterations,
+                predicted_speedup_8_gpus_two_half_chains_each=dt / dt_b,
+                per_gpu_share_note="config 5 on 8 GPUs as stated is one chain of %d frames per GPU; the prediction is this GPU's time for all "
+                                   "%d frames over its time for that share alone (no collective on the path); with 16 chains of %d frames a GPU "
+                                   "holds two edges per step" % (frames_per_chain, T, half),
                 factor_ms_batch_of_chains=fac, factor_ms_single_edge=fac1, factor_jacobi_sweeps=sweeps, chains=n_chains)
 
 
@@ -311,7 +336,15 @@ def main():
         grad = pkg.gpet_utils.comp_grad_img(img, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
 
     E = args.edges
-    seeds = [1 + rank * E + e for e in range(E)]  # independent edges: distinct RNG streams
+    # independent edges: iteration k of an edge draws from RandomState(seed + k + 1) (gpet.py:839), so consecutive seeds
+    # would hand edge e + 1's iteration-k normals to edge e at iteration k + 1; seeds 997 apart (a trace takes < 64
+    # iterations) give every (edge, iteration) of every batch object in flight on every rank its own stream
+    SEED_STRIDE = 997
+    n_objs = max(0, args.pipeline_depth) + 1
+
+    def seeds_of(obj):
+        return [1 + SEED_STRIDE * ((rank * n_objs + obj) * E + e) for e in range(E)]
+    seeds = seeds_of(0)
 
     def make_tracer(n_edges, ctx_, images=None, inits=None, sds=None):
         return pkg.GP_Edge_Tracing_Batch(inits if inits is not None else [init] * n_edges,
@@ -320,8 +353,8 @@ def main():
 
     tracer = make_tracer(E, ctx)
     tracers = [tracer]
-    for d_ in range(depth):  # more batch objects, each with its own context (= HIP stream)
-        tracers.append(make_tracer(E, L.Context(dev_index)))
+    for d_ in range(depth):  # more batch objects, each with its own context (= HIP stream) and its own seeds
+        tracers.append(make_tracer(E, L.Context(dev_index), sds=seeds_of(d_ + 1)))
     if grad is None:
         grad = g.cpu().numpy()  # (the secondary figures below build batches from host arrays)
 
@@ -444,6 +477,41 @@ def main():
         dt2 = time.time() - t1
         secondary["edges_256"] = dict(traces_per_s=2 * n_sec * 256 / dt2, ms_per_step=1e3 * dt2 / (2 * n_sec), iterations=sorted(set(it2)),
                                       in_flight=len(small))
+        # (c2) config 4 AS STATED is 256 edges over 8 GPUs = 32 edges per GPU: one job, nothing to pipeline with.  One batch
+        #      object alone on the GPU at 256 and at 32 edges (median of five steps, loop + converged fits back to back);
+        #      t(256) / t(32) is the strong-scaling factor 8 GPUs can reach on that job (no collective on the path; the
+        #      broadcast of the 1 MB image is reported as bcast_grad_ms at N > 1)
+        def alone_ms(obj, reps=5):
+            ts_ = []
+            for _ in range(reps + 1):
+                obj._ctx.sync()
+                ta = time.time()
+                obj.reset()
+                obj.finish(obj.run_loop())
+                obj._ctx.sync()
+                ts_.append(1e3 * (time.time() - ta))
+            return float(np.median(ts_[1:]))
+        t256 = alone_ms(small[0])
+        e32 = make_tracer(32, tracers[0]._ctx)
+        t32 = alone_ms(e32)
+        e32s = [e32] + [make_tracer(32, tr_._ctx, sds=seeds_of(k_ + 1)[:32]) for k_, tr_ in enumerate(tracers[1:])]
+        timed_steps(e32s, len(e32s), depth, executor, [])
+        for tr_ in e32s:
+            tr_._ctx.sync()
+        t1 = time.time()
+        timed_steps(e32s, 4 * n_sec, depth, executor, [])
+        for tr_ in e32s:
+            tr_._ctx.sync()
+        dt32 = time.time() - t1
+        secondary["edges_32"] = dict(ms_per_step_alone=t32, traces_per_s_alone=32 / (1e-3 * t32),
+                                     traces_per_s_in_flight=4 * n_sec * 32 / dt32, in_flight=len(e32s),
+                                     edges_256_ms_per_step_alone=t256,
+                                     predicted_strong_scaling_8_gpus=t256 / t32,
+                                     note="BASELINE config 4 as stated: 256 edges / 8 GPUs = 32 per GPU; one batch object alone "
+                                          "(loop + converged fits), median of 5; prediction = t(256 alone) / t(32 alone)")
+        for tr_ in e32s:
+            tr_._batch.close()
+        del e32s, e32
         for tr_ in small:
             tr_._batch.close()
         del small
@@ -470,6 +538,9 @@ def main():
                secondary["edges_256"]["traces_per_s"], secondary["edges_256_distinct_images"]["traces_per_s"]))
         secondary["config3"] = secondary_config3(pkg, ctx)
         log("secondary: config 3 GP iteration %.2f ms + scoring %.2f ms" % (secondary["config3"]["gp_iter_ms"], secondary["config3"]["scoring_ms"]))
+        secondary["config3_batch"] = secondary_config3(pkg, ctx, n_edges=8)
+        log("secondary: config 3 x 8 edges: fit + predict + covariance %.2f ms = %.1f TFLOP/s"
+            % (secondary["config3_batch"]["stage_ms"]["fit_predict_cov"], secondary["config3_batch"]["fit_predict_cov_tflops"]))
         secondary["config5"] = secondary_config5(pkg, ctx)
         log("secondary: config 5 %.2f frames/s (8 chains), single chain %.3f s per frame"
             % (secondary["config5"]["frames_per_s"], secondary["config5"]["single_chain_s_per_frame"]))
@@ -618,7 +689,8 @@ def main():
         "config": {"workload": "BASELINE config 2 edge (500x500 sinusoidal image, RBF sigma_f=75 l=20, N_samples=1000, "
                                "delta_x=5, pixel_thresh=5) x %d independent edges per GPU and step (config 4's batch of independent edges, sized to fill the GPU), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
-                   "edges_per_gpu": E, "steps_in_flight_per_gpu": len(tracers), "image": [N, N], "iterations_per_trace": iters[:4],
+                   "edges_per_gpu": E, "steps_in_flight_per_gpu": len(tracers), "image": [N, N],
+                   "seeds": "1 + 997 * ((rank * objects + object) * edges + edge): every (edge, iteration) its own RandomState stream", "iterations_per_trace": iters[:4],
                    "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
                                 "all on the GPU (gpet_final_fit_all); no host workers"},
         "host": {"cpus_usable": usable_cpus(), "cpus_machine": os.cpu_count(), "lbfgs_workers": 0,

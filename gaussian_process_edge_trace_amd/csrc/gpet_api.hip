@@ -395,6 +395,12 @@ int gpet_set_option(const char* name, int value) {
     v = value < 4 ? 4 : (value > 15 ? 15 : value);
     return old;
   }
+  if (name && strcmp(name, "oj_persist") == 0) {
+    int& v = gpet_opt_oj_persist();
+    const int old = v;
+    v = value ? 1 : 0;
+    return old;
+  }
   if (name && strcmp(name, "oj_max_sweeps") == 0) {
     int& v = gpet_opt_oj_max_sweeps();
     const int old = v;
@@ -801,8 +807,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
       if (b->bd.n_cap <= 128 &&
           ((size_t)b->bd.n_cap * (r0_max | 1) + b->bd.n_cap + b->bd.r_cap) * sizeof(double) > (size_t)STRUCT_H_LDS_MAX)
         ok = false;
-      // edges of the same grid length, kernel and length scale have the same prior eigenbasis bit for bit (the unit-
-      // amplitude correlation matrix of a pixel grid knows neither where the edge starts nor its amplitude): they all
+      // edges of the same grid length, first column, kernel and length scale have the same prior eigenbasis bit for bit
+      // (k_rho_fill forms the lags as fl((x_st+i)/l) - fl((x_st+j)/l), which depends on x_st in the last bits unless l is
+      // a power of two -- so x_st is part of the match; the amplitude is not: the matrix has unit amplitude): they all
       // read the first such edge's copy, which then stays in L2 for the whole batch (k_struct_H gathers its rows,
       // k_struct_rows streams it: 288 KB per edge at rank 72, Lg 500) -- GPET_NO_SHARED_BASIS=1: every edge its own
       if (ok && !getenv("GPET_NO_SHARED_BASIS")) {
@@ -810,7 +817,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
           EdgeDev& E = b->h_edges[e];
           for (int j = 0; j < e; ++j) {
             const EdgeDev& F = b->h_edges[j];
-            if (F.Lg == E.Lg && F.kernel_type == E.kernel_type && F.nu_code == E.nu_code && F.nu_gen == E.nu_gen &&
+            if (F.Lg == E.Lg && F.x_st == E.x_st && F.kernel_type == E.kernel_type && F.nu_code == E.nu_code && F.nu_gen == E.nu_gen &&
                 F.length_scale == E.length_scale && F.r0 == E.r0 && F.r_cap == E.r_cap) {
               E.Q0 = F.Q0;
               E.lam0 = F.lam0;

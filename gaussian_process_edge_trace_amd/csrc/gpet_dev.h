@@ -14,7 +14,9 @@ struct EigState {
   int stopped, rank;               // pivoted Cholesky finished; rows of G
   int converged, sweeps;           // Jacobi: every pair orthogonal to the tolerance; sweeps done
   int cand_half;                   // blocked pivoting: which half of pcx_cand holds the latest candidates
-  unsigned int bar;                // arrivals at the barrier of the persistent Jacobi kernel (k_oj_persist), monotonic
+  unsigned int bar;                // k_oj_persist: pair slots FINISHED so far (all rounds and sweeps of this factorisation), monotonic
+  unsigned int ticket;             // k_oj_persist: pair slots HANDED OUT so far (a workgroup takes the next one when it has finished its last)
+  int verdicts;                    // k_oj_persist: sweeps whose convergence verdict has been published
   int t_slot[2], stop_slot[2];     // blocked pivoting: rows so far / finished, as block (blk & 1) must see them -- a block
                                    // writes the OTHER slot, so workgroups of one launch never read what it writes
 };

@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(256) k_pcx_init(EdgeDev* edges, int nw_max) {
     st->converged = 0;
     st->sweeps = 0;
     st->bar = 0u;
+    st->ticket = 0u;
+    st->verdicts = 0;
   }
   if (j0 >= Lg) return;
   const int lane = tid & 63, w = tid >> 6;
@@ -486,6 +488,8 @@ __global__ void __launch_bounds__(64) k_pcb_init(EdgeDev* edges, int nw_max) {
     st->converged = 0;
     st->sweeps = 0;
     st->bar = 0u;
+    st->ticket = 0u;
+    st->verdicts = 0;
     st->cand_half = 0;
     st->t_slot[0] = 0;
     st->stop_slot[0] = 0;
@@ -860,25 +864,33 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
   }
 }
 
-// ---- the rounds and sweeps of one factorisation in ONE launch (batches whose pair-workgroups are all resident) ---------
+// ---- the rounds and sweeps of one factorisation in ONE launch ----------------------------------------------------------
 // A round launch costs ~25 us of which ~12 are the round: the rest is start, drain and cold state.
-// Here the workgroup of pair slot k loops over the rounds and sweeps itself; between rounds the workgroups OF ONE EDGE
-// meet at a barrier in global memory (arrival counter in the edge's EigState, monotonic: target = workgroups x barriers
-// so far).  The rows a workgroup needs next were written by two other workgroups, possibly on another XCD whose L2 is
-// not coherent with this one: the rows are therefore read and written with agent-scope accesses (sc1: write-through to
-// and read from the level all XCDs share) instead of a cache-wide write-back + invalidate at every barrier (a
-// __threadfence() per barrier, what a cooperative grid sync does, made a round 29 us: slower than a launch).  The waiting thread gives up after
-// ~1 s (a workgroup that never became resident: more workgroups than the GPU holds) and fails the edge instead of
-// hanging the device.  Same pairs, same rotations, same arithmetic as k_oj_round<STAGED>: bit-identical rows.
-__device__ __forceinline__ bool oj_edge_barrier(unsigned int* ctr, unsigned int target, int* s_flag) {
-  __syncthreads();  // (every wave's stores are out: hipcc's barrier waits for vmcnt(0))
+// Here the workgroups of an edge loop over the rounds and sweeps themselves.  Work is handed out by TICKET: a workgroup
+// takes the next pair slot (ticket t -> sweep, round, slot; one atomic on the edge's EigState), waits until every slot of
+// the earlier rounds has FINISHED (a second monotonic counter), rotates the pair, counts it finished and comes back for
+// the next ticket.  Nothing requires the workgroups to be resident together: whoever holds the oldest unfinished ticket
+// is running by construction, so fewer resident workgroups than slots (a batch of many edges, other batches' kernels on
+// the GPU, another process on the device) only means that a workgroup serves several slots per round.  (Round 3's form
+// bound workgroup k to slot k and met at a barrier: it needed all workgroups co-resident, gave up after ~1 s when they
+// were not and FAILED the edge -- six traces in flight could starve each other.)  The last slot of a sweep publishes the
+// sweep's verdict; tickets of the next sweep wait for it.  The rows a workgroup needs next were written by two other
+// workgroups, possibly on another XCD whose L2 is not coherent with this one: rows are read and written with agent-scope
+// accesses (sc1: write-through to / read from the level all XCDs share) instead of a cache-wide write-back + invalidate
+// per round (a __threadfence() per barrier made a round 29 us: slower than a launch).  Same pairs, same rotations, same
+// arithmetic as k_oj_round<STAGED>, whichever workgroup serves a slot: bit-identical rows.  The wait is bounded by WALL
+// time (~4 s: a device fault elsewhere, never contention) and then fails the edge instead of hanging the device.
+__device__ __forceinline__ bool oj_wait_slot(EigState* st, unsigned int need_done, int need_verdicts, int* s_flag) {
   if (threadIdx.x == 0) {
-    atomicAdd(ctr, 1u);
     int ok = 1;
-    long long spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const unsigned long long t0 = wall_clock64();  // (constant 100 MHz)
+    for (;;) {
+      const unsigned int d = __hip_atomic_load(&st->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int v = __hip_atomic_load(&st->verdicts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d >= need_done && v >= need_verdicts) break;
+      if (v >= need_verdicts && __hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // (finished while we waited)
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1ll << 23)) {
+      if (wall_clock64() - t0 > 400000000ull) {
         ok = 0;
         break;
       }
@@ -917,8 +929,9 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
   const int nch = (Lg + 15) >> 4;
   const int ldx = ((Lg + 31) & ~31) + 2;
   const int kmax = nch * 16;
-  const unsigned int nwg = gridDim.x;
-  unsigned int nbar = 0;
+  const unsigned int nslots = (unsigned int)(nblk / 2), per_sweep = nslots * (unsigned int)(nblk - 1);
+  unsigned int nbar = 0;  // (slots served by this workgroup)
+  __shared__ unsigned int s_ticket;
 #ifdef GPET_OJ_PROF
   long long pt[6] = {0, 0, 0, 0, 0, 0};
 #define OJ_T(i) { const long long t_ = clock64(); pt[i] += t_ - tl; tl = t_; }
@@ -926,10 +939,23 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
 #else
 #define OJ_T(i)
 #endif
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    for (int round = 0; round < nblk - 1; ++round) {
+  for (;;) {
+    {
+      if (tid == 0) s_ticket = atomicAdd(&st->ticket, 1u);
+      __syncthreads();
+      const unsigned int t = s_ticket;
+      const int sweep = (int)(t / per_sweep);
+      const unsigned int rem = t - (unsigned int)sweep * per_sweep;
+      const int round = (int)(rem / nslots), slot = (int)(rem - (unsigned int)round * nslots);
+      if (sweep >= max_sweeps) break;
+      // every slot of the earlier rounds finished, and the verdict of the previous sweep known
+      if (!oj_wait_slot(st, t - (unsigned int)slot, sweep, &s_flag)) {
+        if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
+        return;
+      }
+      if (__hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       int bI, bJ;
-      oj_rr_pair(nblk - 1, round, blockIdx.x, bI, bJ);
+      oj_rr_pair(nblk - 1, round, slot, bI, bJ);
       if (bI * OJ_B < rank) {  // (bI < bJ: otherwise both blocks are empty)
         // -- stage: thread t takes columns t, t + 256, ... of every row
         {
@@ -1030,31 +1056,28 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
         }
       }
       OJ_T(3)
-      if (!oj_edge_barrier(&st->bar, nwg * ++nbar, &s_flag)) {
-        if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
-        return;
+      ++nbar;
+      __syncthreads();  // (every wave's row stores and the coupling report are out: hipcc's barrier waits for vmcnt(0))
+      if (tid == 0) {
+        const unsigned int d = atomicAdd(&st->bar, 1u) + 1u;
+        if (d == (unsigned int)(sweep + 1) * per_sweep) {
+          // the sweep's last slot: its verdict (k_oj_check), then the count of published verdicts the next sweep waits for
+          const unsigned long long bits = __hip_atomic_load(&st->maxrel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double mr2 = __longlong_as_double((long long)bits);
+          const int sw = st->sweeps + 1;
+          st->sweeps = sw;
+          const_cast<gpet_scalars*>(D.sc)->lml = (double)sw;
+          __hip_atomic_store(&st->maxrel_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&st->converged, mr2 <= tol2 ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&st->verdicts, sweep + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       OJ_T(4)
     }
-    // the sweep's verdict (k_oj_check): one thread of the edge decides, everybody reads it after one more barrier
-    if (blockIdx.x == 0 && tid == 0) {
-      const unsigned long long bits = __hip_atomic_load(&st->maxrel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double mr2 = __longlong_as_double((long long)bits);
-      const int sw = st->sweeps + 1;
-      st->sweeps = sw;
-      const_cast<gpet_scalars*>(D.sc)->lml = (double)sw;
-      __hip_atomic_store(&st->maxrel_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&st->converged, mr2 <= tol2 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!oj_edge_barrier(&st->bar, nwg * ++nbar, &s_flag)) {
-      if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
-      return;
-    }
-    if (__hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
   }
 #ifdef GPET_OJ_PROF
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 37) && blockIdx.y == 0 && nbar > 0)
-    printf("oj persist wg %d: per barrier: stage %lld | gram %lld | inner sweep %lld | update + stores %lld | barrier %lld cycles (%u barriers)\n", (int)blockIdx.x,
+    printf("oj persist wg %d: per slot: stage %lld | gram %lld | inner sweep %lld | update + stores %lld | ticket + wait %lld cycles (%u slots)\n", (int)blockIdx.x,
            pt[0] / nbar, pt[1] / nbar, pt[2] / nbar, pt[3] / nbar, pt[4] / nbar, nbar);
 #endif
 #undef OJ_T
@@ -1186,7 +1209,8 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   // LDS staging costs a workgroup a whole CU (131 KB): worth it while a round's workgroups (pairs x edges) fit the
   // chip's 256 CUs side by side (one edge: 64 pairs; measured 54 vs 61 ms per factor); a bigger batch runs two
   // register-fed workgroups per CU instead (8 edges: 85 vs 106 ms)
-  const bool staged = bd.Lg <= OJ_STAGE_MAX && (long long)(nblk / 2) * B <= 256 && !getenv("GPET_OJ_NO_STAGE");
+  const bool staged_lds_ok = bd.Lg <= OJ_STAGE_MAX && !getenv("GPET_OJ_NO_STAGE");
+  const bool staged = staged_lds_ok && (long long)(nblk / 2) * B <= 256;
   const size_t stage_lds = (size_t)OJ_M * (((bd.Lg + 31) & ~31) + 2) * sizeof(double);
   if (staged) {
     static int attr_done[64] = {};
@@ -1199,20 +1223,29 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     }
   }
   const double tol2 = pow(10.0, -2.0 * (double)gpet_opt_oj_tol_exp());
-  // staged AND every pair-workgroup of the batch resident at once (one per CU: 131 KB of LDS each): the rounds and sweeps in
-  // one launch, the workgroups of an edge meeting at a barrier in global memory (k_oj_persist); GPET_OJ_PERSIST=0: launches
-  static const int oj_persist = getenv("GPET_OJ_PERSIST") ? atoi(getenv("GPET_OJ_PERSIST")) : 1;
-  if (staged && oj_persist && (long long)(nblk / 2) * B <= 240) {
-    static int attr_done2[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_done2[dev]) {
-      (void)hipFuncSetAttribute((const void*)k_oj_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_oj_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-      attr_done2[dev] = 1;
-    }
-    if (use_args) hipLaunchKernelGGL((k_oj_persist<true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
-    else hipLaunchKernelGGL((k_oj_persist<false>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
+  // staged: the rounds and sweeps in ONE launch (k_oj_persist: pair slots by ticket -- no residency requirement, so the
+  // grid is sized to what the device holds at once and a workgroup serves several slots per round when the batch has more
+  // slots than that; beyond four slots per workgroup and round the round launches' two register-fed workgroups per CU
+  // win); option "oj_persist" (GPET_OJ_PERSIST) = 0: launches
+  static int persist_cap[64] = {};  // workgroups of k_oj_persist the device holds at once (occupancy x CUs), per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (staged_lds_ok && gpet_opt_oj_persist() && dev >= 0 && dev < 64 && !persist_cap[dev]) {
+    (void)hipFuncSetAttribute((const void*)k_oj_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_oj_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    int occ = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_oj_persist<false>, 256, stage_lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
+    persist_cap[dev] = occ * cus;
+    (void)hipGetLastError();
+  }
+  const int cap = (dev >= 0 && dev < 64 && persist_cap[dev] > 0) ? persist_cap[dev] : 64;
+  const long long slots_all = (long long)(nblk / 2) * B;
+  if (staged_lds_ok && gpet_opt_oj_persist() && slots_all <= 4LL * cap) {
+    int wpe = nblk / 2;  // workgroups per edge
+    if (slots_all > cap) wpe = cap / B > 0 ? cap / B : 1;
+    if (use_args) hipLaunchKernelGGL((k_oj_persist<true>), dim3(wpe, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
+    else hipLaunchKernelGGL((k_oj_persist<false>), dim3(wpe, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
   } else
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int round = 0; round < nblk - 1; ++round) {
@@ -1233,6 +1266,11 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
 
 int& gpet_opt_oj_tol_exp() {
   static int v = getenv("GPET_OJ_TOL_EXP") != nullptr ? atoi(getenv("GPET_OJ_TOL_EXP")) : 8;
+  return v;
+}
+
+int& gpet_opt_oj_persist() {
+  static int v = getenv("GPET_OJ_PERSIST") != nullptr ? atoi(getenv("GPET_OJ_PERSIST")) : 1;
   return v;
 }
 

@@ -1024,7 +1024,7 @@ __global__ void __launch_bounds__(1024) k_chol_solve(EdgeDev* edges) {
 // (BACK = true, a second launch): workgroup x owns block nt - 1 - x and subtracts L_ji^T alpha_j for j > i.  In both a
 // workgroup waits only for workgroups with a SMALLER blockIdx.x of the same edge, which the dispatcher started before
 // it: no residency requirement.  z / alpha cross XCDs: agent-scope accesses (as k_oj_persist, gpet_eig.hip); the waiting
-// thread gives up after ~1 s and fails the edge.  The chain per block: flag + 64 values + one 64 x 64 product + the
+// thread gives up after 4 s of wall time and fails the edge.  The chain per block: flag + 64 values + one 64 x 64 product + the
 // substitution, ~2-3 us.
 template <bool BACK>
 __global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch) {
@@ -1078,10 +1078,11 @@ __global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch
     const int njb = (n - j0) < CB ? (n - j0) : CB;
     if (tid == 0) {
       int good = 1;
-      long long spins = 0;
-      while (__hip_atomic_load(flag_mine + jb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      const unsigned long long t0 = wall_clock64();  // (constant 100 MHz)
+      // acquire: the vector the flag announces is read after it (pairs with the release store below)
+      while (__hip_atomic_load(flag_mine + jb, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1ll << 23)) {
+        if (wall_clock64() - t0 > 400000000ull) {  // 4 s of wall time: a fault elsewhere, not contention (no residency needed)
           good = 0;
           break;
         }
@@ -1147,8 +1148,9 @@ __global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch
     }
     if (tid < nb) __hip_atomic_store(dst + k0 + tid, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();  // (the stores are out: hipcc's barrier waits for vmcnt(0))
-  if (tid == 0) __hip_atomic_store(flag_mine + ib, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // (every lane's stores are issued and complete: hipcc's barrier waits for vmcnt(0))
+  // release: the flag becomes visible at agent scope only after the vector it announces
+  if (tid == 0) __hip_atomic_store(flag_mine + ib, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // gpet_set_option "solve_mw" (default 1; environment GPET_SOLVE_MW): 0 = alpha of the blocked fit by the single-workgroup

@@ -65,8 +65,11 @@ def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity
     x = np.linspace(-np.pi, np.pi, N)
     A = M // 2 if amplitude > M else amplitude // 2
     cols = np.arange(N)
-    if ltype == "sinusoidal":
+    wave2 = None  # second edge of the two multi-sinusoidal types (gpet_utils.py:203-220)
+    if ltype in ("sinusoidal", "multi-sinusoidal", "close multi-sinusoidal"):
         wave = (np.rint(A * np.sin(N * curvature * x)) + M // 2).astype(int)
+        if ltype != "sinusoidal":
+            wave2 = wave + (A // 2 if ltype == "multi-sinusoidal" else A // 6)
     elif ltype == "co-sinusoidal":
         wave = (np.rint(A * np.cos(N * curvature * x)) + M // 2).astype(int)
     elif ltype == "diag":
@@ -74,8 +77,12 @@ def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity
     elif ltype == "straight":
         wave = np.full(N, M // 2, dtype=int)
     else:
-        raise ValueError("ltype must be one of sinusoidal, co-sinusoidal, diag, straight")
-    img[np.arange(M)[:, None] >= wave[None, :]] = intensity
+        raise ValueError("ltype must be one of sinusoidal, multi-sinusoidal, close multi-sinusoidal, co-sinusoidal, "
+                         "diag, straight")
+    rows = np.arange(M)[:, None]
+    img[rows >= wave[None, :]] = intensity
+    if wave2 is not None:  # the band below the second edge is 1 - intensity
+        img[rows >= wave2[None, :]] = 1 - intensity
     if gaps:
         img[:, 20:30] = 0
         img[:, N // 2:(N // 2 + 10)] = 0
@@ -83,7 +90,10 @@ def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity
         img[:, N // 4:(N // 4 + 20)] = 0
     rng = np.random.default_rng(seed)
     img = np.clip(img + rng.normal(0.0, math.sqrt(noise_level), img.shape), 0.0, 1.0)
-    return img, np.stack([wave, cols], axis=1)
+    edge = np.stack([wave, cols], axis=1)
+    if wave2 is not None:  # both edges, one after the other (2N rows), as the reference returns them
+        edge = np.concatenate([edge, np.stack([wave2, cols], axis=1)], axis=0)
+    return img, edge
 
 
 def trace_MSE(edge_pred, edge_true):

@@ -87,6 +87,8 @@ def add_white(kernel, white):
 
 
 class GaussianProcessRegressor(object):
+    _CACHE_MAX = 2  # device batches kept per regressor (one for predict/LML, one for sample_y is the usual pair)
+
     def __init__(self, kernel=None, alpha=1e-10, optimizer=None, n_restarts_optimizer=0, normalize_y=False,
                  copy_X_train=True, random_state=None, *, device=0, _ctx=None):
         if optimizer is not None and optimizer != "fmin_l_bfgs_b":
@@ -127,7 +129,7 @@ class GaussianProcessRegressor(object):
             raise NotImplementedError("more than 16384 training points (the n x n kernel matrix lives in HBM per edge)")
         self._fit = dict(kt=kt, nu=nu, const=const, ell=ell, x=X[:, 0].copy(), yt=yt, noise=nl * w + alpha)
         self.X_train_, self.y_train_ = X, yt
-        self.log_marginal_likelihood_value_ = None
+        self._lml_value = None  # optimizer=None: evaluated on first access (sklearn_gpr.py:296-299 computes it in fit)
         if self.optimizer is not None:
             self._optimise(const, ell, nl, w, alpha, white)
         return self
@@ -150,16 +152,30 @@ class GaussianProcessRegressor(object):
             if not np.all(np.isfinite(bounds)):
                 raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
             rng = self.random_state if isinstance(self.random_state, np.random.RandomState) else np.random.RandomState(self.random_state)
+            # the reference draws over kernel_.bounds (sklearn_gpr.py:283-288): the NON-FIXED hyper-parameters only, in theta
+            # order -- a "fixed" one (lo == hi) or the absent noise level takes no number from the stream
+            free = bounds[:, 0] != bounds[:, 1]
             for _ in range(self.n_restarts_optimizer):
-                starts.append(rng.uniform(bounds[:, 0], bounds[:, 1]))
+                th = np.array(theta0, dtype=np.float64)
+                th[free] = rng.uniform(bounds[free, 0], bounds[free, 1])
+                starts.append(th)
         b = self._batch_for(np.arange(4.0), 1, False)
         b.final_set_training_all([f["x"]], [f["yt"]], [weights])
         theta, fmin, self._opt_rounds = b.final_optimize(np.asarray(starts)[None], bounds)
         c_opt, l_opt, nl_opt = np.exp(theta[0])
-        self.log_marginal_likelihood_value_ = -float(fmin[0])
+        self._lml_value = -float(fmin[0])
         self.kernel_theta_ = theta[0].copy()
         f.update(const=float(c_opt), ell=float(l_opt), noise=(nl_opt * w + alpha) if white is not None else f["noise"])
         self._fit_nl = float(nl_opt) if white is not None else 1.0
+
+    @property
+    def log_marginal_likelihood_value_(self):
+        """Log marginal likelihood at the fitted hyper-parameters: the optimum's with an optimiser; with
+        ``optimizer=None`` the reference evaluates it inside ``fit`` (sklearn_gpr.py:296-299) -- here on first access,
+        so the tracer's fits do not pay a second Cholesky for a number nobody reads."""
+        if self._lml_value is None and getattr(self, "_fit", None) is not None:
+            self._lml_value = float(self.log_marginal_likelihood())
+        return self._lml_value
 
     def _batch_for(self, X, n_samples, want_factor):
         """The device batch of one edge whose grid is the query progression: built once per (length, samples, factor)
@@ -167,9 +183,19 @@ class GaussianProcessRegressor(object):
         f = self._fit
         xq = np.asarray(X, dtype=np.float64).reshape(-1)
         Lq = xq.shape[0]
-        key = (Lq, max(1, int(n_samples)), bool(want_factor), f["kt"], f["nu"], max(8, len(f["x"])))
-        b = self._batches.get(key)
-        if b is None:
+        # training capacity rounded up to a power of two: refits with a few more points reuse the arena.  The batch's own
+        # length scale is NOT part of the key: every call passes the hyper-parameters through `par`
+        # (gpet_final_predict_all / gpet_lml_batch), params.length_scale only sizes the construction-time defaults.
+        cap = 8
+        while cap < len(f["x"]):
+            cap *= 2
+        key = (Lq, max(1, int(n_samples)), bool(want_factor), f["kt"], f["nu"], cap)
+        b = self._batches.pop(key, None)
+        if b is not None:
+            self._batches[key] = b  # (most recently used last)
+        else:
+            while len(self._batches) >= self._CACHE_MAX:  # an arena holds an n_cap x n_cap K: evict the least recently used
+                self._batches.pop(next(iter(self._batches))).close()
             p = _lib.GpetParams()
             p.kernel_type = _lib.KERNEL_MATERN if f["kt"] == "Matern" else _lib.KERNEL_RBF
             p.nu, p.sigma_f, p.length_scale, p.noise_y = f["nu"], 1.0, f["ell"], 1.0

@@ -144,7 +144,7 @@ def test_many_observations_take_the_streamed_factor_path(amd, ctx):
 def test_lml_objective_with_two_tiles_per_thread(amd, ctx, kernel, nu, n):
     """128 < n <= 250 training points (delta_x = 2..3 on wide edges): the sweep kernel with two 4x4 tiles per thread
     vs the oracle's Cholesky-based objective and gradient (sklearn_gpr.py:512-585)."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     N = 2 * n + 8
     grad, truth = _image(N, 5)
     init = truth[[0, -1], :][:, [1, 0]]
@@ -190,7 +190,7 @@ def test_lml_objective_every_size_class(amd, ctx, two_tiles_from):
     of 4 where the tile count and the border move, one problem per edge with DIFFERENT n in one launch (the launch is
     sized for the largest), single-problem launches; with one 4x4 tile per thread (small launches) and with two (the
     form big launches take, option lml_two_tiles_from).  vs the oracle."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     L = amd._lib
     N = 520
     grad, truth = _image(N, 5)
@@ -354,11 +354,31 @@ def test_batch_with_edges_of_different_length(amd, ctx):
         assert out[e].shape == single.shape and np.array_equal(out[e], single), "edge %d" % e
 
 
+def test_batch_with_edges_of_equal_length_and_different_first_column(amd, ctx):
+    """Edges of the same length, kernel and length scale share ONE prior eigenbasis only when they also start in the same
+    column: the lags are formed as fl((x_st+i)/l) - fl((x_st+j)/l), which depends on x_st in the last bits unless l is a
+    power of two (l = 3: 23 % of the entries differ by up to 1.6e-14 between x_st = 0 and 7).  An edge must never inherit
+    another start column's basis -- its trace would depend on the batch's composition: every edge equals its
+    single-edge run, and the edges that DO start together (0 and 3) still share."""
+    grad, truth = _image(96, 4)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 3}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=4, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    spans = [(0, 59), (7, 66), (30, 89), (0, 59), (7, 66)]
+    inits = [np.array([[a, int(truth[a, 0])], [b, int(truth[b, 0])]]) for a, b in spans]
+    seeds = [3, 4, 5, 6, 7]
+    bt = amd.GP_Edge_Tracing_Batch(inits, grad, seeds, **kw, _ctx=ctx)
+    assert bt._batch.info()["structured"] == 1
+    out = bt()
+    for e, (init, seed) in enumerate(zip(inits, seeds)):
+        single = amd.GP_Edge_Tracing(init, grad, seed=seed, **kw, _ctx=ctx)()
+        assert out[e].shape == single.shape and np.array_equal(out[e], single), "edge %d" % e
+
+
 @pytest.mark.parametrize("kernel,nu,n", [("RBF", 2.5, 251), ("Matern", 2.5, 400), ("Matern", 1.5, 700)])
 def test_lml_objective_beyond_250_points_blocked_path(amd, ctx, kernel, nu, n):
     """More than 250 training points (wide edge, delta_x = 2): the objective runs on the blocked HBM path -- virtual
     edges, blocked Cholesky, L^-1, tiles of K^-1 on the matrix cores contracted with dK/dtheta -- vs the oracle."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     N = 2 * n + 8
     grad, truth = _image(N, 5)
     init = truth[[0, -1], :][:, [1, 0]]

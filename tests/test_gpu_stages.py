@@ -383,6 +383,59 @@ def test_gaussian_process_regressor_optimizer(amd, ctx):
         GaussianProcessRegressor(kernel=kd, optimizer=lambda *a: None, _ctx=ctx)
 
 
+def test_gaussian_process_regressor_restarts_over_free_dims_lml_value_and_cache(amd, ctx):
+    """(1) Restarts are drawn over the NON-FIXED hyper-parameters only (the reference draws over kernel_.bounds,
+    sklearn_gpr.py:283-288): with the noise level fixed a restart takes two numbers from RandomState, not three, so the
+    second restart onwards still starts where the reference's does.  (2) optimizer=None: log_marginal_likelihood_value_ is
+    the LML at the kernel's own hyper-parameters (sklearn_gpr.py:296-299), not None.  (3) the per-shape cache of device
+    batches is bounded (two entries), refits with a few more points reuse an arena."""
+    import scipy.optimize
+    from gaussian_process_edge_trace_amd.sklearn_gpr import GaussianProcessRegressor, WeightedWhiteKernel
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.choice(np.arange(0, 200), size=40, replace=False)).astype(float)
+    y = 3 * np.cos(x / 18.0) + rng.normal(0, 0.2, x.size) - 2.0
+    w = np.ones(x.size)
+    xq = np.arange(0, 200, dtype=float)
+    bounds = np.array([[1e-2, 1e3], [1.0, 150.0], [0.25, 0.25]])  # noise level fixed
+    white = WeightedWhiteKernel(noise_weight=w, edge_length=xq.size, noise_level=0.25)
+    kd = dict(kernel="RBF", nu=2.5, constant=1.5, length_scale=15.0, white=white, bounds=bounds)
+    gp = GaussianProcessRegressor(kernel=kd, alpha=1e-6, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=3, normalize_y=False,
+                                  random_state=7, _ctx=ctx).fit(x[:, None], y)
+    yt = (y - y.mean()) / y.std()
+    lb = np.log(bounds)
+    th0 = np.log([1.5, 15.0, 0.25])
+    r = np.random.RandomState(7)
+    starts = [th0]
+    for _ in range(3):
+        th = th0.copy()
+        th[:2] = r.uniform(lb[:2, 0], lb[:2, 1])
+        starts.append(th)
+
+    def obj(th):
+        lml, g = orc.lml_and_grad(th, x, yt, w, "RBF", 2.5)
+        return -lml, -g
+    res = [scipy.optimize.minimize(obj, s0, method="L-BFGS-B", jac=True, bounds=list(map(tuple, lb))) for s0 in starts]
+    best = min(res, key=lambda q: q.fun)
+    np.testing.assert_allclose(-gp.log_marginal_likelihood_value_, best.fun, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(gp.kernel_theta_, best.x, rtol=0, atol=2e-3)
+    assert gp.kernel_theta_[2] == th0[2]
+    # (2)
+    gp0 = GaussianProcessRegressor(kernel=kd, alpha=1e-6, optimizer=None, normalize_y=False, _ctx=ctx).fit(x[:, None], y)
+    lml0, _ = orc.lml_and_grad(th0, x, yt, w, "RBF", 2.5)
+    np.testing.assert_allclose(gp0.log_marginal_likelihood_value_, lml0, rtol=1e-9)
+    # (3)
+    gp3 = GaussianProcessRegressor(kernel=dict(kernel="RBF", nu=2.5, constant=1.5, length_scale=15.0), alpha=1e-2,
+                                   normalize_y=True, _ctx=ctx)
+    for n in (40, 38, 36, 33):  # capacities round up to 64: one arena
+        gp3.fit(x[:n, None], y[:n]).predict(xq[:, None])
+    assert len(gp3._batches) == 1
+    for Lq in (200, 180, 160, 140):
+        m_ = gp3.predict(np.arange(Lq, dtype=float)[:, None])
+        assert m_.shape == (Lq,) and len(gp3._batches) <= 2
+    for g_ in (gp, gp0, gp3):
+        g_.close()
+
+
 def test_gaussian_process_regressor_mirror_many_points(amd, ctx):
     """The GPR mirror beyond the LDS-resident sizes: 300 training points (K and the factor in HBM)."""
     from gaussian_process_edge_trace_amd.sklearn_gpr import GaussianProcessRegressor, WeightedWhiteKernel

@@ -158,7 +158,7 @@ def test_trace_quality_band(amd, ctx):
 
 def test_lml_kernel_vs_oracle(amd, ctx, golden):
     """f2: batched -log marginal likelihood + gradient (sklearn_gpr.py:512-585) vs the oracle."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128")]:
         g = golden(name)
         grad = golden(stage)["ref_grad"]
@@ -219,7 +219,7 @@ def test_device_training_sets_and_start_points_equal_numpy(amd, ctx, golden):
     """gpet_final_fit_all builds its inputs on the device: sorted training set standardised twice (gpet.py:235-238,
     sklearn_gpr.py:229-234) with numpy's pairwise summation order, and theta0 + 12 restarts from MT19937
     (sklearn_gpr.py:283-288).  Bit-identical to the NumPy restatement (= the reference's own arithmetic)."""
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     L = amd._lib
     for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128"), ("trace_rbf65", "stage_rbf65")]:
         g = golden(name)
@@ -245,7 +245,7 @@ def test_device_lbfgsb_against_scipy_on_the_same_objective(amd, ctx, golden):
     calls, sklearn_gpr.py:589) driving the SAME device objective from the same 13 start points: per restart the same
     minimum to 1e-7 relative (flat noise directions aside, theta to 1e-3), and the same best restart."""
     import scipy.optimize
-    from gaussian_process_edge_trace_amd import _final_fit as ff
+    from tests import final_fit_inputs as ff
     L = amd._lib
     for name, stage in [("trace_rbf500", "stage_rbf500"), ("trace_mat128", "stage_mat128")]:
         g = golden(name)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from gaussian_process_edge_trace_amd import gpet as G
-from gaussian_process_edge_trace_amd import _final_fit as ff
+from tests import final_fit_inputs as ff
 from oracle import gpet_oracle as orc
 
 CASES = [
@@ -66,6 +66,33 @@ def test_kernel_builder_and_synthetic_generator_match_oracle():
     shifted = edge.copy()
     shifted[:, 0] += 3
     assert U.trace_MSE(shifted, edge) == 9.0 and 0.9 < U.trace_dicecoef(shifted, edge) < 1.0
+
+
+def test_multi_sinusoidal_generators_follow_the_reference_recipe():
+    """The two two-edge image types (gpet_utils.py:203-220): per column the first edge at rint(A sin) + M//2, the second
+    A//2 (resp. A//6) rows below it, the band under the second edge at 1 - intensity; the truth holds both edges, one
+    after the other.  Checked against the recipe written out column by column (no noise)."""
+    from gaussian_process_edge_trace_amd import gpet_utils as U
+    M = N = 96
+    for ltype, div in (("multi-sinusoidal", 2), ("close multi-sinusoidal", 6)):
+        img, edge = U.construct_test_img((M, N), 40, 4, 0.0, ltype, 0.3, gaps=True, seed=1)
+        A = 40 // 2
+        x = np.linspace(-np.pi, np.pi, N)
+        ref = np.zeros((M, N))
+        y0 = []
+        for j in range(N):
+            w = int(np.rint(A * np.sin(N * 4 * x[j])) + M // 2)
+            y0.append(w)
+            ref[w:M, j] = 0.3
+            ref[w + A // div:M, j] = 1 - 0.3
+        for a, b in ((20, 30), (N // 2, N // 2 + 10), (N - 100, N - 90), (N // 4, N // 4 + 20)):
+            ref[:, a:b] = 0  # (N - 100 < 0 here: the empty slice of the reference)
+        assert np.array_equal(img, ref)
+        assert edge.shape == (2 * N, 2)
+        assert np.array_equal(edge[:N, 0], y0) and np.array_equal(edge[N:, 0], np.asarray(y0) + A // div)
+        assert np.array_equal(edge[:N, 1], np.arange(N)) and np.array_equal(edge[N:, 1], np.arange(N))
+    with pytest.raises(ValueError):
+        U.construct_test_img((M, N), 40, 4, 0.0, "zigzag", 0.3)
 
 
 def test_host_start_points_are_the_reference_restarts():
