@@ -277,6 +277,18 @@ static int& opt_rng_chunked() {
   return v;
 }
 
+// One sequential walk per stream: the register-resident generator (four streams per wave, gpet_rng.hip) when the batch is
+// homogeneous and the launch has enough streams to fill the GPU with single waves (2 048 = half of its SIMDs; a wave of
+// four streams takes ~2.5 ms against 0.6 ms for a three-wave workgroup per stream, so small launches keep the old kernel),
+// else one workgroup per stream (k_mt_normals).  The same numbers either way.
+static hipError_t launch_normals_seq(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l,
+                                     int add_iter, int iter_abs, int n_ahead, int z_store) {
+  const int opt = gpet_opt_rng4();
+  if (b->bd.rng4 && (opt > 0 || (opt < 0 && (long long)B_l * n_ahead >= 2048)))
+    return launch_normals4(st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store, b->bd.Lg, b->bd.S, b->bd.z_cols);
+  return launch_normals(st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store);
+}
+
 // The normals of `n_ahead` iterations of B_l edges: one workgroup per stream (k_mt_normals), or -- when that leaves
 // most of the GPU idle and the streams are long -- every stream cut into chunks that many workgroups generate at once
 // (MT19937 jump-ahead, launch_normals_chunked).  The same numbers either way.
@@ -290,9 +302,10 @@ static int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l
   const int streams = B_l * n_ahead;
   const int nc = mtj_chunks((long long)b->bd.S * b->bd.Lg);
   const int opt = opt_rng_chunked();
-  const bool chunked = nc >= 2 && (opt > 0 || (opt < 0 && streams <= 32 && nc >= 4));
+  const bool force4 = gpet_opt_rng4() > 0 && b->bd.rng4;  // (tests: the register-resident generator on any launch shape)
+  const bool chunked = !force4 && nc >= 2 && (opt > 0 || (opt < 0 && streams <= 32 && nc >= 4));
   if (!chunked) {
-    HIPCHK(c, launch_normals(st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store));
+    HIPCHK(c, launch_normals_seq(b, st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store));
     return GPET_OK;
   }
   const size_t need = mtj_work_bytes(streams, nc);
@@ -394,6 +407,12 @@ int gpet_set_option(const char* name, int value) {
     const int old = v;
     v = value < 4 ? 4 : (value > 15 ? 15 : value);
     return old;
+  }
+  if (name && strcmp(name, "rng4") == 0) {
+    int& v = gpet_opt_rng4();
+    const int old = v;
+    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
+    return old < 0 ? 2 : old;  // (2 = "by the number of streams of the launch")
   }
   if (name && strcmp(name, "oj_persist") == 0) {
     int& v = gpet_opt_oj_persist();
@@ -680,6 +699,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     if (bd.z_ring == 0 || E.z_ring < bd.z_ring) bd.z_ring = E.z_ring;
     bd.jlog = E.jlog_cap > 0 ? 1 : 0;
   }
+  bd.rng4 = normals4_applies(b->h_edges.data(), B) ? 1 : 0;
   b->bd = bd;
   // measure, allocate, carve
   const size_t px = (size_t)M * N;
@@ -1327,7 +1347,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
         HIPCHK(c, launch_struct_iteration(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 120))); break;
       case 2:
         if (b->rng_mode == 1) HIPCHK(c, launch_normals_philox(c->stream, b->d_edges, b->B, b->bd, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b)));
-        else HIPCHK(c, launch_normals(c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b)));
+        else HIPCHK(c, launch_normals_seq(b, c->stream, b->d_edges, b->B, b->d_seeds, 1, -1, b->bd.z_ring, loop_z_store(b)));
         break;
       case 3: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
       case 4: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd)); break;

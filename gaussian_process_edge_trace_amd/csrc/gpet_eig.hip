@@ -898,7 +898,8 @@ __device__ __forceinline__ bool oj_wait_slot(EigState* st, unsigned int need_don
     *s_flag = ok;
   }
   __syncthreads();
-  return *s_flag != 0;
+  // (readfirstlane: the verdict is the same in every lane, and the compiler has to KNOW it -- see the loop below)
+  return __builtin_amdgcn_readfirstlane(*s_flag) != 0;
 }
 
 template <bool ARGS>
@@ -939,11 +940,18 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
 #else
 #define OJ_T(i)
 #endif
+  if (tid == 0) s_ticket = atomicAdd(&st->ticket, 1u);
   for (;;) {
     {
-      if (tid == 0) s_ticket = atomicAdd(&st->ticket, 1u);
+      // Two things the compiler must not get wrong here.  (1) Every exit of this loop has to be a branch it KNOWS to be
+      // uniform (hence the readfirstlanes on what comes out of LDS or global memory).  (2) There is exactly ONE
+      // `if (tid == 0)` per trip: thread 0 counts the slot finished AND takes the next ticket in the same block at the
+      // end of the trip.  With a second one at the top of the loop the compiler threads the two (thread 0: tail -> head;
+      // everybody else: neither), which makes two cycles; it nests them, and the lanes that are not thread 0 then run
+      // the barriers of the next trip on the old ticket while thread 0 waits for them to leave the loop -- the first
+      // form of this kernel hung exactly so.
       __syncthreads();
-      const unsigned int t = s_ticket;
+      const unsigned int t = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_ticket);
       const int sweep = (int)(t / per_sweep);
       const unsigned int rem = t - (unsigned int)sweep * per_sweep;
       const int round = (int)(rem / nslots), slot = (int)(rem - (unsigned int)round * nslots);
@@ -953,7 +961,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
         if (tid == 0) const_cast<gpet_scalars*>(D.sc)->status = GPET_ERR_STATE;
         return;
       }
-      if (__hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&st->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
       int bI, bJ;
       oj_rr_pair(nblk - 1, round, slot, bI, bJ);
       if (bI * OJ_B < rank) {  // (bI < bJ: otherwise both blocks are empty)
@@ -1059,6 +1067,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
       ++nbar;
       __syncthreads();  // (every wave's row stores and the coupling report are out: hipcc's barrier waits for vmcnt(0))
       if (tid == 0) {
+        s_ticket = atomicAdd(&st->ticket, 1u);  // (the next trip's; read after the barrier at the top)
         const unsigned int d = atomicAdd(&st->bar, 1u) + 1u;
         if (d == (unsigned int)(sweep + 1) * per_sweep) {
           // the sweep's last slot: its verdict (k_oj_check), then the count of published verdicts the next sweep waits for

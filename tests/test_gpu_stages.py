@@ -163,6 +163,60 @@ def test_normals_stream_chunked_equals_sequential(amd, ctx, golden, name, z_cols
     np.testing.assert_allclose(out[1], ref, rtol=0, atol=5e-15)
 
 
+@pytest.mark.parametrize("name,z_cols,n_samples", [("stage_rbf500", 72, 1000), ("stage_rbf500", 96, 1000), ("stage_rbf500", 250, 1000),
+                                                   ("stage_rbf500", 500, 1000), ("stage_rbf500", 71, 333), ("stage_rbf64", 64, 700),
+                                                   ("stage_rbf64", 16, 2000), ("stage_rbf64", 1, 128), ("stage_mat128", 128, 256)])
+def test_normals_stream_register_resident_generator(amd, ctx, golden, name, z_cols, n_samples):
+    """k_mt_normals4 (csrc/gpet_rng.hip: MT19937 state in registers, four streams per wave, float32 pre-filter of the accept
+    test, queued evaluation of the stored pairs; option rng4 = 1 forces it on any launch shape) against the one-workgroup-
+    per-stream generator bit for bit and against numpy's RandomState(seed).standard_normal: the sparse form (<= 96 stored
+    columns of a wide row), the dense form (everything stored, or a narrow row), odd column counts, a single column."""
+    g = golden(name)
+    L = amd._lib
+    kw = dict(CTOR[name], N_samples=n_samples)
+    seed = 424242
+    out = {}
+    for mode in (0, 1):
+        old4, oldc = L.set_option("rng4", mode), L.set_option("rng_chunked", 0)
+        try:
+            tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **kw, _ctx=ctx, z_cols=z_cols)
+            tr._batch.normals([seed])
+            out[mode] = tr._batch.read(L.BUF_NORMALS)
+        finally:
+            L.set_option("rng4", -1 if old4 == 2 else old4)
+            L.set_option("rng_chunked", -1 if oldc == 2 else oldc)
+    assert out[1].shape == (n_samples, z_cols)
+    N = int(g["ref_scalars"][8])
+    ref = orc.legacy_standard_normal(seed, n_samples * N).reshape(n_samples, N)[:, :z_cols]
+    np.testing.assert_allclose(out[1], ref, rtol=0, atol=5e-15)
+    assert np.array_equal(out[0], out[1])
+
+
+def test_normals_register_resident_generator_batch_ring_and_loop(amd, ctx, golden):
+    """The same generator where it runs in production: a batch (streams = edges x iterations ahead, four per wave, the last
+    wave partly filled), every ring slot of the loop's look-ahead, finished edges skipped -- whole traces and iteration
+    counts equal those of the one-workgroup-per-stream generator."""
+    g = golden("stage_rbf500")
+    L = amd._lib
+    kw = dict(CTOR["stage_rbf500"])
+    kw.pop("seed")
+    B = 7
+    seeds = [5 + 997 * e for e in range(B)]
+    res = {}
+    for mode in (0, 1):
+        old4 = L.set_option("rng4", mode)
+        try:
+            bt = amd.GP_Edge_Tracing_Batch([g["in_init"]] * B, g["ref_grad"], seeds, **kw, _ctx=ctx)
+            assert bt._batch.info()["structured"] == 1
+            res[mode] = ([np.asarray(t) for t in bt()], bt.timings["iters"])
+            bt._batch.close()
+        finally:
+            L.set_option("rng4", -1 if old4 == 2 else old4)
+    assert res[0][1] == res[1][1]
+    for a, c in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a, c)
+
+
 def test_normals_stream_config3_shape(amd, ctx):
     """BASELINE config 3's stream: RandomState(seed).standard_normal((4000, 2048)) = 8.2 M normals of ONE stream (21 M words,
     ~525 chunks, ten doubling levels of the jump-ahead), chosen automatically for a single edge; against numpy's own
