@@ -46,19 +46,48 @@ __device__ __forceinline__ unsigned int r4_dppz(unsigned int v) {  // row shift;
 #define R4_SHL(n) (0x100 + (n))
 #define R4_SHR(n) (0x110 + (n))
 
-__device__ __forceinline__ unsigned int r4_mix(unsigned int a, unsigned int b) {
-  const unsigned int y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
-  return (y >> 1) ^ ((b & 1u) ? 0x9908B0DFu : 0u);
+// The constants of the recurrence and of the tempering as OPAQUE scalar registers: with literal constants the compiler
+// folds the masks into and / and-or / xor sequences; with a register it selects the three-operand forms (v_bfi_b32 for
+// the 1 + 31 bit merge, v_bitop3_b32 for y ^ (t & mask)) -- a vector instruction less per word and step.
+struct R4Consts {
+  unsigned int lo31, mag, tb, tc;
+};
+__device__ __forceinline__ R4Consts r4_consts() {
+  R4Consts k;
+  asm volatile("s_mov_b32 %0, 0x7fffffff" : "=s"(k.lo31));
+  asm volatile("s_mov_b32 %0, 0x9908b0df" : "=s"(k.mag));
+  asm volatile("s_mov_b32 %0, 0x9d2c5680" : "=s"(k.tb));
+  asm volatile("s_mov_b32 %0, 0xefc60000" : "=s"(k.tc));
+  return k;
+}
+// (the compiler keeps and + and-or / and + xor even with register masks, so the two three-operand instructions are spelled
+//  out; plain vector ALU operations whose results feed ordinary instructions -- never a DPP source or a lane read, the
+//  cases whose wait states the compiler's hazard pass would not see behind inline assembly)
+__device__ __forceinline__ unsigned int r4_bfi(unsigned int mask, unsigned int one, unsigned int zero) {  // (one & mask) | (zero & ~mask)
+  unsigned int d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(one), "v"(zero));
+  return d;
+}
+__device__ __forceinline__ unsigned int r4_xor_and(unsigned int y, unsigned int t, unsigned int mask) {  // y ^ (t & mask)
+  unsigned int d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x78" : "=v"(d) : "v"(y), "v"(t), "s"(mask));
+  return d;
+}
+__device__ __forceinline__ unsigned int r4_mix(const R4Consts& k, unsigned int a, unsigned int b) {
+  const unsigned int y = r4_bfi(k.lo31, b, a);
+  return (y >> 1) ^ ((unsigned int)(-(int)(b & 1u)) & k.mag);
 }
 // tempering without its last step (y ^= y >> 18): what the float32 pre-filter reads
-__device__ __forceinline__ unsigned int r4_temper3(unsigned int y) {
+__device__ __forceinline__ unsigned int r4_temper3(const R4Consts& k, unsigned int y) {
+  y ^= y >> 11;
+  y = r4_xor_and(y, y << 7, k.tb);
+  y = r4_xor_and(y, y << 15, k.tc);
+  return y;
+}
+__device__ __forceinline__ unsigned int r4_temper(unsigned int y) {  // (the rare paths: literal constants)
   y ^= y >> 11;
   y ^= (y << 7) & 0x9D2C5680u;
   y ^= (y << 15) & 0xEFC60000u;
-  return y;
-}
-__device__ __forceinline__ unsigned int r4_temper(unsigned int y) {
-  y = r4_temper3(y);
   return y ^ (y >> 18);
 }
 
@@ -106,6 +135,20 @@ __device__ __attribute__((noinline)) void r4_drain_call(const uint4* q_w, const 
   r4_drain_body(q_w, q_d, z0, z1, z2, z3, qhead, count);
 }
 
+// The double-precision accept test of legacy_gauss for the attempts the float32 pre-filter cannot decide (~1e-4 of them):
+// numpy's own comparison.  Not inlined: ten copies (one per group of the unrolled block) would be 4 KB of code that runs
+// once in 250 groups.
+__device__ __attribute__((noinline)) bool r4_exact_accept(unsigned int ta, unsigned int wb, unsigned int tc, unsigned int wd) {
+#pragma clang fp contract(off)
+  const unsigned int a = (ta ^ (ta >> 18)) >> 5, b = r4_temper(wb) >> 6;
+  const unsigned int c = (tc ^ (tc >> 18)) >> 5, d = r4_temper(wd) >> 6;
+  const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+  const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
+  const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
+  const double r2 = x1 * x1 + x2 * x2;
+  return !(r2 >= 1.0 || r2 == 0.0);
+}
+
 }  // namespace
 
 // grid = ceil(streams / 4) single-wave workgroups; stream L = 4 blockIdx.x + (lane >> 4) -> edge L / n_ahead, iteration
@@ -127,17 +170,15 @@ __global__ void __launch_bounds__(64) k_mt_normals4(EdgeDev* edges, const unsign
 #pragma unroll
   for (int r = 0; r < 40; ++r) R[r] = 0u;
   double* Zb[4];
-  // stream position, wave-uniform: pairs LEFT in the current sample row (H at its start) and the row; `live`: bit s = stream
-  // s still has rows to fill
-  int rem[4], row[4];
-  unsigned int live = 0u;
+  // position of MY stream (the same value in the sixteen lanes of its row): pairs LEFT in the current sample row (H at its
+  // start), the row, and whether the stream still has rows to fill.  One vector instruction advances all four streams.
+  int rem = H, row = 0;
+  bool live = false;
   // ---- per stream: edge, ring slot, seed -> init_genrand into the stream's row (word i -> register 4 g + j, lane 16 s + t)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int L = 4 * (int)blockIdx.x + s;
     Zb[s] = nullptr;
-    rem[s] = H;
-    row[s] = 0;
     if (L < n_streams) {
       const int e_idx = L / n_ahead, ahead = L - e_idx * n_ahead;
       // (loads through pointers the compiler cannot prove read-only come back in vector registers and would make everything
@@ -150,7 +191,7 @@ __global__ void __launch_bounds__(64) k_mt_normals4(EdgeDev* edges, const unsign
         const int iter_idx = (iter_abs >= 0 ? iter_abs : r4_uni(sc->iter)) + ahead;
         const int ring = r4_uni(E.z_ring);
         Zb[s] = (double*)r4_uni_ptr(E.Z) + (size_t)(iter_idx % ring) * ((size_t)S * zc);
-        live |= 1u << s;
+        if (my_s == s) live = true;
         unsigned int p = (unsigned int)r4_uni((int)seeds[e_idx]) + (add_iter ? (unsigned int)(iter_idx + 1) : 0u);  // gpet.py:839
 #pragma unroll
         for (int g = 0; g < 10; ++g) {
@@ -169,14 +210,15 @@ __global__ void __launch_bounds__(64) k_mt_normals4(EdgeDev* edges, const unsign
     }
   }
   const unsigned int keep12 = tl < 12 ? 0xFFFFFFFFu : 0u;  // the last group's four registers hold words in lanes 0..11 only
-  const unsigned int below = (1u << tl) - 1u;              // lanes of my row before me
   unsigned int qhead = 0, qtail = 0;                       // (wave-uniform)
   auto drain = [&](unsigned int count) {
     r4_drain_call(q_w, q_d, Zb[0], Zb[1], Zb[2], Zb[3], qhead, count);
     qhead += count;
   };
   const int max_blocks = (int)(((long long)S * H) / 100) + 64;  // (an acceptance below 64 % does not happen: a guard, not a limit)
-  for (int blk = 0; blk < max_blocks && live != 0u; ++blk) {
+  const unsigned int below = (1u << tl) - 1u;  // the lanes of my row before me
+  const R4Consts K = r4_consts();
+  for (int blk = 0; blk < max_blocks && __builtin_amdgcn_ballot_w64(live) != 0ull; ++blk) {
     // ---- twist: the next 624 words, in place (ascending groups: sources 6-7 groups ahead are still old, 3-4 back already new)
 #pragma unroll
     for (int g = 0; g < 10; ++g) {
@@ -187,7 +229,7 @@ __global__ void __launch_bounds__(64) k_mt_normals4(EdgeDev* edges, const unsign
       else t1 = r4_dppz<R4_SHL(1)>(R[36]) | r4_dppz<R4_SHR(11)>(R[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        unsigned int x = r4_mix(R[4 * g + j], j < 3 ? R[4 * g + j + 1] : t1);
+        unsigned int x = r4_mix(K, R[4 * g + j], j < 3 ? R[4 * g + j + 1] : t1);
         const int js = (j + 1) & 3;  // the source word's register within its group
         if (g <= 3) {                // words <= 226: old word i + 397 = 6 groups + 3 lanes + 1 register on
           if (j < 3) {
@@ -214,67 +256,48 @@ __global__ void __launch_bounds__(64) k_mt_normals4(EdgeDev* edges, const unsign
     // ---- 156 polar attempts per stream: group g = attempts 16 g + t, words in registers 4 g .. 4 g + 3 of lane t
 #pragma unroll
     for (int g = 0; g < 10; ++g) {
-      const unsigned int ta = r4_temper3(R[4 * g]), tc = r4_temper3(R[4 * g + 2]);
+      const unsigned int ta = r4_temper3(K, R[4 * g]), tc = r4_temper3(K, R[4 * g + 2]);
       // x ~ (word - 2^31) / 2^31 (exactly: (a - 2^26) / 2^26 + b / 2^52 with a = word >> 5): r2 in units of 2^62
       const float xf = (float)(int)(ta ^ 0x80000000u), yf = (float)(int)(tc ^ 0x80000000u);
       const float rf = xf * xf + yf * yf;
       constexpr float kOne = 4611686018427387904.0f;  // 2^62
-      bool ok = rf < kOne * (1.0f - 5e-5f);           // accepted for certain
-      const bool grey = !(ok || rf > kOne * (1.0f + 5e-5f)) || rf < kOne * 1e-4f;  // within 5e-5 of 1, or tiny (r2 == 0 is rejected)
-      if (__ballot(grey) != 0ull) {
-        if (grey) {  // numpy's own comparison, in double
-          const unsigned int a = (ta ^ (ta >> 18)) >> 5, b = r4_temper(R[4 * g + 1]) >> 6;
-          const unsigned int c = (tc ^ (tc >> 18)) >> 5, d = r4_temper(R[4 * g + 3]) >> 6;
-          const double u1 = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-          const double u2 = ((double)c * 67108864.0 + (double)d) / 9007199254740992.0;
-          const double x1 = 2.0 * u1 - 1.0, x2 = 2.0 * u2 - 1.0;
-          const double r2 = x1 * x1 + x2 * x2;
-          ok = !(r2 >= 1.0 || r2 == 0.0);
+      // the accept mask of the 64 attempts as a scalar: accepted for certain, corrected where the estimate cannot decide
+      // (within 5e-5 of 1, or tiny: r2 == 0 is rejected) by numpy's own comparison in double
+      unsigned long long M = __builtin_amdgcn_ballot_w64(rf < kOne * (1.0f - 5e-5f));
+      const bool grey = !(rf < kOne * (1.0f - 5e-5f) || rf > kOne * (1.0f + 5e-5f)) || rf < kOne * 1e-4f;
+      const unsigned long long G = __builtin_amdgcn_ballot_w64(grey);
+      if (G != 0ull) M = (M & ~G) | (__builtin_amdgcn_ballot_w64(r4_exact_accept(ta, R[4 * g + 1], tc, R[4 * g + 3])) & G);
+      // (lanes 12..15 of the last group hold zero words: x = y = -1, r2 = 2, rejected without a mask)
+      // accepted attempts of MY stream in this group (bits 16 s .. 16 s + 15 of the mask) and what they do to its position
+      const unsigned int m16 = ((my_s & 2 ? (unsigned int)(M >> 32) : (unsigned int)M) >> (16 * (my_s & 1))) & 0xFFFFu;
+      const int c = __popc(m16);
+      const int rem0 = rem, u = rem0 - c;
+      // the common case in ONE comparison per stream: the group lies strictly inside the columns that are not stored (pair
+      // index >= Hs before it, the row not finished by it): rem0 <= D and u >= 1  <=>  (unsigned)(u - 1) < (unsigned)(D - c)
+      const bool easy = SPARSE && (unsigned int)(u - 1) < (unsigned int)(D - c);
+      rem = u;
+      if (__builtin_amdgcn_ballot_w64(!easy) != 0ull) {  // (some stream of the wave is at its stored columns or at the end of a row)
+        const int pp0 = H - rem0;     // pair index of my stream's first accepted attempt of the group within its row
+        const int k = __popc(m16 & below);  // my rank among them
+        int q = pp0 + k, r = row;
+        if (q >= H) {
+          q -= H;
+          r += 1;
         }
-      }
-      if (g == 9) ok = ok && tl < 12;
-      const unsigned long long M = __ballot(ok);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned int m16 = (unsigned int)(M >> (16 * s)) & 0xFFFFu;
-        const int c = __popc(m16);
-        const int rem0 = rem[s], u = rem0 - c;
-        // the common case in ONE comparison: the group lies strictly inside the columns that are not stored (pair index
-        // >= Hs before it, the row not finished by it): rem0 <= D and u >= 1  <=>  (unsigned)(u - 1) < (unsigned)(D - c)
-        if (SPARSE && (unsigned int)(u - 1) < (unsigned int)(D - c)) {
-          rem[s] = u;
-          continue;
+        // stored pairs are [0, Hs) of every row (the group may run over the end of the row into the next one's)
+        const bool push = live && ((m16 >> tl) & 1u) && q < Hs && r < S;
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(push);
+        if (push) {
+          const unsigned int idx = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
+          const unsigned int slot = (qtail + idx) & (R4_QCAP - 1);
+          q_w[slot] = make_uint4(ta, R[4 * g + 1], tc, R[4 * g + 3]);
+          q_d[slot] = (unsigned int)(r * zc + 2 * q) | ((2 * q + 1 < zs) ? 0x10000000u : 0u) | ((unsigned int)my_s << 30);
         }
-        const int pp0 = H - rem0;  // pair index of the group's first accepted attempt within its row
-        // stored pairs are [0, Hs) of every row: does this group hold one? (it may run over the end of the row)
-        if (((live >> s) & 1u) && (pp0 < Hs || c > rem0)) {
-          bool push = false;
-          unsigned int dst = 0u;
-          if (my_s == s) {
-            const int k = __popc(m16 & below);  // my rank among this group's accepted attempts of the stream
-            int q = pp0 + k, r = row[s];
-            if (q >= H) {
-              q -= H;
-              r += 1;
-            }
-            push = ((m16 >> tl) & 1u) && q < Hs && r < S;
-            dst = (unsigned int)(r * zc + 2 * q) | ((2 * q + 1 < zs) ? 0x10000000u : 0u) | ((unsigned int)s << 30);
-          }
-          const unsigned long long pm = __ballot(push);
-          if (push) {
-            const unsigned int idx = __builtin_amdgcn_mbcnt_hi((unsigned int)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)pm, 0u));
-            const unsigned int slot = (qtail + idx) & (R4_QCAP - 1);
-            q_w[slot] = make_uint4(ta, R[4 * g + 1], tc, R[4 * g + 3]);
-            q_d[slot] = dst;
-          }
-          qtail += (unsigned int)__popcll(pm);
-        }
-        if (u <= 0) {  // the row is complete
-          rem[s] = u + H;
-          row[s] += 1;
-          if (row[s] >= S) live &= ~(1u << s);
-        } else {
-          rem[s] = u;
+        qtail += (unsigned int)__popcll(pm);
+        if (u <= 0) {  // my stream's row is complete
+          rem = u + H;
+          row += 1;
+          if (row >= S) live = false;
         }
       }
       // sparse: half a block (80 attempts per stream) meets at most ONE run of stored columns per stream (runs are D >= 80
