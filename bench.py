@@ -27,7 +27,7 @@ README_KW = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale':
 STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "curve_kde"]
 # gpet_profile_stage ids of the single kernels of one iteration (include/gpet_hip.h)
 # structured loop path (prior eigenbasis; what gpet_trace_iterate runs for on-grid batches): 120-123;
-# generic path (per-stage API, off-grid observations, GPET_NO_STRUCT=1): 100-113
+# generic path (per-stage API, off-grid observations, option struct_path = 0): 100-113
 KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_seat", 123: "k_struct_rows"}
 KERNEL_IDS_GENERIC = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram",
                       112: "k_jacobi_seat", 113: "k_factor_rows"}

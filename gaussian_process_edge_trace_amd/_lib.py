@@ -52,6 +52,10 @@ _P = C.c_void_p
 SYMBOLS = {
     "gpet_abi_version": (C.c_int, []),
     "gpet_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "gpet_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "gpet_option_count": (C.c_int, []),
+    "gpet_option_info": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "gpet_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     "gpet_ctx_destroy": (None, [_P]),
     "gpet_last_error": (C.c_char_p, [_P]),
@@ -102,12 +106,32 @@ SYMBOLS = {
 _lib = None
 
 
+def get_option(name):
+    """Current value of a process-wide tuning switch (gpet_get_option; -1 = chosen automatically)."""
+    v = C.c_int()
+    if load().gpet_get_option(name.encode(), C.byref(v)) != 0:
+        raise ValueError("unknown option %r" % (name,))
+    return v.value
+
+
 def set_option(name, value):
-    """Process-wide tuning switch of the library (gpet_set_option); returns the previous value."""
-    old = load().gpet_set_option(name.encode(), int(value))
-    if old < 0:
+    """Process-wide tuning switch of the library (gpet_set_option); returns the previous value (-1 = automatic)."""
+    old = get_option(name)
+    if load().gpet_set_option(name.encode(), int(value)) < 0:
         raise ValueError("unknown option %r" % (name,))
     return old
+
+
+def options():
+    """The table of tuning switches: {name: dict(value, default, lo, hi, doc)} (gpet_option_info)."""
+    lib = load()
+    out = {}
+    for i in range(lib.gpet_option_count()):
+        name, doc = C.c_char_p(), C.c_char_p()
+        v, d, lo, hi = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib.gpet_option_info(i, C.byref(name), C.byref(v), C.byref(d), C.byref(lo), C.byref(hi), C.byref(doc))
+        out[name.value.decode()] = dict(value=v.value, default=d.value, lo=lo.value, hi=hi.value, doc=doc.value.decode())
+    return out
 
 
 def load():

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "gpet_kernels.h"
+#include "gpet_options.h"
 
 using namespace gpet;
 
@@ -102,14 +103,14 @@ struct gpet_batch {
 // (device loop + converged fits in flight) eight ranks would keep 32 threads spinning on a node's cores.  In blocking
 // mode (gpet_set_option("blocking_sync", 1); default: on when WORLD_SIZE > 1, i.e. under torch.distributed.run) a wait
 // is an event created with hipEventBlockingSync: the thread sleeps until the GPU signals.
-static int& opt_blocking_sync() {
-  static int v = [] {
-    const char* e = getenv("GPET_BLOCKING_SYNC");
-    if (e) return atoi(e) ? 1 : 0;
+static int opt_blocking_sync() {
+  static int& v = option("blocking_sync");
+  if (v >= 0) return v;
+  static const int by_world = [] {  // (WORLD_SIZE is torch.distributed's variable, not a switch of this library)
     const char* w = getenv("WORLD_SIZE");
     return (w && atoi(w) > 1) ? 1 : 0;
   }();
-  return v;
+  return by_world;
 }
 static hipError_t gpet_wait(hipStream_t st) {
   if (!opt_blocking_sync()) return hipStreamSynchronize(st);
@@ -268,12 +269,12 @@ static int fin_lattice(const double* x, int n, double* hinv) {
 // lock-step rounds over all running problems: -1 = for problem sets resident at once (<= 1024), 0 = never, 1 = always
 // (where the training sets allow it)
 static int& opt_fit_persistent() {
-  static int v = getenv("GPET_FIT_PERSISTENT") != nullptr ? atoi(getenv("GPET_FIT_PERSISTENT")) : -1;
+  static int& v = option("fit_persistent");
   return v;
 }
 
 static int& opt_rng_chunked() {
-  static int v = getenv("GPET_RNG_CHUNKED") != nullptr ? atoi(getenv("GPET_RNG_CHUNKED")) : -1;  // -1: by launch shape
+  static int& v = option("rng_chunked");  // -1: by launch shape
   return v;
 }
 
@@ -336,97 +337,28 @@ extern "C" {
 int gpet_abi_version(void) { return GPET_ABI_VERSION; }
 
 int gpet_set_option(const char* name, int value) {
-  if (name && strcmp(name, "lml_two_tiles_from") == 0) {
-    int& v = gpet_opt_lml_two_tiles_from();
-    const int old = v;
-    v = value < 1 ? 1 : value;
-    return old > 0x3fffffff ? 0x3fffffff : old;
-  }
-  if (name && strcmp(name, "rng_chunked") == 0) {
-    int& v = opt_rng_chunked();
-    const int old = v;
-    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
-    return old < 0 ? 2 : old;  // (2 = "chosen by launch shape")
-  }
-  if (name && strcmp(name, "fit_persistent") == 0) {
-    int& v = opt_fit_persistent();
-    const int old = v;
-    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
-    return old < 0 ? 2 : old;  // (2 = "by the number of problems")
-  }
-  if (name && strcmp(name, "jacobi_logw") == 0) {
-    int& v = gpet_opt_jacobi_logw();
-    const int old = v;
-    v = value != 0 ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "lml_mfma") == 0) {
-    int& v = gpet_opt_lml_mfma();
-    const int old = v;
-    v = value;
-    return old;
-  }
-  if (name && (strcmp(name, "solve_mw") == 0 || strcmp(name, "diag_in_syrk") == 0)) {
-    int& v = name[0] == 's' ? gpet_opt_solve_mw() : gpet_opt_diag_in_syrk();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "fused_score") == 0) {
-    int& v = gpet_opt_fused_score();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "rng_lookahead") == 0) {
-    int& v = gpet_opt_rng_lookahead();
-    const int old = v;
-    v = value < 0 ? -1 : (value > 15 ? 15 : value);
-    return old < 0 ? 16 : old;  // (16 = "chosen by batch size")
-  }
-  if (name && strcmp(name, "scalar_jacobi") == 0) {
-    int& v = gpet_opt_scalar_jacobi();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "jacobi_variant") == 0) {
-    int& v = gpet_opt_jacobi_variant();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "blocking_sync") == 0) {
-    int& v = opt_blocking_sync();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "oj_tol_exp") == 0) {
-    int& v = gpet_opt_oj_tol_exp();
-    const int old = v;
-    v = value < 4 ? 4 : (value > 15 ? 15 : value);
-    return old;
-  }
-  if (name && strcmp(name, "rng4") == 0) {
-    int& v = gpet_opt_rng4();
-    const int old = v;
-    v = value < 0 ? -1 : (value > 0 ? 1 : 0);
-    return old < 0 ? 2 : old;  // (2 = "by the number of streams of the launch")
-  }
-  if (name && strcmp(name, "oj_persist") == 0) {
-    int& v = gpet_opt_oj_persist();
-    const int old = v;
-    v = value ? 1 : 0;
-    return old;
-  }
-  if (name && strcmp(name, "oj_max_sweeps") == 0) {
-    int& v = gpet_opt_oj_max_sweeps();
-    const int old = v;
-    v = value < 1 ? 1 : (value > 64 ? 64 : value);
-    return old;
-  }
-  return -1;
+  int prev = 0, idx = -1;
+  for (int i = 0; i < option_count(); ++i)
+    if (name && strcmp(option_def(i).name, name) == 0) idx = i;
+  if (idx < 0 || option_set(name, value, &prev) != 0) return -1;
+  // ("chosen automatically", -1, is reported as the option's largest value + 1: a negative return means "unknown name")
+  return prev < 0 ? option_def(idx).hi + 1 : prev;
+}
+
+int gpet_get_option(const char* name, int* value) { return option_get(name, value) == 0 ? GPET_OK : GPET_ERR_BAD_ARG; }
+
+int gpet_option_count(void) { return option_count(); }
+
+int gpet_option_info(int index, const char** name, int* value, int* def, int* lo, int* hi, const char** doc) {
+  if (index < 0 || index >= option_count()) return GPET_ERR_BAD_ARG;
+  const OptionDef& d = option_def(index);
+  if (name) *name = d.name;
+  if (value) (void)option_get(d.name, value);
+  if (def) *def = d.def;
+  if (lo) *lo = d.lo;
+  if (hi) *hi = d.hi;
+  if (doc) *doc = d.doc;
+  return GPET_OK;
 }
 
 int gpet_ctx_create(int device, void* stream, gpet_ctx** out) {
@@ -667,10 +599,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     // slots of the normals ring: 16 for small batches (eight iterations ahead on the side stream), 9 above 64 edges (the
     // eight iterations of a group are generated by one launch), 2 when a row holds the whole grid (config 3)
     E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 9);
-    if (getenv("GPET_Z_RING") && atoi(getenv("GPET_Z_RING")) >= 2 && atoi(getenv("GPET_Z_RING")) <= 16) E.z_ring = atoi(getenv("GPET_Z_RING"));  // (experiments)
     // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
     // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
-    static const int jlog_max_b = getenv("GPET_JLOG_MAX_B") ? atoi(getenv("GPET_JLOG_MAX_B")) : 16;  // (experiments: the rotation-log form for bigger batches)
+    const int jlog_max_b = option("jlog_max_b");  // (16; the rotation-log form for bigger batches was measured slower)
     E.jlog_cap = (B <= jlog_max_b && E.r_cap <= 96) ? 40 : 0;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;
@@ -752,22 +683,14 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
   HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
   {
-    // GPET_RNG_PRIORITY = normal (default) | low | high: priority of the stream the normals run ahead of the loop on
-    int pl = 0, pg = 0;
-    HIPCHK(c, hipDeviceGetStreamPriorityRange(&pl, &pg));
-    const char* rp = getenv("GPET_RNG_PRIORITY");
-    if (rp && strcmp(rp, "low") == 0) HIPCHK(c, hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, pl));
-    else if (rp && strcmp(rp, "high") == 0) HIPCHK(c, hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, pg));
-    else HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    // (the stream the normals run ahead of the loop on: default priority -- lowest / highest were measured, +-0)
+    HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
   }
   {
     int pr_least = 0, pr_greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-    // GPET_FIT_PRIORITY = high (default) | normal | low: priority of the stream the converged fits' objective runs on
-    const char* fp = getenv("GPET_FIT_PRIORITY");
-    int prio = pr_greatest;
-    if (fp && strcmp(fp, "low") == 0) prio = pr_least;
-    else if (fp && strcmp(fp, "normal") == 0) prio = (pr_least + pr_greatest) / 2;
+    // the stream the converged fits' objective runs on has the highest priority (its launches are small and many)
+    const int prio = pr_greatest;
     HIPCHK(c, hipStreamCreateWithPriority(&b->fit, hipStreamNonBlocking, prio));
   }
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_norm[i], hipEventDisableTiming));
@@ -796,9 +719,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : B, b->bd, 1));
   HIPCHK(c, gpet_wait(c->stream));
   // structured loop path: eigenbasis of the grid's correlation matrix, once per edge.  Usable when the
-  // LDS Jacobi applies (capacity <= 96) and every init x lies on the grid; GPET_NO_STRUCT=1 disables it.
+  // LDS Jacobi applies (capacity <= 96) and every init x lies on the grid; option "struct_path" = 0 disables it.
   b->structured = false;
-  if (!any_big && !getenv("GPET_NO_STRUCT")) {
+  if (!any_big && option("struct_path")) {
     bool ok = true;
     // without fix_endpoints the pixel selection admits every image column (gpet.py:655-657 only filters when it is
     // set), so the loop can accept observations outside [x_st, x_en] unless the edge spans the whole image: those are
@@ -831,8 +754,8 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
       // (k_rho_fill forms the lags as fl((x_st+i)/l) - fl((x_st+j)/l), which depends on x_st in the last bits unless l is
       // a power of two -- so x_st is part of the match; the amplitude is not: the matrix has unit amplitude): they all
       // read the first such edge's copy, which then stays in L2 for the whole batch (k_struct_H gathers its rows,
-      // k_struct_rows streams it: 288 KB per edge at rank 72, Lg 500) -- GPET_NO_SHARED_BASIS=1: every edge its own
-      if (ok && !getenv("GPET_NO_SHARED_BASIS")) {
+      // k_struct_rows streams it: 288 KB per edge at rank 72, Lg 500) -- option "shared_basis" = 0: every edge its own
+      if (ok && option("shared_basis")) {
         for (int e = 1; e < B; ++e) {
           EdgeDev& E = b->h_edges[e];
           for (int j = 0; j < e; ++j) {
@@ -1193,7 +1116,7 @@ int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
 // the prior's r0 eigen-directions), so only that many columns of the z_cols-wide block are ever multiplied.  The stage
 // API (gpet_gp_normals) always stores the whole block: its factor may come from the generic path or from the caller.
 static inline int loop_z_store(const gpet_batch* b) {
-  if (!b->structured || b->bd.r0_max < 1 || getenv("GPET_Z_STORE_FULL")) return 0;
+  if (!b->structured || b->bd.r0_max < 1 || option("z_store_full")) return 0;
   return (b->bd.r0_max + 3) & ~3;
 }
 
@@ -1898,8 +1821,8 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       // of ALL the iterations of a group in one launch on the loop's own stream (batches above 64 edges: the default -- the
       // launch fills the GPU and runs beside nothing, 157-159 instead of 161-162 ms per step of 1 024 traces); 1 = one
       // iteration per launch on the loop's stream (an experiment: 179 ms)
-      static const int rng_inline_env = getenv("GPET_RNG_INLINE") ? atoi(getenv("GPET_RNG_INLINE")) : -1;
-      const int rng_inline = rng_inline_env >= 0 ? rng_inline_env : (deep ? 0 : 2);
+      const int rng_inline_opt = option("rng_inline");
+      const int rng_inline = rng_inline_opt >= 0 ? rng_inline_opt : (deep ? 0 : 2);
       if (rng_inline == 1) {  // experiment: the normals of this iteration on the loop's own stream, overlapping nothing
         int rcn = normals_auto(b, c->stream, edges_l, B_l, seeds_l, 1, cur, 1, loop_z_store(b));
         if (rcn) return rcn;
@@ -1929,8 +1852,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
         b->norm_issued = j + n;
       }
-      static const int rng_after_gemm = getenv("GPET_RNG_AFTER_GEMM") ? atoi(getenv("GPET_RNG_AFTER_GEMM")) : 0;
-      const int look_now = (rng_after_gemm && !deep) ? 0 : look;  // (this iteration's own stream only, if it is not there yet)
+      const int look_now = look;  // (after the GEMM instead of beside the eigen-solver was measured: +-0)
       while (!rng_inline && !deep && b->norm_issued <= cur + look_now && b->norm_issued < horizon) {
         const int j = b->norm_issued;
         if (look == 0) {
@@ -1961,15 +1883,6 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       if (fused) HIPCHK(c, launch_sample_score(c->stream, edges_l, B_l, b->bd, rank_max));
       else HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, rank_max));
       HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
-      if (rng_after_gemm && !rng_inline && !deep && b->norm_issued == cur + 1 && cur + 1 < horizon) {
-        // the next iteration's stream starts when this iteration's GEMM is through: it then runs beside the scorer and the
-        // KDE instead of beside the eigen-solver and the GEMM, whose speed hangs on two workgroups per CU
-        HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[cur % 16], 0));
-        int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, cur + 1, 1, loop_z_store(b));
-        if (rcn) return rcn;
-        HIPCHK(c, hipEventRecord(b->ev_norm[(cur + 1) % 16], b->side));
-        b->norm_issued = cur + 2;
-      }
       if (!fused) HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
       // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
       HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));

@@ -16,6 +16,7 @@
 //                -> the accumulated 16x16 rotation applied to the 16 rows on the matrix cores.
 //   3. k_oj_norms / k_oj_order / k_oj_rows: singular values = row norms, descending order, sign convention.
 #include "gpet_kernels.h"
+#include "gpet_options.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -1163,7 +1164,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   // small batches: the per-edge pointers travel in the kernel arguments (h_edges = host copy of the edge table)
   OjArgs oj_args;
   memset(&oj_args, 0, sizeof oj_args);
-  const bool use_args = h_edges != nullptr && B <= OJ_ARGS_MAXB && !getenv("GPET_OJ_NO_ARGS");
+  const bool use_args = h_edges != nullptr && B <= OJ_ARGS_MAXB && option("oj_args");
   if (use_args)
     for (int e = 0; e < B; ++e) {
       OjEdge& d = oj_args.e[e];
@@ -1195,7 +1196,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
       d.r_cap = h.r_cap;
       d.factor_injected = h.factor_injected;
     }
-  if (nw <= 64 && !getenv("GPET_PCX_ONE_PIVOT")) {
+  if (nw <= 64 && !option("pcx_one_pivot")) {
     // blocks of up to PCB_NB pivots; rejected candidates cost extra blocks, so the budget is generous (a block that
     // finds the factorisation finished returns at once)
     hipLaunchKernelGGL(k_pcb_init, dim3(nw, B), dim3(64), 0, st, d_edges, nw);
@@ -1218,7 +1219,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   // LDS staging costs a workgroup a whole CU (131 KB): worth it while a round's workgroups (pairs x edges) fit the
   // chip's 256 CUs side by side (one edge: 64 pairs; measured 54 vs 61 ms per factor); a bigger batch runs two
   // register-fed workgroups per CU instead (8 edges: 85 vs 106 ms)
-  const bool staged_lds_ok = bd.Lg <= OJ_STAGE_MAX && !getenv("GPET_OJ_NO_STAGE");
+  const bool staged_lds_ok = bd.Lg <= OJ_STAGE_MAX && option("oj_stage");
   const bool staged = staged_lds_ok && (long long)(nblk / 2) * B <= 256;
   const size_t stage_lds = (size_t)OJ_M * (((bd.Lg + 31) & ~31) + 2) * sizeof(double);
   if (staged) {
@@ -1235,7 +1236,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   // staged: the rounds and sweeps in ONE launch (k_oj_persist: pair slots by ticket -- no residency requirement, so the
   // grid is sized to what the device holds at once and a workgroup serves several slots per round when the batch has more
   // slots than that; beyond four slots per workgroup and round the round launches' two register-fed workgroups per CU
-  // win); option "oj_persist" (GPET_OJ_PERSIST) = 0: launches
+  // win); option "oj_persist" = 0: launches
   static int persist_cap[64] = {};  // workgroups of k_oj_persist the device holds at once (occupancy x CUs), per device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1274,17 +1275,17 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
 }
 
 int& gpet_opt_oj_tol_exp() {
-  static int v = getenv("GPET_OJ_TOL_EXP") != nullptr ? atoi(getenv("GPET_OJ_TOL_EXP")) : 8;
+  static int& v = option("oj_tol_exp");
   return v;
 }
 
 int& gpet_opt_oj_persist() {
-  static int v = getenv("GPET_OJ_PERSIST") != nullptr ? atoi(getenv("GPET_OJ_PERSIST")) : 1;
+  static int& v = option("oj_persist");
   return v;
 }
 
 int& gpet_opt_oj_max_sweeps() {
-  static int v = getenv("GPET_OJ_MAX_SWEEPS") != nullptr ? atoi(getenv("GPET_OJ_MAX_SWEEPS")) : 16;
+  static int& v = option("oj_max_sweeps");
   return v;
 }
 

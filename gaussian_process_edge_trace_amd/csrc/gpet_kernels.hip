@@ -1,6 +1,7 @@
 // Hand-written gfx950 kernels for the GP edge-tracing hot path.
 // Wavefront = 64 lanes everywhere.  blockIdx.y selects the edge of the batch.
 #include "gpet_kernels.h"
+#include "gpet_options.h"
 #include "gpet_lbfgsb_dev.h"
 
 #include <atomic>
@@ -1153,14 +1154,14 @@ __global__ void __launch_bounds__(256) k_chol_solve_mw(EdgeDev* edges, int epoch
   if (tid == 0) __hip_atomic_store(flag_mine + ib, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// gpet_set_option "solve_mw" (default 1; environment GPET_SOLVE_MW): 0 = alpha of the blocked fit by the single-workgroup
-// kernel; "diag_in_syrk" (default 1; GPET_DIAG_IN_SYRK): 0 = a launch of its own for every diagonal block
+// gpet_set_option "solve_mw" (default 1): 0 = alpha of the blocked fit by the single-workgroup
+// kernel; "diag_in_syrk" (default 1): 0 = a launch of its own for every diagonal block
 int& gpet_opt_solve_mw() {
-  static int v = getenv("GPET_SOLVE_MW") ? atoi(getenv("GPET_SOLVE_MW")) : 1;
+  static int& v = option("solve_mw");
   return v;
 }
 int& gpet_opt_diag_in_syrk() {
-  static int v = getenv("GPET_DIAG_IN_SYRK") ? atoi(getenv("GPET_DIAG_IN_SYRK")) : 1;
+  static int& v = option("diag_in_syrk");
   return v;
 }
 
@@ -1170,7 +1171,7 @@ static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   hipLaunchKernelGGL(k_fit_head, dim3(1, B), dim3(1024), (size_t)bd.n_cap * sizeof(long long), st, d_edges);
   hipLaunchKernelGGL(k_fit_kbuild, dim3(nt, nt, B), dim3(256), 0, st, d_edges);
   // per panel: [diagonal block] -> rows below it -> trailing update, whose first workgroup goes on to factor the next
-  // diagonal block (GPET_DIAG_IN_SYRK=0: a launch of its own per diagonal block)
+  // diagonal block (option "diag_in_syrk" = 0: a launch of its own per diagonal block)
   const int diag_in_syrk = gpet_opt_diag_in_syrk() ? 1 : 0;
   for (int k0 = 0; k0 < bd.n_cap; k0 += CB) {
     if (k0 == 0 || !diag_in_syrk) hipLaunchKernelGGL(k_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, 1);
@@ -1180,7 +1181,7 @@ static void launch_fit_blocked(hipStream_t st, EdgeDev* d_edges, int B, const Ba
       hipLaunchKernelGGL(k_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0, diag_in_syrk);
     }
   }
-  // alpha: one workgroup per 64-row block and direction (GPET_SOLVE_MW=0: the single-workgroup kernel)
+  // alpha: one workgroup per 64-row block and direction (option "solve_mw" = 0: the single-workgroup kernel)
   if (gpet_opt_solve_mw()) {
     static std::atomic<int> launch_no{0};
     const int epoch = ++launch_no;  // (flags hold the number of the launch that published them: never reset)
@@ -3382,29 +3383,6 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
     }
     // one 16-column group at a time: its 4 stores go out while the matrix pipe works on the next group (and the
     // accumulators take 8 registers instead of 32)
-#if defined(GPET_GEMM_EXP) && GPET_GEMM_EXP == 2  // experiment: two column groups at a time (two independent accumulator chains)
-#pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      if (j0 + 32 * tp >= Lg) continue;
-      v4f64 acc0 = (v4f64){0.0, 0.0, 0.0, 0.0}, acc1 = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * GEMM_LDA + li + 32 * tp], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[q], s_fa[(4 * q + lq) * GEMM_LDA + li + 32 * tp + 16], acc1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int j = j0 + 32 * tp + 16 * h + li;
-        if (j >= Lg) continue;
-        const double mu = mu_lds ? s_mu[j] : meang[j];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int sidx = s0 + 16 * w + lq + 4 * g;
-          if (sidx < S) Yo[(size_t)sidx * Lg + j] = (yt)(((h ? acc1[g] : acc0[g]) + mu) * y_s);
-        }
-      }
-    }
-#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (j0 + 16 * t >= Lg) continue;  // (an empty group: uniform over the workgroup)
@@ -3418,14 +3396,10 @@ __device__ __forceinline__ void sample_gemm_body(const EdgeDev& E, const gpet_sc
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int sidx = s0 + 16 * w + lq + 4 * g;
-#if defined(GPET_GEMM_EXP) && GPET_GEMM_EXP == 1  // experiment: no stores (the condition is never true)
-        if (sidx < S && acc[g] == 1.2345e300) Yo[(size_t)sidx * Lg + j] = (yt)((acc[g] + mu) * y_s);
-#else  // (streaming stores, __builtin_nontemporal_store, were measured 35 % slower here)
+        // (streaming stores, __builtin_nontemporal_store, were measured 35 % slower here)
         if (sidx < S) Yo[(size_t)sidx * Lg + j] = (yt)((acc[g] + mu) * y_s);
-#endif
       }
     }
-#endif
   }
 }
 
@@ -3653,24 +3627,13 @@ __device__ __forceinline__ double dpp_row(double v) {
 }
 // sum over the 16 lanes of a row, in every lane; the operands of every addition are those of the xor-8, 4, 2, 1 butterfly
 // (after the first step lanes i and i ^ 8 hold the same value, so a rotation by 4 brings what xor 4 would).
-// GPET_ROWSUM_SWZ (bit s set: step s by ds_swizzle): the exchange through the LDS crossbar (no memory access) instead of
-// two v_mov_b32_dpp -- the scorer is bound by vector-ALU issue and its LDS pipe is nearly idle.
-#ifndef GPET_ROWSUM_SWZ
-#define GPET_ROWSUM_SWZ 0
-#endif
-template <int XOR>
-__device__ __forceinline__ double swz_xor(double v) {
-  const long long b = __double_as_longlong(v);
-  constexpr int pat = (XOR << 10) | 0x1F;  // bit mode: and 0x1f, or 0, xor XOR (within 32 lanes)
-  const int lo = __builtin_amdgcn_ds_swizzle((int)b, pat);
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), pat);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+// (The exchanges through the LDS crossbar -- ds_swizzle instead of two v_mov_b32_dpp per step -- were measured for every
+// subset of the four steps: 1.21-1.22 against 1.20 ms per 1 024 edges; DPP stays.)
 __device__ __forceinline__ double row16_sum(double v) {
-  v += (GPET_ROWSUM_SWZ & 1) ? swz_xor<8>(v) : dpp_row<0x128>(v);  // row_ror:8
-  v += (GPET_ROWSUM_SWZ & 2) ? swz_xor<4>(v) : dpp_row<0x124>(v);  // row_ror:4
-  v += (GPET_ROWSUM_SWZ & 4) ? swz_xor<2>(v) : dpp_row<0x4E>(v);   // quad_perm:[2,3,0,1]
-  v += (GPET_ROWSUM_SWZ & 8) ? swz_xor<1>(v) : dpp_row<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_row<0x128>(v);  // row_ror:8
+  v += dpp_row<0x124>(v);  // row_ror:4
+  v += dpp_row<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_row<0xB1>(v);   // quad_perm:[1,0,3,2]
   return v;
 }
 __device__ __forceinline__ double grad_lds(const float* __restrict__ col, int M, double y) {
@@ -6270,28 +6233,28 @@ hipError_t launch_final_predict(hipStream_t st, EdgeDev* d_edges, int B, const B
 }
 
 int& gpet_opt_lml_two_tiles_from() {
-  static int v = getenv("GPET_LML_TWO_TILES_FROM") != nullptr ? atoi(getenv("GPET_LML_TWO_TILES_FROM")) : 600;
+  static int& v = option("lml_two_tiles_from");
   return v;
 }
 
 int& gpet_opt_lml_mfma() {
-  static int v = getenv("GPET_LML_MFMA") != nullptr ? atoi(getenv("GPET_LML_MFMA")) : 1;
+  static int& v = option("lml_mfma");
   return v;
 }
 
 int& gpet_opt_rng_lookahead() {
-  static int v = getenv("GPET_RNG_LOOKAHEAD") != nullptr ? atoi(getenv("GPET_RNG_LOOKAHEAD")) : -1;  // -1: by batch size
+  static int& v = option("rng_lookahead");  // -1: by batch size
   return v;
 }
 
 // LDS Jacobi of ranks <= 96: 1 (default) = seated (k_jacobi_seat), 0 = by row index (k_jacobi_lds, the round-1 form)
 int& gpet_opt_jacobi_variant() {
-  static int v = getenv("GPET_JACOBI_VARIANT") ? atoi(getenv("GPET_JACOBI_VARIANT")) : 1;
+  static int& v = option("jacobi_variant");
   return v;
 }
 // rotation log + separate eigenvector pass for batches that have a log (gpet_batch_create: up to 16 edges): 1 = on (default)
 int& gpet_opt_jacobi_logw() {
-  static int v = getenv("GPET_JACOBI_LOGW") ? atoi(getenv("GPET_JACOBI_LOGW")) : 1;
+  static int& v = option("jacobi_logw");
   return v;
 }
 static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int rank_max, int scaled_out, bool logw) {
@@ -6324,7 +6287,7 @@ static void launch_jacobi_small(hipStream_t st, EdgeDev* d_edges, int B, int ran
 }
 
 int& gpet_opt_scalar_jacobi() {
-  static int v = getenv("GPET_SCALAR_JACOBI") != nullptr ? 1 : 0;
+  static int& v = option("scalar_jacobi");
   return v;
 }
 
@@ -6487,10 +6450,8 @@ hipError_t launch_normals_philox(hipStream_t st, EdgeDev* d_edges, int B, const 
 hipError_t launch_normals(hipStream_t st, EdgeDev* d_edges, int B, const unsigned int* d_seeds, int add_iter,
                           int iter_abs, int n_ahead, int z_store) {
   (void)hipGetLastError();  // drop stale errors: report only these launches
-  // GPET_RNG_WAVES = 3 | 4 (default 3): waves per workgroup of the generator
-  static const int rng_waves = getenv("GPET_RNG_WAVES") ? atoi(getenv("GPET_RNG_WAVES")) : 3;
-  if (rng_waves == 4) hipLaunchKernelGGL((k_mt_normals<false, 4>), dim3(n_ahead, B), dim3(256), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
-  else hipLaunchKernelGGL((k_mt_normals<false, 3>), dim3(n_ahead, B), dim3(192), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
+  // (three waves per workgroup: four were measured 4 % slower)
+  hipLaunchKernelGGL((k_mt_normals<false, 3>), dim3(n_ahead, B), dim3(192), 0, st, d_edges, d_seeds, add_iter, iter_abs, z_store, MtjWork{});
   return hipGetLastError();
 }
 
@@ -6615,10 +6576,9 @@ hipError_t launch_sample(hipStream_t st, EdgeDev* d_edges, int B, const BatchDim
     }
     // (an edge too wide for its posterior mean to sit behind the chunk reads it from global memory in the epilogue)
     const int mu_in_lds = ((size_t)4 * 24 * GEMM_LDA + bd.Lg) * sizeof(double) <= (size_t)GEMM_LDS_MAX ? 1 : 0;
-    static const size_t gemm_lds_pad = getenv("GPET_GEMM_LDS_PAD") ? (size_t)atoi(getenv("GPET_GEMM_LDS_PAD")) : 0;  // (experiments: one workgroup per CU)
 #define GPET_GEMM_LAUNCH(KERNEL, KS_)                                                                                                  \
   do {                                                                                                                                 \
-    const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double) + gemm_lds_pad;                             \
+    const size_t lds_ = ((size_t)4 * KS_ * GEMM_LDA + (mu_in_lds ? bd.Lg : 0)) * sizeof(double);                                            \
     if (bd.y_f32 && mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, true, true>), grid, block, lds_, st, d_edges, ncs);                        \
     else if (bd.y_f32) hipLaunchKernelGGL((KERNEL<KS_, true, false>), grid, block, lds_, st, d_edges, ncs);                               \
     else if (mu_in_lds) hipLaunchKernelGGL((KERNEL<KS_, false, true>), grid, block, lds_, st, d_edges, ncs);                              \
@@ -6661,7 +6621,7 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
     }
   }
   if (parts & 2u) {
-    if (bd.S <= 1024 && !getenv("GPET_TOPK_RANK")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
+    if (bd.S <= 1024 && !option("topk_rank")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
     else hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
   }
   return hipGetLastError();
@@ -6673,7 +6633,7 @@ hipError_t launch_score(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims
 // the bench shape (3.2 + 0.4 ms against 1.8 + 1.25 ms per 1 024 edges: every column tile streams the edge's normals
 // through its CU's L1 again, 13 GB per launch), so it is off by default.
 int& gpet_opt_fused_score() {
-  static int v = getenv("GPET_FUSED_SCORE") != nullptr ? atoi(getenv("GPET_FUSED_SCORE")) : 0;
+  static int& v = option("fused_score");
   return v;
 }
 
@@ -6712,18 +6672,16 @@ hipError_t launch_sample_score(hipStream_t st, EdgeDev* d_edges, int B, const Ba
   if (parts & 1u) {
     const int n_tiles = cdiv((bd.Lg - 2) / 2, SC_PAIRS);
     // two workgroups of four waves per CU while two slabs fit its LDS (one stages while the other works), else one of eight
-    static const int threads_env = getenv("GPET_SS_THREADS") ? atoi(getenv("GPET_SS_THREADS")) : 0;  // (experiments: 256, 384, 512)
-    const int threads = threads_env > 0 ? threads_env : (2 * lds + 4096 <= 160 * 1024 ? 256 : 512);
+    const int threads = 2 * lds + 4096 <= 160 * 1024 ? 256 : 512;  // (256 / 384 / 512 were measured: 256 x 2 per CU best)
     // curves split over workgroups only while the tiles alone do not fill the GPU (every part stages the slab again)
     int ny = cdiv(768, B * n_tiles);
     const int ny_max = cdiv(bd.S, threads / 4);
     ny = ny > ny_max ? ny_max : (ny < 1 ? 1 : ny);
     const dim3 grid(n_tiles, ny, B), block(threads);
-    static const size_t lds_pad = getenv("GPET_SS_LDS_PAD") ? (size_t)atoi(getenv("GPET_SS_LDS_PAD")) : 0;  // (experiments: one workgroup per CU)
 #define GPET_SS_LAUNCH(KS_)                                                                                  \
   do {                                                                                                       \
-    if (bd.y_f32) hipLaunchKernelGGL((k_sample_score<KS_, true>), grid, block, lds + lds_pad, st, d_edges);  \
-    else hipLaunchKernelGGL((k_sample_score<KS_, false>), grid, block, lds + lds_pad, st, d_edges);          \
+    if (bd.y_f32) hipLaunchKernelGGL((k_sample_score<KS_, true>), grid, block, lds, st, d_edges);  \
+    else hipLaunchKernelGGL((k_sample_score<KS_, false>), grid, block, lds, st, d_edges);          \
   } while (0)
     if (ks <= 8) GPET_SS_LAUNCH(8);
     else if (ks <= 12) GPET_SS_LAUNCH(12);
@@ -6733,7 +6691,7 @@ hipError_t launch_sample_score(hipStream_t st, EdgeDev* d_edges, int B, const Ba
     hipLaunchKernelGGL(k_score_combine, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges, n_tiles);
   }
   if (parts & 2u) {
-    if (bd.S <= 1024 && !getenv("GPET_TOPK_RANK")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
+    if (bd.S <= 1024 && !option("topk_rank")) hipLaunchKernelGGL(k_topk_sort, dim3(1, B), dim3(512), 0, st, d_edges);
     else hipLaunchKernelGGL(k_topk, dim3(cdiv(bd.S, 256), B), dim3(256), 0, st, d_edges);
   }
   if (parts & 4u) {

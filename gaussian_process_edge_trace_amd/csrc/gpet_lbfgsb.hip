@@ -14,6 +14,7 @@
 // function values); the policy for the result is stated in the tests: final theta within 1e-4 of the reference run
 // (noise level compared in linear space), mean / credible interval within 1e-5, edge_trace equal.
 #include "gpet_kernels.h"
+#include "gpet_options.h"
 #include "gpet_lbfgsb_dev.h"
 
 #include <math.h>
@@ -370,7 +371,7 @@ hipError_t launch_fin_prepare(hipStream_t st, EdgeDev* d_edges, int B, const uns
                               double* d_scratch, int scratch_stride, int n_cap) {
   (void)hipGetLastError();
   const size_t lds = (size_t)4 * n_cap * sizeof(double);
-  if (n_cap > 0 && lds <= 60 * 1024 && !getenv("GPET_FIN_PREPARE_SERIAL"))
+  if (n_cap > 0 && lds <= 60 * 1024 && !option("fin_prepare_serial"))
     hipLaunchKernelGGL(k_fin_prepare_wave, dim3(B), dim3(64), lds, st, d_edges, B, d_seeds, d_starts, n_cap);
   else
     hipLaunchKernelGGL(k_fin_prepare, dim3((B + 63) / 64), dim3(64), 0, st, d_edges, B, d_seeds, d_starts, d_scratch,

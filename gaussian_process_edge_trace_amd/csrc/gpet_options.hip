@@ -1,0 +1,99 @@
+// The table of process-wide options (gpet_options.h).  Host code only.
+#include "gpet_options.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace gpet {
+
+namespace {
+
+// name, default, lo, hi, meaning.  (-1 = automatic where lo == -1.)
+const OptionDef kDefs[] = {
+    {"blocking_sync", -1, -1, 1, "host waits sleep on a hipEventBlockingSync event instead of spinning in hipStreamSynchronize; -1: on when WORLD_SIZE > 1 (several ranks per host share its cores)"},
+    {"rng4", -1, -1, 1, "normals by the register-resident generator k_mt_normals4 (four MT19937 streams per wave): -1 = launches of >= 2048 streams, 0 = never, 1 = whenever the batch is homogeneous"},
+    {"rng_chunked", -1, -1, 1, "one MT19937 stream on many workgroups by jump-ahead: -1 = launches of <= 32 streams of >= 4 chunks, 0 = never, 1 = always"},
+    {"rng_lookahead", -1, -1, 15, "iterations the normals may run ahead of the device loop on the side stream; -1: 8 up to 64 edges, else 1"},
+    {"rng_inline", -1, -1, 2, "where the loop's normals are generated: 0 = side stream, 1 = one iteration per launch on the loop's stream, 2 = all iterations of a group in one launch on the loop's stream; -1: 2 above 64 edges, else 0"},
+    {"z_store_full", 0, 0, 1, "1: the structured loop stores all z_cols normals of a sample row instead of the r0 (rounded to 4) its factors multiply"},
+    {"fit_persistent", -1, -1, 1, "converged fits as one workgroup per (edge, restart) problem: -1 = problem sets resident at once (<= 1024), 0 = lock-step rounds, 1 = always"},
+    {"fin_prepare_serial", 0, 0, 1, "1: training sets of the converged fits by one thread per edge (cross-check of the one-wave-per-edge kernel)"},
+    {"lml_mfma", 1, 0, 1, "objective of the converged fits on the f64 matrix cores (k_lml16) where the training set allows it; 0: register-tile kernels k_lml / k_lml2"},
+    {"lml_two_tiles_from", 600, 1, 0x3fffffff, "problems per launch from which k_lml2 (two 4x4 tiles per thread) replaces k_lml"},
+    {"jacobi_variant", 1, 0, 1, "LDS Jacobi of ranks <= 96: 1 = seated form (k_jacobi_seat), 0 = addressed by row index (k_jacobi_lds: the cross-check)"},
+    {"jacobi_logw", 1, 0, 1, "batches that have a rotation log (<= jlog_max_b edges): eigenvectors by a separate pass over the logged rotations"},
+    {"jlog_max_b", 16, 0, 4096, "largest batch that gets a rotation log (read when a batch is created)"},
+    {"scalar_jacobi", 0, 0, 1, "1: ranks above 96 by round 1's whole-GPU scalar Jacobi (cross-check of gpet_eig.hip)"},
+    {"oj_persist", 1, 0, 1, "any-rank Jacobi: rounds and sweeps in one launch, pair slots handed out by ticket (k_oj_persist); 0: one launch per round"},
+    {"oj_stage", 1, 0, 1, "any-rank Jacobi: a pair's 16 rows staged in LDS; 0: operands from global memory"},
+    {"oj_args", 1, 0, 1, "any-rank factor: per-edge pointers of small batches in the kernel arguments; 0: through the edge table"},
+    {"oj_tol_exp", 8, 4, 15, "any-rank Jacobi stops after a sweep whose pairs were all orthogonal to 10^-x relative"},
+    {"oj_max_sweeps", 16, 1, 64, "sweep budget of the any-rank Jacobi"},
+    {"pcx_one_pivot", 0, 0, 1, "1: multi-workgroup pivoted Cholesky one pivot per launch (cross-check of the blocked candidate selection)"},
+    {"solve_mw", 1, 0, 1, "blocked fit: alpha by one workgroup per 64-row block and direction (k_chol_solve_mw); 0: one workgroup per edge"},
+    {"diag_in_syrk", 1, 0, 1, "blocked fit: the trailing update's first workgroup factors the next diagonal block; 0: a launch of its own"},
+    {"fused_score", 0, 0, 1, "1: sample GEMM and scorer in one kernel (k_sample_score; measured slower, DESIGN 6c)"},
+    {"topk_rank", 0, 0, 1, "1: argsort of the costs by rank counting (k_topk) also where the bitonic sort applies"},
+    {"struct_path", 1, 0, 1, "structured loop path (prior eigenbasis of the pixel grid) where it applies; 0: the generic kernels"},
+    {"shared_basis", 1, 0, 1, "edges of one geometry share one prior eigenbasis; 0: every edge its own copy"},
+};
+constexpr int kCount = (int)(sizeof(kDefs) / sizeof(kDefs[0]));
+int g_val[kCount];
+std::once_flag g_once;
+
+int clampv(const OptionDef& d, int v) { return v < d.lo ? d.lo : (v > d.hi ? d.hi : v); }
+
+void init_all() {
+  for (int i = 0; i < kCount; ++i) {
+    const OptionDef& d = kDefs[i];
+    char env[64] = "GPET_";
+    size_t n = strlen(env);
+    for (const char* p = d.name; *p && n + 1 < sizeof env; ++p) env[n++] = (*p >= 'a' && *p <= 'z') ? (char)(*p - 32) : *p;
+    env[n] = 0;
+    const char* e = getenv(env);
+    g_val[i] = e ? clampv(d, atoi(e)) : d.def;
+  }
+}
+
+int find(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < kCount; ++i)
+    if (strcmp(kDefs[i].name, name) == 0) return i;
+  return -1;
+}
+
+}  // namespace
+
+int& option(const char* name) {
+  std::call_once(g_once, init_all);
+  const int i = find(name);
+  if (i < 0) {
+    fprintf(stderr, "libgpet_hip: unknown option '%s'\n", name ? name : "(null)");
+    abort();
+  }
+  return g_val[i];
+}
+
+int option_set(const char* name, int value, int* previous) {
+  std::call_once(g_once, init_all);
+  const int i = find(name);
+  if (i < 0) return -1;
+  if (previous) *previous = g_val[i];
+  g_val[i] = clampv(kDefs[i], value);
+  return 0;
+}
+
+int option_get(const char* name, int* value) {
+  std::call_once(g_once, init_all);
+  const int i = find(name);
+  if (i < 0) return -1;
+  if (value) *value = g_val[i];
+  return 0;
+}
+
+int option_count() { return kCount; }
+const OptionDef& option_def(int i) { return kDefs[i]; }
+
+}  // namespace gpet

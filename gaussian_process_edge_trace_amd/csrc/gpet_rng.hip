@@ -34,6 +34,7 @@
 
 #include "gpet_dev.h"
 #include "gpet_kernels.h"
+#include "gpet_options.h"
 
 namespace gpet {
 
@@ -324,7 +325,7 @@ bool normals4_applies(const EdgeDev* h_edges, int B) {
 }
 
 int& gpet_opt_rng4() {
-  static int v = getenv("GPET_RNG4") != nullptr ? atoi(getenv("GPET_RNG4")) : -1;
+  static int& v = option("rng4");
   return v;
 }
 

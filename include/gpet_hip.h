@@ -123,24 +123,18 @@ typedef struct gpet_batch gpet_batch;
 /* ---- context ------------------------------------------------------------------------ */
 int gpet_abi_version(void);
 
-/* Process-wide tuning switches (no reference counterpart).  name = "scalar_jacobi": 1 factors posterior covariances of
- * rank > 96 (Matern; short-length-scale RBF) with round 1's whole-GPU scalar Jacobi on the covariance instead of the
- * default (pivoted Cholesky over the GPU + one-sided block Jacobi on its rows, ~12x faster and closer to LAPACK's
- * factor); kept as an independent cross-check.  name = "oj_tol_exp" (default 8) / "oj_max_sweeps" (default 16): the
- * default solver stops after a sweep in which every pair of rows it met was orthogonal to 10^-x relative, or after
- * that many sweeps.  name = "blocking_sync": 1 = host waits sleep on a blocking event instead of spinning in
- * hipStreamSynchronize (default: on when WORLD_SIZE > 1 -- one process per GPU, several driver threads each, on a node's
- * shared cores; environment GPET_BLOCKING_SYNC).  name = "rng_lookahead": how many iterations the random-number stream of the device loop may
- * run ahead of it (default -1 = by batch size: 8 for batches of up to 64 edges, whose loop is bound by the latency of
- * one sequential stream per edge and iteration, 1 for larger ones, which are bound by the generator's throughput; 0: it
- * starts when the previous iteration's pixel selection is done, so nothing is drawn for finished edges, but it then
- * delays the start of every iteration; larger n only adds draws for edges that finish meanwhile; results are identical).  name = "lml_two_tiles_from": launches of gpet_lml_batch with at least this many
- * problems use the two-tiles-per-thread objective kernel also below 129 training points (default 600; same pivots and
- * element updates, the final sums are added in a different order).  name = "jacobi_variant": the LDS-resident Jacobi
- * of factors of rank <= 96: 1 (default) = seated form (blocks addressed by seat, upper triangle, in place, two workgroups
- * per CU), 0 = by row index (round 1's kernel; the same rotations in the same order, results equal to rounding; kept as
- * the cross-check).  Returns the previous value, or -1 for an unknown name. */
+/* Process-wide tuning switches (no reference counterpart): ONE table (csrc/gpet_options.hip; INTEGRATION.md section 5
+ * lists every name with its default, range and meaning).  An option's initial value is the environment variable
+ * GPET_<NAME IN CAPITALS> if set, else the table's default; results never depend on an option except where its
+ * description says so (cross-check solvers, opt-in modes).
+ * gpet_set_option returns the previous value -- "chosen automatically" (-1) is reported as the option's largest value
+ * + 1 -- or -1 for an unknown name; values outside an option's range are clamped.  gpet_get_option stores the current
+ * value (-1 = automatic) and returns 0, or GPET_ERR_BAD_ARG for an unknown name.  gpet_option_count / gpet_option_info
+ * enumerate the table (any out pointer may be NULL; strings are static). */
 int gpet_set_option(const char* name, int value);
+int gpet_get_option(const char* name, int* value);
+int gpet_option_count(void);
+int gpet_option_info(int index, const char** name, int* value, int* def, int* lo, int* hi, const char** doc);
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
  * to let the library create its own. */
 int gpet_ctx_create(int device, void* stream, gpet_ctx** out);

@@ -76,3 +76,34 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f
+
+
+def test_option_registry_round_trip_and_documented():
+    """The process-wide tuning switches are ONE table behind gpet_set_option / gpet_get_option / gpet_option_info (host
+    code: no GPU needed): enumerate, set / get, clamping, "automatic" reported as the largest value + 1 by the C entry
+    point, unknown names rejected -- and every option has a row in INTEGRATION.md section 3b."""
+    import os
+    from gaussian_process_edge_trace_amd import _lib as L
+    opts = L.options()
+    assert len(opts) >= 20 and all(o["lo"] <= o["default"] <= o["hi"] and o["doc"] for o in opts.values())
+    assert "rng4" in opts and "oj_persist" in opts and "struct_path" in opts
+    old = L.set_option("oj_max_sweeps", 1000)
+    try:
+        assert L.get_option("oj_max_sweeps") == opts["oj_max_sweeps"]["hi"]  # clamped
+        assert L.set_option("oj_max_sweeps", 7) == opts["oj_max_sweeps"]["hi"] and L.get_option("oj_max_sweeps") == 7
+    finally:
+        L.set_option("oj_max_sweeps", old)
+    lib = L.load()
+    o4 = L.get_option("rng4")
+    try:
+        L.set_option("rng4", -1)
+        assert lib.gpet_set_option(b"rng4", 1) == opts["rng4"]["hi"] + 1  # -1 ("automatic") as hi + 1
+        assert lib.gpet_set_option(b"rng4", 0) == 1
+    finally:
+        L.set_option("rng4", o4)
+    assert lib.gpet_set_option(b"no_such_option", 1) == -1
+    with pytest.raises(ValueError):
+        L.get_option("no_such_option")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in opts:
+        assert "| `%s` |" % name in doc, name

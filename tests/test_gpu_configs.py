@@ -213,16 +213,23 @@ def test_any_rank_factor_full_rank_matern_vs_lapack(amd, ctx):
     assert d_lapack < 1e-5 and d_scalar < 0.05  # (measured: 2.7e-7 px; the scalar rounds are 4e-3 px from LAPACK)
 
 
-@pytest.mark.parametrize("env", [{}, {"GPET_PCX_ONE_PIVOT": "1"}, {"GPET_OJ_NO_STAGE": "1"}, {"GPET_OJ_NO_ARGS": "1"},
-                                 {"GPET_PCX_ONE_PIVOT": "1", "GPET_OJ_NO_STAGE": "1", "GPET_OJ_NO_ARGS": "1"}])
-def test_any_rank_factor_code_paths_agree(amd, ctx, env, monkeypatch):
+@pytest.mark.parametrize("opts", [{}, {"pcx_one_pivot": 1}, {"oj_stage": 0}, {"oj_args": 0}, {"oj_persist": 0},
+                                  {"pcx_one_pivot": 1, "oj_stage": 0, "oj_args": 0}])
+def test_any_rank_factor_code_paths_agree(amd, ctx, opts):
     """Every variant of the any-rank factor -- blocked or one-pivot-per-launch Cholesky, rows staged in LDS or fed from
     registers, per-edge pointers in the kernel arguments or in the edge table (the forms wide edges and big batches
     take) -- on a batch of three 320-column Matern edges of different observation sets: valid factors (reconstruction,
     LAPACK's eigenvalues) whose samples agree with LAPACK's to 1e-5 px."""
     L = amd._lib
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    old = {k: L.set_option(k, v) for k, v in opts.items()}
+    try:
+        _any_rank_paths_body(amd, ctx, L)
+    finally:
+        for k, v in old.items():
+            L.set_option(k, v)
+
+
+def _any_rank_paths_body(amd, ctx, L):
     N = 320
     img, truth = orc.synth_sinusoid_image(N, 5)
     grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)

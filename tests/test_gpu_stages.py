@@ -529,18 +529,15 @@ def test_topk_sort_and_rank_counting_agree_with_stable_argsort(amd, ctx, monkeyp
         costs[rng.integers(0, S, size=3)] = 0.0
         costs[rng.integers(0, S, size=2)] = -0.0
         want = np.argsort(costs, kind="stable")[:n_keep]
-        for env in ("", "1"):
-            if env:
-                monkeypatch.setenv("GPET_TOPK_RANK", env)
-            else:
-                monkeypatch.delenv("GPET_TOPK_RANK", raising=False)
+        for env in (0, 1):
+            L.set_option("topk_rank", env)
             b.write(L.BUF_COSTS, costs)
             b.profile_stage(141, 1)
             got_idx = b.read(L.BUF_BEST_IDX)[:n_keep]
             got_cost = b.read(L.BUF_BEST_COSTS)[:n_keep]
             assert np.array_equal(got_idx, want), (S, env)
             assert np.array_equal(got_cost, costs[want])
-        monkeypatch.delenv("GPET_TOPK_RANK", raising=False)
+        L.set_option("topk_rank", 0)
 
 
 def test_philox_normals_equal_the_oracle_generator(amd, ctx, golden):

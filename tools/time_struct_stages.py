@@ -12,4 +12,4 @@ seeds = list(range(1, E + 1))
 tr = amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx)
 b = tr._batch
 b.iterate(seeds, 7)
-print("shared basis off" if os.environ.get("GPET_NO_SHARED_BASIS") else "shared basis on", " ".join("%d: %.3f ms" % (k, b.profile_stage(k, 20)) for k in (120, 121, 122, 123)), flush=True)
+print("shared basis off" if os.environ.get("GPET_SHARED_BASIS") == "0" else "shared basis on", " ".join("%d: %.3f ms" % (k, b.profile_stage(k, 20)) for k in (120, 121, 122, 123)), flush=True)
