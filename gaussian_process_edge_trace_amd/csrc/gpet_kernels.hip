@@ -3973,6 +3973,121 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GPET_S
 #undef SS_STAMP
 }
 
+// a6 + a7 in one kernel, the OTHER way round (round 4): k_sample_score above is stationary in the COLUMN tile -- its workgroup
+// keeps one image slab and streams the normals of all curves through it, so the 17 tiles of an edge each pull the edge's
+// 0.58 MB of normals through their CU again, with 64 different rows per load instruction: 2 000 cycles to issue and 1 000 to
+// wait for 18 loads per group of 16 curves, 3.2 ms per 1 024 edges against 3.05 for the separate kernels.  Here the workgroup
+// is stationary in the CURVES, like the sample GEMM: 16 waves x 16 rows of Z in registers for the whole kernel (read once),
+// and it sweeps the column tiles: per tile the 32 factor columns (even / odd points de-interleaved: the B operands of the
+// two accumulator tiles, conflict-free 128-byte rows) and the 32 x M image slab are staged in LDS -- fully coalesced
+// 128-byte rows of the image, which all edges of a batch share and which therefore lives in L2.  Four workgroups per edge
+// stage the whole image once each (4 MB per edge through L2 -> LDS) where the separate kernels write and re-read 8 MB of
+// samples in HBM.  The MFMA chain, the epilogue and the scoring arithmetic are those of k_sample_score / k_score_tile
+// (score_pairs_row), the per-tile partials go where k_score_combine expects them: costs, best_idx, kept rows and traces
+// are identical to the unfused path bit for bit.
+template <int KS, bool F32>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_score2(EdgeDev* edges) {
+  int edge, part;  // the curve blocks of an edge on one XCD: its factor and its slabs come out of HBM / the other L2s once
+  xcd_edge_part((int)gridDim.x, edge, part);
+  const EdgeDev E = edges[edge];
+  const gpet_scalars* sc = E.sc;
+  if ((sc->done && !sc->force) || sc->status != GPET_OK) return;
+  const int M = E.M, N = E.N, Lg = E.Lg, S = E.S, zc = E.z_cols;
+  const int s_blk = part * 256;
+  if (s_blk >= S) return;
+  extern __shared__ float s_img2[];  // [32][ldm] slab, then the factor tile and the tile's posterior mean
+  constexpr int NCOL = 2 * SC_PAIRS + 2;  // 32
+  const int ldm = M | 1;
+  double* s_fe = reinterpret_cast<double*>(s_img2 + (((size_t)NCOL * ldm + 3) & ~(size_t)3));  // [4 KS][16] even points
+  double* s_fo = s_fe + 4 * KS * 16;                                                                // [4 KS][16] odd points
+  double* s_mu = s_fo + 4 * KS * 16;                                                                // [32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pl = lane & 15, lq = lane >> 4;
+  const int npair = (Lg - 2) / 2;
+  const int n_tiles = (npair + SC_PAIRS - 1) / SC_PAIRS;
+  const int rows = sc->rank;
+  const GPET_GLOBAL double* __restrict__ Ag = as_global(E.A);
+  const GPET_GLOBAL double* __restrict__ Zs = as_global(E.Z) + (size_t)(sc->iter % E.z_ring) * ((size_t)S * zc);
+  const GPET_GLOBAL float* __restrict__ gimg = as_global(E.grad);
+  const GPET_GLOBAL double* __restrict__ meang = as_global(E.mean);
+  const double y_s = sc->y_s;
+  // the wave's 16 rows of Z: A operand lane (pl, lq) <- Z[row pl][4 q + lq]
+  const int s0 = s_blk + 16 * w;
+  double a[KS];
+  {
+    const int srow = s0 + pl;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int kk = 4 * q + lq;
+      a[q] = (kk < rows && srow < S) ? Zs[(size_t)srow * zc + kk] : 0.0;
+    }
+  }
+  for (int bx = 0; bx < n_tiles; ++bx) {
+    const int p0 = bx * SC_PAIRS;
+    const int c0 = E.x_st + 2 * p0;  // first image column of the slab
+    __syncthreads();                 // (the previous tile's operands and slab are no longer read)
+    for (int e0 = tid; e0 < NCOL * M; e0 += 4 * 1024) {  // the slab: four 128-byte image rows per wave instruction
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 1024 * u;
+        const int y = e >> 5, c = e & 31;
+        v[u] = (e < NCOL * M && c0 + c < N) ? gimg[(size_t)y * N + c0 + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 1024 * u;
+        if (e < NCOL * M) s_img2[(e & 31) * ldm + (e >> 5)] = v[u];
+      }
+    }
+    for (int e = tid; e < 4 * KS * NCOL; e += 1024) {  // the tile's 32 factor columns, zero beyond rank and grid
+      const int kk = e >> 5, c = e & 31;
+      const int j = 2 * p0 + c;
+      const double v = (kk < rows && j < Lg) ? Ag[(size_t)kk * Lg + j] : 0.0;
+      ((c & 1) ? s_fo : s_fe)[kk * 16 + (c >> 1)] = v;
+    }
+    if (tid < NCOL) s_mu[tid] = (2 * p0 + tid < Lg) ? meang[2 * p0 + tid] : 0.0;
+    __syncthreads();
+    v4f64 accE = (v4f64){0.0, 0.0, 0.0, 0.0}, accO = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      accE = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], s_fe[(4 * q + lq) * 16 + pl], accE, 0, 0, 0);
+      accO = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], s_fo[(4 * q + lq) * 16 + pl], accO, 0, 0, 0);
+    }
+    const double mu0 = s_mu[2 * pl], mu1 = s_mu[2 * pl + 1];
+    const float* col0 = s_img2 + (2 * pl) * ldm;
+    const float* col1 = col0 + ldm;
+    const bool on = pl < SC_PAIRS && (p0 + pl) < npair;
+    GPET_GLOBAL double* __restrict__ cpart = as_global(E.cost_part) + ((size_t)bx * S) * 2;
+    // two curves of the lane's four at a time (the scoring of four needs ~150 registers; two fit the 128 that let four
+    // waves share a SIMD): register g of lane (pl, lq) = curve s0 + lq + 4 g at the two points of pair p0 + pl
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double ya[2], yb[2], al[2], li[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        ya[g] = (accE[2 * h + g] + mu0) * y_s;
+        yb[g] = (accO[2 * h + g] + mu1) * y_s;
+        if (F32) {
+          ya[g] = (double)(float)ya[g];
+          yb[g] = (double)(float)yb[g];
+        }
+      }
+      score_pairs_row<2>(ya, yb, col0, col1, M, on, al, li);
+      if (pl == 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int sidx = s0 + lq + 4 * (2 * h + g);
+          if (sidx < S) {
+            cpart[2 * sidx] = al[g];
+            cpart[2 * sidx + 1] = li[g];
+          }
+        }
+      }
+    }
+  }
+}
+
 // The n_keep best curves of an iteration whose samples were scored out of the accumulators (k_sample_score): rows
 // best_idx[0 .. n_keep) of the sample matrix, formed by the MFMA chain of the sample GEMM (same bits) and stored where the
 // KDE and the pixel kernels read them.  One wave per (group of 16 kept rows, 16 columns).
@@ -4352,7 +4467,7 @@ __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
 //   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
 // columns outside the padded grid never receive weight.
-__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band) {
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band, int form) {
   int edge, tile;  // the column tiles of an edge on one XCD: neighbours share 8 of their 24 staged columns of every curve
   xcd_edge_part((int)gridDim.x, edge, tile);
   const EdgeDev E = edges[edge];
@@ -4364,7 +4479,8 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
   const int M = E.M, N = E.N;
   const int x0 = tile * KDE_TX;
   if (x0 >= N) return;
-  const int NC = KDE_TX + 8;
+  constexpr int NC_ = KDE_TX + 8;
+  const int NC = NC_;
   const int ld = (KDE_H + 8) | 1;
   double* s_y = s_a + NC * ld;        // [KDE_NB][NC] staged points (-1: none)
   double* s_wt = s_y + KDE_NB * NC;   // [KDE_NB] staged weights
@@ -4437,21 +4553,30 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
     for (int r0 = y_lo; r0 <= y_hi; r0 += KDE_H) {
       const int nrow = (y_hi + 1 - r0) < KDE_H ? (y_hi + 1 - r0) : KDE_H;
       // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
-      for (int i = tid; i < NC * ld; i += KDE_THREADS) s_a[i] = 0.0;
-      __syncthreads();
-      for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
-        const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
-        if (!single) {
-          int dl = 0, dh = 0;
-          __syncthreads();
-          stage(b0, nb, dl, dh);
-          __syncthreads();
-        }
-        // linear binning, one (curve, column) point per thread: 64-bit fixed-point LDS atomics, so the sums do
-        // not depend on the order the points arrive in (deterministic), at the resolution of f64 arithmetic
+      if (single && form != 0) {
+        // All kept curves are staged (the usual case; option "kde_form" = 1, the default): clearing, conversion and the
+        // vertical pass touch ONE column at a time, so every wave takes three of the tile's 24 columns through them on
+        // its own -- LDS operations of a wave execute in order, no workgroup barrier between conversion, halo and sliding
+        // window, and the vertical pass runs on 63 lanes of every wave (round 3's form, kde_form = 0: every phase over
+        // the whole tile with a barrier after each -- eight per chunk --, the vertical pass on 240 of 512 threads).  Four
+        // barriers instead of eight per chunk buy 3 %: what the kernel waits for is its binning atomics and the gathers
+        // of the staged points, not its barriers.  The same sums in both forms: fixed-point binning is order-
+        // independent, the vertical taps are added in the same order.
+        const int lane = tid & 63, wv = tid >> 6;
+        constexpr int WC = NC_ / (KDE_THREADS / 64);  // columns per wave
+        static_assert(WC * (KDE_THREADS / 64) == NC_, "the tile's columns divide evenly over the waves");
+        const int cw0 = wv * WC;
+        double* colw = s_a + cw0 * ld;
+        for (int i = lane; i < WC * ld; i += 64) colw[i] = 0.0;
         unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_a);
-        const int lmax = nrow + 8;
-        for (int e = tid; e < nb * NC; e += KDE_THREADS) {
+        const int lmax = nrow + 8, nbk = E.n_keep;
+        __syncthreads();
+        // linear binning by the whole workgroup, consecutive threads = the 24 columns of a curve: 64-bit fixed-point LDS
+        // atomics (order-independent sums).  (Binning per wave too -- its three columns only, no barrier at all before the
+        // horizontal pass -- puts ~21 curves of ONE column into a wave instruction, and the kept curves run within a few
+        // pixels of each other: the atomics of a wave hit a handful of addresses and serialise.  Measured at the same
+        // states: 0.90-0.92 ms per 1 024 edges against 0.85-0.88 for this form and 0.89-0.90 for round 3's.)
+        for (int e = tid; e < nbk * NC; e += KDE_THREADS) {
           const double y = s_y[e];
           if (y < 0.0) continue;
           const int bb = e / NC, bc = e - bb * NC;
@@ -4465,38 +4590,107 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
           if (l >= 0) atomicAdd(&col[l], (unsigned long long)__double2ll_rn((1.0 - fy) * w));
           if (l + 1 < lmax) atomicAdd(&col[l + 1], (unsigned long long)__double2ll_rn(fy * w));
         }
-      }
-      __syncthreads();
-      for (int i = tid; i < NC * ld; i += KDE_THREADS)
-        s_a[i] = (double)(long long)reinterpret_cast<unsigned long long*>(s_a)[i] * finv;
-      __syncthreads();
-      {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
-        int nseg = KDE_THREADS / NC;
-        if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
-        const int seg = tid / NC, c = tid % NC;
-        const int R = (nrow + nseg - 1) / nseg;
-        const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
-        double* col = s_a + c * ld;
-        double head[4], tail[4];
-        const bool active = (seg < nseg) && (q0 < nrow);
-        if (active) {
+        __syncthreads();
+        for (int i = lane; i < WC * ld; i += 64)
+          colw[i] = (double)(long long)reinterpret_cast<unsigned long long*>(colw)[i] * finv;
+        __builtin_amdgcn_wave_barrier();
+        {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4; lane = (segment, column)
+          int nseg = 64 / WC;
+          if (nseg > nrow / 4) nseg = (nrow / 4 > 0) ? nrow / 4 : 1;
+          const int seg = lane / WC, c = lane - seg * WC;
+          const int R = (nrow + nseg - 1) / nseg;
+          const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
+          double* col = colw + c * ld;
+          double head[4], tail[4];
+          const bool active = (seg < nseg) && (q0 < nrow);
+          double w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
+          if (active) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            head[t] = col[q0 + t];
-            tail[t] = col[q1 + 4 + t];
+            for (int t = 0; t < 4; ++t) {
+              head[t] = col[q0 + t];
+              tail[t] = col[q1 + 4 + t];
+            }
+            w4 = col[q0 + 4];
+            w5 = col[q0 + 5];
+            w6 = col[q0 + 6];
+            w7 = col[q0 + 7];
+          }
+          __builtin_amdgcn_wave_barrier();  // (every lane's halo is read before any lane writes: same instruction stream)
+          if (active) {
+            double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
+            for (int q = q0; q < q1; ++q) {
+              const int lnew = q + 8;
+              const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
+              const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
+                                 w7 * g[7] + w8 * g[8];
+              col[q + 4] = acc;
+              w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+            }
+          }
+        }
+      } else {
+        // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
+        for (int i = tid; i < NC * ld; i += KDE_THREADS) s_a[i] = 0.0;
+        __syncthreads();
+        for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
+          const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
+          if (!single) {
+            int dl = 0, dh = 0;
+            __syncthreads();
+            stage(b0, nb, dl, dh);
+            __syncthreads();
+          }
+          // linear binning, one (curve, column) point per thread: 64-bit fixed-point LDS atomics, so the sums do
+          // not depend on the order the points arrive in (deterministic), at the resolution of f64 arithmetic
+          unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_a);
+          const int lmax = nrow + 8;
+          for (int e = tid; e < nb * NC; e += KDE_THREADS) {
+            const double y = s_y[e];
+            if (y < 0.0) continue;
+            const int bb = e / NC, bc = e - bb * NC;
+            const double gy = y + 1.0;
+            const int iy = (int)floor(gy);
+            const int l = iy - (r0 - 3);
+            if (l + 1 < 0 || l >= lmax) continue;
+            const double w = s_wt[bb] * fscale;
+            const double fy = gy - (double)iy;
+            unsigned long long* col = s_bits + bc * ld;
+            if (l >= 0) atomicAdd(&col[l], (unsigned long long)__double2ll_rn((1.0 - fy) * w));
+            if (l + 1 < lmax) atomicAdd(&col[l + 1], (unsigned long long)__double2ll_rn(fy * w));
           }
         }
         __syncthreads();
-        if (active) {
-          double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
-          double w4 = col[q0 + 4], w5 = col[q0 + 5], w6 = col[q0 + 6], w7 = col[q0 + 7];
-          for (int q = q0; q < q1; ++q) {
-            const int lnew = q + 8;
-            const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
-            const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
-                               w7 * g[7] + w8 * g[8];
-            col[q + 4] = acc;
-            w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+        for (int i = tid; i < NC * ld; i += KDE_THREADS)
+          s_a[i] = (double)(long long)reinterpret_cast<unsigned long long*>(s_a)[i] * finv;
+        __syncthreads();
+        {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
+          int nseg = KDE_THREADS / NC;
+          if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
+          const int seg = tid / NC, c = tid % NC;
+          const int R = (nrow + nseg - 1) / nseg;
+          const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
+          double* col = s_a + c * ld;
+          double head[4], tail[4];
+          const bool active = (seg < nseg) && (q0 < nrow);
+          if (active) {
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              head[t] = col[q0 + t];
+              tail[t] = col[q1 + 4 + t];
+            }
+          }
+          __syncthreads();
+          if (active) {
+            double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
+            double w4 = col[q0 + 4], w5 = col[q0 + 5], w6 = col[q0 + 6], w7 = col[q0 + 7];
+            for (int q = q0; q < q1; ++q) {
+              const int lnew = q + 8;
+              const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
+              const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
+                                 w7 * g[7] + w8 * g[8];
+              col[q + 4] = acc;
+              w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
+            }
           }
         }
       }
@@ -6464,7 +6658,7 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
     const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
     if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(1024), 0, st, d_edges);
     if (parts & 2u)
-      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band);
+      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band, option("kde_form"));
     if ((parts & 4u) && !raw_band) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
@@ -6683,7 +6877,34 @@ hipError_t launch_sample_score(hipStream_t st, EdgeDev* d_edges, int B, const Ba
     if (bd.y_f32) hipLaunchKernelGGL((k_sample_score<KS_, true>), grid, block, lds, st, d_edges);  \
     else hipLaunchKernelGGL((k_sample_score<KS_, false>), grid, block, lds, st, d_edges);          \
   } while (0)
-    if (ks <= 8) GPET_SS_LAUNCH(8);
+    // option "fused_score" = 2: the curve-stationary form (k_sample_score2: 256 curves per workgroup, slab and factor tile
+    // re-staged per column tile), while its LDS fits one workgroup per CU
+    const size_t lds2 = (((size_t)(2 * SC_PAIRS + 2) * (bd.M | 1) + 3) & ~(size_t)3) * sizeof(float) +
+                        ((size_t)2 * 4 * (ks <= 8 ? 8 : ks <= 12 ? 12 : ks <= 16 ? 16 : 18) * 16 + 32) * sizeof(double);
+    if (gpet_opt_fused_score() == 2 && lds2 <= 160 * 1024) {
+      static PerDeviceOnce once2;
+      if (once2.first()) {
+#define GPET_SS2_ATTR(KS_)                                                                                                      \
+  (void)hipFuncSetAttribute((const void*)k_sample_score2<KS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)k_sample_score2<KS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        GPET_SS2_ATTR(8);
+        GPET_SS2_ATTR(12);
+        GPET_SS2_ATTR(16);
+        GPET_SS2_ATTR(18);
+#undef GPET_SS2_ATTR
+      }
+      const dim3 grid2(cdiv(bd.S, 256), B), block2(1024);
+#define GPET_SS2_LAUNCH(KS_)                                                                            \
+  do {                                                                                                  \
+    if (bd.y_f32) hipLaunchKernelGGL((k_sample_score2<KS_, true>), grid2, block2, lds2, st, d_edges);   \
+    else hipLaunchKernelGGL((k_sample_score2<KS_, false>), grid2, block2, lds2, st, d_edges);           \
+  } while (0)
+      if (ks <= 8) GPET_SS2_LAUNCH(8);
+      else if (ks <= 12) GPET_SS2_LAUNCH(12);
+      else if (ks <= 16) GPET_SS2_LAUNCH(16);
+      else GPET_SS2_LAUNCH(18);
+#undef GPET_SS2_LAUNCH
+    } else if (ks <= 8) GPET_SS_LAUNCH(8);
     else if (ks <= 12) GPET_SS_LAUNCH(12);
     else if (ks <= 16) GPET_SS_LAUNCH(16);
     else GPET_SS_LAUNCH(18);

@@ -21,8 +21,9 @@ def ctx(amd):
     return amd._lib.Context(0)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("name,dtype", [("stage_rbf500", "f64"), ("stage_rbf500", "f32"), ("stage_rbf64", "f64")])
-def test_fused_stage_equals_gemm_plus_scorer(amd, ctx, golden, name, dtype):
+def test_fused_stage_equals_gemm_plus_scorer(amd, ctx, golden, name, dtype, variant):
     """One iteration's state (structured factor, numpy-stream normals): costs from the accumulators == costs of the
     stored samples, bit for bit; the kept rows are the GEMM's rows; no other row is written."""
     L = amd._lib
@@ -49,7 +50,11 @@ def test_fused_stage_equals_gemm_plus_scorer(amd, ctx, golden, name, dtype):
     b.profile_stage(132, 1)  # (best_idx is still the separate scorer's)
     Y_f = b.read(L.BUF_SAMPLES)
     assert np.array_equal(Y_f[idx_u], Y_u[idx_u]), np.abs(Y_f[idx_u] - Y_u[idx_u]).max()
-    b.profile_stage(131, 1)
+    old = L.set_option("fused_score", variant)  # (1: column-tile-stationary k_sample_score, 2: curve-stationary k_sample_score2)
+    try:
+        b.profile_stage(131, 1)
+    finally:
+        L.set_option("fused_score", old)
     costs_f = b.read(L.BUF_COSTS)
     assert np.array_equal(costs_f, costs_u), np.abs(costs_f / costs_u - 1).max()
     b.profile_stage(141, 1)
@@ -58,8 +63,9 @@ def test_fused_stage_equals_gemm_plus_scorer(amd, ctx, golden, name, dtype):
     assert (Y_f[rest] == marker).all()
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("name", ["stage_rbf64", "stage_mat15_96", "stage_rbf500"])
-def test_fused_loop_traces_equal_unfused(amd, ctx, golden, name):
+def test_fused_loop_traces_equal_unfused(amd, ctx, golden, name, variant):
     """Whole traces with the fused kernel (default) and with the separate GEMM + scorer: identical observation sets per
     iteration, iteration counts, final costs and edge traces; return_lines hands back every sample in both modes."""
     L = amd._lib
@@ -67,7 +73,7 @@ def test_fused_loop_traces_equal_unfused(amd, ctx, golden, name):
     kw = dict(CTOR[name])
     out = {}
     for fused in (1, 0):
-        old = L.set_option("fused_score", fused)
+        old = L.set_option("fused_score", variant if fused else 0)
         try:
             tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **kw, _ctx=ctx)
             et = tr()
@@ -78,7 +84,7 @@ def test_fused_loop_traces_equal_unfused(amd, ctx, golden, name):
     for a, c in zip(out[1], out[0]):
         assert np.array_equal(np.asarray(a), np.asarray(c))
     # return_lines: the whole sample matrix of every iteration (the loop then runs the separate kernels)
-    old = L.set_option("fused_score", 1)
+    old = L.set_option("fused_score", variant)
     try:
         tr = amd.GP_Edge_Tracing(g["in_init"], g["ref_grad"], **kw, _ctx=ctx)
         et, (all_samples, all_obs, curves) = tr(return_lines=True)
@@ -89,7 +95,8 @@ def test_fused_loop_traces_equal_unfused(amd, ctx, golden, name):
         assert np.isfinite(Y).all() and np.abs(Y).max() > 0 and (np.abs(Y).max(axis=0) > 0).all()
 
 
-def test_fused_loop_batch_of_edges(amd, ctx, golden):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_fused_loop_batch_of_edges(amd, ctx, golden, variant):
     """A batch of edges with their own seeds (config 4's form): fused == separate for every edge."""
     L = amd._lib
     g = golden("stage_rbf500")
@@ -98,7 +105,7 @@ def test_fused_loop_batch_of_edges(amd, ctx, golden):
     B = 6
     res = {}
     for fused in (1, 0):
-        old = L.set_option("fused_score", fused)
+        old = L.set_option("fused_score", variant if fused else 0)
         try:
             bt = amd.GP_Edge_Tracing_Batch([g["in_init"]] * B, g["ref_grad"], seeds=list(range(3, 3 + B)), **kw, _ctx=ctx)
             traces = bt()

@@ -233,57 +233,75 @@ def test_t3_device_trace_vs_reference_trace(amd, ctx, golden, name):
 
 
 def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
-    """T3 as a DISTRIBUTION (tests/golden/quality_rbf500.npz: the unmodified reference on the README configuration,
-    image seeds {1, 3} x RNG seeds 1..24 -> iterations, MSE, DICE vs the true edge).  The library draws equally valid
-    samples with other eigenvector signs than LAPACK, so a single trace is a different draw; the spread of its quality
-    over seeds must be the reference's.  Image seed 1 is bistable IN THE REFERENCE (a third of its seeds end on a branch
-    with MSE 2000-12000, e.g. the 8443 of trace_rbf500's sign-flipped twin), image seed 3 is not.  The table goes to
-    gpurun_out/r03_t3_quality.json (kept as profiles/r03_t3_quality.json)."""
+    """T3 on INDEPENDENT seeds (tests/golden/quality_rbf500.npz, made by tests/golden/make_quality_fixture.py): the
+    README configuration on image seeds {1, 3} x 240 RNG seeds 997 apart (iteration k of seed s draws from
+    RandomState(s + k + 1), so closer seeds share normal streams).
+      * The device is the oracle under the library's sign convention, trace for trace: iterations, MSE and DICE of all
+        480 traces are IDENTICAL to the fixture's "harmonic" rows.
+      * The reference itself has no sign convention: LAPACK's singular-vector signs are implementation-defined and
+        change with the BLAS thread count -- the fixture holds the oracle under LAPACK's signs with 1 and with 8 threads
+        (the first equal to the unmodified reference with one thread, seed by seed), and those two disagree on most
+        seeds.  Image seed 1 is bistable (a branch with MSE < 2000, one with 2000-12000); which branch a seed takes is a
+        coin that every convention flips differently, so only the DISTRIBUTION is comparable: the device's good-branch
+        fraction lies within 3 standard errors of each LAPACK variant (and the two LAPACK variants of each other), the
+        good-branch median MSE, median DICE and iterations agree.
+    The table goes to gpurun_out/r04_t3_quality.json (kept as profiles/r04_t3_quality.json)."""
     import json
     import os
-    ref = golden("quality_rbf500")["ref_quality"]
+    fx = golden("quality_rbf500")
+    orq = fx["oracle_quality"]  # img_seed, seed, convention (0 LAPACK 1 thread, 1 harmonic, 2 LAPACK 8 threads), n_iter, mse, dice, relarea
     kw = CTOR["stage_rbf500"]
-    seeds = sorted(set(int(v) for v in ref[:, 1]))  # 1..24 and 48 seeds 997 apart (tests/golden/make_fixtures.py)
-    assert len(seeds) == 72
-    report = {"config": "README: 500x500, RBF sigma_f=75 l=20, N_samples=1000, delta_x=5, pixel_thresh=5; 72 RNG seeds "
-                        "(1..24: neighbours share most of their normal streams; 48 more, 997 apart)",
-              "columns": ["n_iter", "mse", "dice"], "images": {}}
+    seeds = sorted(set(int(v) for v in orq[orq[:, 2] == 1][:, 1]))
+    assert len(seeds) >= 200 and min(np.diff(seeds)) >= 64
+    report = {"config": "README: 500x500, RBF sigma_f=75 l=20, N_samples=1000, delta_x=5, pixel_thresh=5; %d RNG seeds 997 apart"
+                        % len(seeds), "columns": ["n_iter", "mse", "dice"], "images": {}}
+
+    def summary(x):
+        good = x[:, 1] < 2000.0
+        return {"n": int(len(x)), "n_iter_median": float(np.median(x[:, 0])), "n_iter_range": [int(x[:, 0].min()), int(x[:, 0].max())],
+                "good_fraction_mse_lt_2000": float(good.mean()), "good_fraction_se": float(np.sqrt(good.mean() * (1 - good.mean()) / len(x))),
+                "mse_quartiles": [float(v) for v in np.percentile(x[:, 1], [25, 50, 75])],
+                "mse_median_good_branch": float(np.median(x[good, 1])),
+                "dice_quartiles": [float(v) for v in np.percentile(x[:, 2], [25, 50, 75])], "dice_min": float(x[:, 2].min())}
     for img_seed in (1, 3):
         img, truth = orc.synth_sinusoid_image(500, img_seed)
         grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
-        if img_seed == 1:
-            assert np.array_equal(grad, golden("stage_rbf500")["ref_grad"])
         init = truth[[0, -1], :][:, [1, 0]]
         kwb = {k: v for k, v in kw.items() if k != "seed"}
         batch = amd.GP_Edge_Tracing_Batch([init] * len(seeds), np.asarray(grad, dtype=np.float32), seeds, **kwb, _ctx=ctx)
         traces = batch()
         dev = np.array([[it, amd.gpet_utils.trace_MSE(et, truth), amd.gpet_utils.trace_dicecoef(et, truth)]
                         for it, et in zip(batch.timings["iters"], traces)])
-        rr = ref[ref[:, 0] == img_seed]
-        rr = rr[np.argsort(rr[:, 1])]
-        assert [int(v) for v in rr[:, 1]] == seeds
-        r = rr[:, 2:5]
-        assert r.shape == dev.shape
-
-        def summary(x):
-            return {"n_iter_median": float(np.median(x[:, 0])), "n_iter_range": [int(x[:, 0].min()), int(x[:, 0].max())],
-                    "good_fraction_mse_lt_2000": float(np.mean(x[:, 1] < 2000.0)),
-                    "mse_quartiles": [float(v) for v in np.percentile(x[:, 1], [25, 50, 75])],
-                    "mse_median_good_branch": float(np.median(x[x[:, 1] < 2000.0, 1])),
-                    "dice_quartiles": [float(v) for v in np.percentile(x[:, 2], [25, 50, 75])], "dice_min": float(x[:, 2].min())}
-        sd, sr = summary(dev), summary(r)
-        report["images"][str(img_seed)] = {"device": sd, "reference": sr, "device_rows": dev.tolist(), "reference_rows": r.tolist()}
-        print("image seed %d: device %s" % (img_seed, sd))
-        print("image seed %d: reference %s" % (img_seed, sr))
-        # bands: 72 draws each -- a fraction has a standard error of ~0.055 (the difference of two: 0.08), medians of this
-        # heavy-tailed MSE move by tens of %
-        assert abs(sd["good_fraction_mse_lt_2000"] - sr["good_fraction_mse_lt_2000"]) <= 0.25
-        assert abs(sd["n_iter_median"] - sr["n_iter_median"]) <= 1.5
-        assert sd["mse_median_good_branch"] <= 1.5 * sr["mse_median_good_branch"] + 25.0
-        assert sd["dice_quartiles"][1] >= sr["dice_quartiles"][1] - 0.015
-        assert sd["dice_min"] >= sr["dice_min"] - 0.05
+        batch._batch.close()
+        rows = {}
+        for conv in (0, 1, 2):
+            r = orq[(orq[:, 0] == img_seed) & (orq[:, 2] == conv)]
+            r = r[np.argsort(r[:, 1])]
+            assert [int(v) for v in r[:, 1]] == seeds
+            rows[conv] = r[:, 3:6]
+        # the device IS the oracle under the harmonic convention, seed by seed
+        assert np.array_equal(dev, rows[1]), np.argwhere(dev != rows[1])[:5]
+        sd, s0, s2 = summary(dev), summary(rows[0]), summary(rows[2])
+        report["images"][str(img_seed)] = {"device = oracle, harmonic signs": sd, "oracle = reference, LAPACK signs, 1 BLAS thread": s0,
+                                           "oracle, LAPACK signs, 8 BLAS threads": s2,
+                                           "seeds_with_identical_quality_lapack_1_vs_8_threads": int(np.sum(np.all(rows[0] == rows[2], axis=1))),
+                                           "seeds_with_identical_quality_device_vs_lapack_1_thread": int(np.sum(np.all(dev == rows[0], axis=1)))}
+        print("image seed %d: device / harmonic %s" % (img_seed, sd))
+        print("image seed %d: LAPACK signs, 1 thread %s" % (img_seed, s0))
+        print("image seed %d: LAPACK signs, 8 threads %s" % (img_seed, s2))
+        for other in (s0, s2):
+            se = np.hypot(sd["good_fraction_se"], other["good_fraction_se"])
+            assert abs(sd["good_fraction_mse_lt_2000"] - other["good_fraction_mse_lt_2000"]) <= 3.0 * max(se, 0.02)
+            assert abs(sd["n_iter_median"] - other["n_iter_median"]) <= 1.0
+            assert sd["mse_median_good_branch"] <= 1.25 * other["mse_median_good_branch"] + 25.0
+            assert sd["dice_quartiles"][1] >= other["dice_quartiles"][1] - 0.01
+            assert sd["dice_min"] >= other["dice_min"] - 0.05
+    # the reference itself (unmodified, one BLAS thread) on its 60-seed subset = the oracle's LAPACK rows, seed by seed
+    ref = fx["ref_quality_t1"]
+    lut = {(int(r[0]), int(r[1])): r[3:] for r in orq if int(r[2]) == 0}
+    assert len(ref) >= 100 and all(np.array_equal(lut[(int(r[0]), int(r[1]))], r[2:]) for r in ref)
     out = os.environ.get("GPET_T3_OUT", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
-                                                     "r03_t3_quality.json"))
+                                                     "r04_t3_quality.json"))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(report, f, indent=1)

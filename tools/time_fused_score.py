@@ -18,10 +18,15 @@ tr = amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx)
 b = tr._batch
 b.iterate(seeds, 7)
 for rep in range(2):
-    t = {k: b.profile_stage(k, 20) for k in (130, 140, 141, 131, 132)}
-    print("E=%d  gemm %.3f + score %.3f = %.3f ms | fused %.3f + keep rows %.3f = %.3f ms | topk %.3f"
-          % (E, t[130], t[140], t[130] + t[140], t[131], t[132], t[131] + t[132], t[141]), flush=True)
-for fused in (1, 0, 1, 0):
+    t = {k: b.profile_stage(k, 20) for k in (130, 140, 141, 132)}
+    f = {}
+    for variant in (1, 2):  # 1: column-tile-stationary (k_sample_score), 2: curve-stationary (k_sample_score2)
+        L.set_option("fused_score", variant)
+        f[variant] = b.profile_stage(131, 20)
+    L.set_option("fused_score", 0)
+    print("E=%d  gemm %.3f + score %.3f = %.3f ms | fused (column tiles) %.3f, (curve blocks) %.3f + keep rows %.3f = %.3f / %.3f ms | topk %.3f"
+          % (E, t[130], t[140], t[130] + t[140], f[1], f[2], t[132], f[1] + t[132], f[2] + t[132], t[141]), flush=True)
+for fused in (2, 0, 1, 2, 0):
     L.set_option("fused_score", fused)
     tr.reset()
     ctx.sync()
