@@ -3985,6 +3985,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GPET_S
 // samples in HBM.  The MFMA chain, the epilogue and the scoring arithmetic are those of k_sample_score / k_score_tile
 // (score_pairs_row), the per-tile partials go where k_score_combine expects them: costs, best_idx, kept rows and traces
 // are identical to the unfused path bit for bit.
+// Measured (1 024 edges of the bench shape, tools/time_fused_score.py): 3.05 ms against 3.15-3.17 for the column-tile form
+// and 2.98-3.03 for the separate GEMM (1.79) + scorer (1.20) -- plus 0.38 ms for the kept rows in both fused forms.  The
+// floor of ANY fused form is the matrix instructions (0.94 ms at peak) plus the scoring's vector work (1.1 ms): an f64
+// matrix instruction holds the vector unit's FMA lanes, the two do not overlap.  What this kernel adds to that
+// floor is the staging of slab and factor tile between two barriers per tile (16 image loads per thread in four dependent
+// batches).  Staging tile t + 1 under tile t's matrix instructions into a second pair of buffers was built as well
+// (161 KB of LDS: two 31-column slabs, two factor tiles): with 1 024 threads the staged values do not fit the 128
+// registers four waves per SIMD leave (the rows of Z spill and are reloaded per tile: 4.6 ms), with 768 threads (three
+// waves per SIMD, no spill, six workgroups per edge) 3.69 ms -- both slower than this plain form, which is the one kept.
 template <int KS, bool F32>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_sample_score2(EdgeDev* edges) {
   int edge, part;  // the curve blocks of an edge on one XCD: its factor and its slabs come out of HBM / the other L2s once
