@@ -636,8 +636,10 @@ def main():
     ridge = FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)  # flop per byte
     use_flops = (a_flops / a_bytes) > ridge
     traffic = None
-    tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if os.path.exists(tp):
+    import glob
+    tps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))  # (the latest round's PMC passes)
+    tp = tps[-1] if tps else ""
+    if tp and os.path.exists(tp):
         prof = json.load(open(tp))
         if prof.get("edges") == E and prof.get("image") == [N, N] and dom in prof.get("kernels", {}):
             traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
@@ -658,8 +660,10 @@ def main():
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                     note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
                           "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_seat" else
-                          ("bound by the samples it stores (8 S Lg bytes per edge: 2.7-2.85 TB/s is what a store-only kernel of this "
-                           "shape reaches, tools/ubench/gemm_pipe.hip), see DESIGN.md section 6" if dom == "k_sample_gemm_mfma_r" else
+                          ("bound by the samples it stores (8 S Lg bytes per edge = 4.1 GB per launch): a kernel that ONLY stores them in the "
+                           "same row-tile shape takes 1.13-1.19 ms = 3.4-3.6 TB/s (profiles/r03_gemm_store_counters.txt, "
+                           "tools/ubench/hbm_write.hip) -- the one store-only ceiling, also quoted in DESIGN.md section 6; the matrix "
+                           "instructions alone 1.12 ms; this kernel overlaps the two to 1.8 ms" if dom == "k_sample_gemm_mfma_r" else
                           ("numpy's RandomState(seed).standard_normal stream, bit for bit: MT19937 + polar method, every attempt of the "
                            "S x Lg stream decided, zc of Lg columns stored; vector-ALU bound (integer; the `valu` entry), not HBM or MFMA: "
                            "DESIGN.md section 6b; the sample GEMM (next in device time) is at %.2f of the f64 MFMA peak"

@@ -601,7 +601,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     E.z_ring = (E.z_cols >= Lg && Lg > 128) ? 2 : (B <= 64 ? 16 : 9);
     // small batches are bound by the chain of Jacobi rounds: their rotations are logged and the eigenvectors formed by a
     // second kernel (k_jacobi_wpass); 40 sweeps x (m - 1) rounds x m / 2 pairs x 16 bytes = 2.9 MB per edge at rank 96
-    const int jlog_max_b = option("jlog_max_b");  // (16; the rotation-log form for bigger batches was measured slower)
+    const int jlog_max_b = option("jlog_max_b");  // (32: the rotation-log form pays while the chain of rounds is the time)
     E.jlog_cap = (B <= jlog_max_b && E.r_cap <= 96) ? 40 : 0;
     E.kernel_type = p.kernel_type;
     E.nu_code = p.kernel_type == GPET_KERNEL_MATERN ? nu_to_code(p.nu) : 2;

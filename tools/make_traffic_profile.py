@@ -1,4 +1,4 @@
-"""profiles/r03_pmc_traffic.json from two rocprofv3 PMC passes of tools/prof_stages.py:
+"""profiles/<round>_pmc_traffic.json from two rocprofv3 PMC passes of tools/prof_stages.py:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_stages.py 1024 2
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stages.py 1024 2
@@ -32,6 +32,7 @@ def mean_of(path, name, kernel):
 
 def main():
     E, N = int(sys.argv[1]), int(sys.argv[2])
+    R = sys.argv[3] if len(sys.argv) > 3 else "r04"
     fe, wr = last("gpurun_out/pmc_fetch", "FETCH_SIZE"), last("gpurun_out/pmc_write", "WRITE_SIZE")
     out = dict(edges=E, image=[N, N], source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/prof_stages.py",
                correction="HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024", kernels={})
@@ -41,7 +42,7 @@ def main():
                                      hbm_bytes_per_launch=(2.0 * fe[k] + wr[k]) * 1024.0)
     # the LML kernel of the converged fits is not part of tools/prof_stages.py: its entry comes from two more PMC passes
     # over `tools/prof_final.py E 0` (gpurun_out/pmc_lml_f, pmc_lml_w), averaged over all its launches
-    old_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    old_path = os.path.join(ROOT, "profiles", R + "_pmc_traffic.json")
     if glob.glob(os.path.join(ROOT, "gpurun_out/pmc_lml_f", "*", "*_counter_collection.csv")):
         lf, lw = mean_of("gpurun_out/pmc_lml_f", "FETCH_SIZE", "k_lml"), mean_of("gpurun_out/pmc_lml_w", "WRITE_SIZE", "k_lml")
         out["kernels"]["k_lml"] = dict(fetch_size_kb=lf[0], write_size_kb=lw[0], launches=lf[1],

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Regenerates profiles/r03_* on the GPU box (run through gpurun from the repo root):
+# Regenerates profiles/<round>_* on the GPU box (run through gpurun from the repo root; round tag = $2, default r04):
 #   bench line, rocprofv3 --kernel-trace --stats of the same command, the dominant kernel alone, PMC traffic.
 # Every rocprofv3 pass is its own run (PMC passes never share a run with a trace), program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=${1:-1024}
+R=${2:-r04}
 O=gpurun_out/prof
 rm -rf $O gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 mkdir -p $O
@@ -29,26 +30,29 @@ echo "== single-edge trace under rocprofv3 --kernel-trace (launch gaps)"
 rocprofv3 --kernel-trace --output-format csv -d $O/se_trace -- python3 tools/single_edge_latency.py > $O/se.log 2>&1
 echo "== instruction counters of the objective kernel"
 bash tools/pmc_l16.sh 98 13312 > $O/pmc_l16.log 2>&1
+echo "== instruction counters of the generator (k_mt_normals4 against k_mt_normals)"
+bash tools/pmc_groups.sh rng4 k_mt_normals "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY" -- tools/time_rng4.py $E > $O/pmc_rng4.log 2>&1
 echo "== summaries"
 mkdir -p gpurun_out/profiles_new
-python3 tools/make_traffic_profile.py $E 500 > $O/traffic.log
-cp profiles/r03_pmc_traffic.json gpurun_out/profiles_new/
-grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('gpurun_out/profiles_new/r03_bench_n1.json','w'), indent=1)"
-cp $(ls $O/bench_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r03_bench_kernel_stats.csv
-cp $(ls $O/stage_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r03_stage_kernel_stats.csv
-cp $(ls $O/eig_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r03_matern_factor_kernel_stats.csv
-python3 tools/trace_gaps.py $O/eig_trace > gpurun_out/profiles_new/r03_matern_factor_launches.txt
-grep "^N=" $O/eig.log >> gpurun_out/profiles_new/r03_matern_factor_launches.txt
-cp $(ls $O/c3_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/r03_config3_kernel_stats.csv
-python3 tools/single_edge_timeline.py $O/se_trace gpurun_out/profiles_new/r03_single_edge_timeline.json > $O/se_timeline.log 2>&1
-cp $O/pmc_l16.log gpurun_out/profiles_new/r03_k_lml16_counters.txt
+python3 tools/make_traffic_profile.py $E 500 $R > $O/traffic.log
+cp profiles/${R}_pmc_traffic.json gpurun_out/profiles_new/
+grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('gpurun_out/profiles_new/'+'$R'+'_bench_n1.json','w'), indent=1)"
+cp $(ls $O/bench_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/${R}_bench_kernel_stats.csv
+cp $(ls $O/stage_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/${R}_stage_kernel_stats.csv
+cp $(ls $O/eig_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/${R}_matern_factor_kernel_stats.csv
+python3 tools/trace_gaps.py $O/eig_trace > gpurun_out/profiles_new/${R}_matern_factor_launches.txt
+grep "^N=" $O/eig.log >> gpurun_out/profiles_new/${R}_matern_factor_launches.txt
+cp $(ls $O/c3_trace/*/*kernel_stats.csv | head -1) gpurun_out/profiles_new/${R}_config3_kernel_stats.csv
+python3 tools/single_edge_timeline.py $O/se_trace gpurun_out/profiles_new/${R}_single_edge_timeline.json > $O/se_timeline.log 2>&1
+cp $O/pmc_l16.log gpurun_out/profiles_new/${R}_k_lml16_counters.txt
+cp $O/pmc_rng4.log gpurun_out/profiles_new/${R}_k_mt_normals4_counters.txt
 DOM=$(grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel'])")
 echo "dominant kernel: $DOM"
 if [ "$DOM" = "k_lml" ]; then
   NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//3)")
-  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/r03_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
+  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
 else
-  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/r03_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
+  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
 fi
 rm -rf $O/bench_trace $O/stage_trace $O/lml_trace $O/eig_trace $O/c3_trace $O/se_trace gpurun_out/pmc_l16 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 ls -la gpurun_out/profiles_new
