@@ -135,8 +135,9 @@ def main():
     n8 = sum(1 for r in ref_old if (int(r[0]), int(r[1])) in lut2)
     e8 = sum(1 for r in ref_old if (int(r[0]), int(r[1])) in lut2 and np.array_equal(lut2[(int(r[0]), int(r[1]))], r[2:]))
     print("oracle (LAPACK signs, 8 BLAS threads) == round 3's reference rows (default threads) on %d of %d pairs" % (e8, n8))
-    t1_vs_t8 = sum(1 for k in lut0 if k in lut2 and np.array_equal(lut0[k], lut2[k]))
-    print("LAPACK signs, 1 thread vs 8 threads: the same trace quality on %d of %d (image, seed) pairs" % (t1_vs_t8, len(lut0)))
+    both = [k for k in lut0 if k in lut2]
+    t1_vs_t8 = sum(1 for k in both if np.array_equal(lut0[k], lut2[k]))
+    print("LAPACK signs, 1 thread vs 8 threads: the same trace quality on %d of %d (image, seed) pairs" % (t1_vs_t8, len(both)))
     for a in IMG_SEEDS:
         for c in (0, 2, 1):
             r = orc_rows[(orc_rows[:, 0] == a) & (orc_rows[:, 2] == c)]

@@ -6,7 +6,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import gaussian_process_edge_trace_amd as amd  # noqa: E402
-from gaussian_process_edge_trace_amd import _final_fit as ff  # noqa: E402
+from tests import final_fit_inputs as ff  # noqa: E402
 from oracle import gpet_oracle as orc  # noqa: E402  (checker + synthetic image)
 
 n_time = int(sys.argv[1]) if len(sys.argv) > 1 else 98

@@ -3,7 +3,7 @@ import sys
 import numpy as np
 sys.path.insert(0, ".")
 import gaussian_process_edge_trace_amd as amd
-from gaussian_process_edge_trace_amd import _final_fit as ff
+from tests import final_fit_inputs as ff
 from oracle import gpet_oracle as orc
 from tests.test_oracle_vs_golden import CTOR
 L = amd._lib

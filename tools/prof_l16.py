@@ -3,7 +3,7 @@ import sys
 import numpy as np
 sys.path.insert(0, ".")
 import gaussian_process_edge_trace_amd as amd  # noqa: E402
-from gaussian_process_edge_trace_amd import _final_fit as ff  # noqa: E402
+from tests import final_fit_inputs as ff  # noqa: E402
 from bench import synth_image  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 98
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -29,9 +29,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_trace -- python3 t
 echo "== single-edge trace under rocprofv3 --kernel-trace (launch gaps)"
 rocprofv3 --kernel-trace --output-format csv -d $O/se_trace -- python3 tools/single_edge_latency.py > $O/se.log 2>&1
 echo "== instruction counters of the objective kernel"
-bash tools/pmc_l16.sh 98 13312 > $O/pmc_l16.log 2>&1
+bash tools/pmc_l16.sh 98 13312 > $O/pmc_l16.log 2>&1 || echo "(pmc_l16 failed: see $O/pmc_l16.log)"
 echo "== instruction counters of the generator (k_mt_normals4 against k_mt_normals)"
-bash tools/pmc_groups.sh rng4 k_mt_normals "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY" -- tools/time_rng4.py $E > $O/pmc_rng4.log 2>&1
+bash tools/pmc_groups.sh rng4 k_mt_normals "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY" -- tools/time_rng4.py $E > $O/pmc_rng4.log 2>&1 || echo "(pmc rng4 failed)"
 echo "== summaries"
 mkdir -p gpurun_out/profiles_new
 python3 tools/make_traffic_profile.py $E 500 $R > $O/traffic.log
