@@ -4476,7 +4476,11 @@ __global__ void __launch_bounds__(1024) k_kde_prep(EdgeDev* edges) {
 //   horizontal 9 taps + crop + f32 cast + min/max, straight to HBM.
 // Rows outside the band are written as zeros.  No global binning grid, no boundary tests: rows and
 // columns outside the padded grid never receive weight.
-__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band, int form) {
+// (Round 4: clearing, conversion and the vertical pass per wave on its own three columns -- four barriers per chunk instead
+//  of eight, the vertical pass on 63 lanes of every wave -- was built and is bit-identical: 0.85-0.88 against 0.89-0.90 ms
+//  per 1 024 edges on a batch alone, 15.2 against 14.6 ms per step inside the bench; binning per wave as well: 0.90-0.92.
+//  The kernel waits for its binning atomics and the gathers of the staged points, not for its barriers.  Dropped.)
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int raw_band) {
   int edge, tile;  // the column tiles of an edge on one XCD: neighbours share 8 of their 24 staged columns of every curve
   xcd_edge_part((int)gridDim.x, edge, tile);
   const EdgeDev E = edges[edge];
@@ -4488,8 +4492,7 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
   const int M = E.M, N = E.N;
   const int x0 = tile * KDE_TX;
   if (x0 >= N) return;
-  constexpr int NC_ = KDE_TX + 8;
-  const int NC = NC_;
+  const int NC = KDE_TX + 8;
   const int ld = (KDE_H + 8) | 1;
   double* s_y = s_a + NC * ld;        // [KDE_NB][NC] staged points (-1: none)
   double* s_wt = s_y + KDE_NB * NC;   // [KDE_NB] staged weights
@@ -4562,30 +4565,21 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
     for (int r0 = y_lo; r0 <= y_hi; r0 += KDE_H) {
       const int nrow = (y_hi + 1 - r0) < KDE_H ? (y_hi + 1 - r0) : KDE_H;
       // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
-      if (single && form != 0) {
-        // All kept curves are staged (the usual case; option "kde_form" = 1, the default): clearing, conversion and the
-        // vertical pass touch ONE column at a time, so every wave takes three of the tile's 24 columns through them on
-        // its own -- LDS operations of a wave execute in order, no workgroup barrier between conversion, halo and sliding
-        // window, and the vertical pass runs on 63 lanes of every wave (round 3's form, kde_form = 0: every phase over
-        // the whole tile with a barrier after each -- eight per chunk --, the vertical pass on 240 of 512 threads).  Four
-        // barriers instead of eight per chunk buy 3 %: what the kernel waits for is its binning atomics and the gathers
-        // of the staged points, not its barriers.  The same sums in both forms: fixed-point binning is order-
-        // independent, the vertical taps are added in the same order.
-        const int lane = tid & 63, wv = tid >> 6;
-        constexpr int WC = NC_ / (KDE_THREADS / 64);  // columns per wave
-        static_assert(WC * (KDE_THREADS / 64) == NC_, "the tile's columns divide evenly over the waves");
-        const int cw0 = wv * WC;
-        double* colw = s_a + cw0 * ld;
-        for (int i = lane; i < WC * ld; i += 64) colw[i] = 0.0;
+      for (int i = tid; i < NC * ld; i += KDE_THREADS) s_a[i] = 0.0;
+      __syncthreads();
+      for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
+        const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
+        if (!single) {
+          int dl = 0, dh = 0;
+          __syncthreads();
+          stage(b0, nb, dl, dh);
+          __syncthreads();
+        }
+        // linear binning, one (curve, column) point per thread: 64-bit fixed-point LDS atomics, so the sums do
+        // not depend on the order the points arrive in (deterministic), at the resolution of f64 arithmetic
         unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_a);
-        const int lmax = nrow + 8, nbk = E.n_keep;
-        __syncthreads();
-        // linear binning by the whole workgroup, consecutive threads = the 24 columns of a curve: 64-bit fixed-point LDS
-        // atomics (order-independent sums).  (Binning per wave too -- its three columns only, no barrier at all before the
-        // horizontal pass -- puts ~21 curves of ONE column into a wave instruction, and the kept curves run within a few
-        // pixels of each other: the atomics of a wave hit a handful of addresses and serialise.  Measured at the same
-        // states: 0.90-0.92 ms per 1 024 edges against 0.85-0.88 for this form and 0.89-0.90 for round 3's.)
-        for (int e = tid; e < nbk * NC; e += KDE_THREADS) {
+        const int lmax = nrow + 8;
+        for (int e = tid; e < nb * NC; e += KDE_THREADS) {
           const double y = s_y[e];
           if (y < 0.0) continue;
           const int bb = e / NC, bc = e - bb * NC;
@@ -4599,107 +4593,38 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_fused(EdgeDev* edges, int r
           if (l >= 0) atomicAdd(&col[l], (unsigned long long)__double2ll_rn((1.0 - fy) * w));
           if (l + 1 < lmax) atomicAdd(&col[l + 1], (unsigned long long)__double2ll_rn(fy * w));
         }
-        __syncthreads();
-        for (int i = lane; i < WC * ld; i += 64)
-          colw[i] = (double)(long long)reinterpret_cast<unsigned long long*>(colw)[i] * finv;
-        __builtin_amdgcn_wave_barrier();
-        {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4; lane = (segment, column)
-          int nseg = 64 / WC;
-          if (nseg > nrow / 4) nseg = (nrow / 4 > 0) ? nrow / 4 : 1;
-          const int seg = lane / WC, c = lane - seg * WC;
-          const int R = (nrow + nseg - 1) / nseg;
-          const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
-          double* col = colw + c * ld;
-          double head[4], tail[4];
-          const bool active = (seg < nseg) && (q0 < nrow);
-          double w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;
-          if (active) {
+      }
+      __syncthreads();
+      for (int i = tid; i < NC * ld; i += KDE_THREADS)
+        s_a[i] = (double)(long long)reinterpret_cast<unsigned long long*>(s_a)[i] * finv;
+      __syncthreads();
+      {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
+        int nseg = KDE_THREADS / NC;
+        if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
+        const int seg = tid / NC, c = tid % NC;
+        const int R = (nrow + nseg - 1) / nseg;
+        const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
+        double* col = s_a + c * ld;
+        double head[4], tail[4];
+        const bool active = (seg < nseg) && (q0 < nrow);
+        if (active) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              head[t] = col[q0 + t];
-              tail[t] = col[q1 + 4 + t];
-            }
-            w4 = col[q0 + 4];
-            w5 = col[q0 + 5];
-            w6 = col[q0 + 6];
-            w7 = col[q0 + 7];
-          }
-          __builtin_amdgcn_wave_barrier();  // (every lane's halo is read before any lane writes: same instruction stream)
-          if (active) {
-            double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
-            for (int q = q0; q < q1; ++q) {
-              const int lnew = q + 8;
-              const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
-              const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
-                                 w7 * g[7] + w8 * g[8];
-              col[q + 4] = acc;
-              w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
-            }
-          }
-        }
-      } else {
-        // LDS row l <-> padded-grid row gy = r0 - 3 + l  (image row y sits at l = y - r0 + 4)
-        for (int i = tid; i < NC * ld; i += KDE_THREADS) s_a[i] = 0.0;
-        __syncthreads();
-        for (int b0 = 0; b0 < E.n_keep; b0 += KDE_NB) {
-          const int nb = (E.n_keep - b0) < KDE_NB ? (E.n_keep - b0) : KDE_NB;
-          if (!single) {
-            int dl = 0, dh = 0;
-            __syncthreads();
-            stage(b0, nb, dl, dh);
-            __syncthreads();
-          }
-          // linear binning, one (curve, column) point per thread: 64-bit fixed-point LDS atomics, so the sums do
-          // not depend on the order the points arrive in (deterministic), at the resolution of f64 arithmetic
-          unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_a);
-          const int lmax = nrow + 8;
-          for (int e = tid; e < nb * NC; e += KDE_THREADS) {
-            const double y = s_y[e];
-            if (y < 0.0) continue;
-            const int bb = e / NC, bc = e - bb * NC;
-            const double gy = y + 1.0;
-            const int iy = (int)floor(gy);
-            const int l = iy - (r0 - 3);
-            if (l + 1 < 0 || l >= lmax) continue;
-            const double w = s_wt[bb] * fscale;
-            const double fy = gy - (double)iy;
-            unsigned long long* col = s_bits + bc * ld;
-            if (l >= 0) atomicAdd(&col[l], (unsigned long long)__double2ll_rn((1.0 - fy) * w));
-            if (l + 1 < lmax) atomicAdd(&col[l + 1], (unsigned long long)__double2ll_rn(fy * w));
+          for (int t = 0; t < 4; ++t) {
+            head[t] = col[q0 + t];
+            tail[t] = col[q1 + 4 + t];
           }
         }
         __syncthreads();
-        for (int i = tid; i < NC * ld; i += KDE_THREADS)
-          s_a[i] = (double)(long long)reinterpret_cast<unsigned long long*>(s_a)[i] * finv;
-        __syncthreads();
-        {  // vertical pass in place: filtered value of chunk row q is written to LDS row q + 4
-          int nseg = KDE_THREADS / NC;
-          if (nseg > nrow / 12) nseg = (nrow / 12 > 0) ? nrow / 12 : 1;
-          const int seg = tid / NC, c = tid % NC;
-          const int R = (nrow + nseg - 1) / nseg;
-          const int q0 = seg * R, q1 = (q0 + R < nrow) ? (q0 + R) : nrow;
-          double* col = s_a + c * ld;
-          double head[4], tail[4];
-          const bool active = (seg < nseg) && (q0 < nrow);
-          if (active) {
-  #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              head[t] = col[q0 + t];
-              tail[t] = col[q1 + 4 + t];
-            }
-          }
-          __syncthreads();
-          if (active) {
-            double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
-            double w4 = col[q0 + 4], w5 = col[q0 + 5], w6 = col[q0 + 6], w7 = col[q0 + 7];
-            for (int q = q0; q < q1; ++q) {
-              const int lnew = q + 8;
-              const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
-              const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
-                                 w7 * g[7] + w8 * g[8];
-              col[q + 4] = acc;
-              w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
-            }
+        if (active) {
+          double w0 = head[0], w1 = head[1], w2 = head[2], w3 = head[3];
+          double w4 = col[q0 + 4], w5 = col[q0 + 5], w6 = col[q0 + 6], w7 = col[q0 + 7];
+          for (int q = q0; q < q1; ++q) {
+            const int lnew = q + 8;
+            const double w8 = (lnew >= q1 + 4) ? tail[lnew - (q1 + 4)] : col[lnew];
+            const double acc = w0 * g[0] + w1 * g[1] + w2 * g[2] + w3 * g[3] + w4 * g[4] + w5 * g[5] + w6 * g[6] +
+                               w7 * g[7] + w8 * g[8];
+            col[q + 4] = acc;
+            w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7; w7 = w8;
           }
         }
       }
@@ -6667,7 +6592,7 @@ hipError_t launch_kde(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& 
     const size_t lds = ((size_t)(KDE_TX + 8) * ((KDE_H + 8) | 1) + (size_t)KDE_NB * (KDE_TX + 8) + KDE_NB) * sizeof(double);
     if (parts & 1u) hipLaunchKernelGGL(k_kde_prep, dim3(1, B), dim3(1024), 0, st, d_edges);
     if (parts & 2u)
-      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band, option("kde_form"));
+      hipLaunchKernelGGL(k_kde_fused, dim3(cdiv(bd.N, KDE_TX), B), dim3(KDE_THREADS), lds, st, d_edges, raw_band);
     if ((parts & 4u) && !raw_band) hipLaunchKernelGGL(k_kde_normalise, dim3(64, B), dim3(256), 0, st, d_edges, mode);
     return hipGetLastError();
   }
