@@ -207,9 +207,10 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
   E.jb_norm = cv.take<double>(2);
   E.jlog = cv.take<double>(E.jlog_cap > 0 ? (size_t)E.jlog_cap * 2 * rc * (rc / 2 + 1) : 2);
-  E.A = cv.take<double>((size_t)E.a_rows_cap * Lg);
+  E.A = cv.take<double>((size_t)E.a_rows_cap * Lg + 64);  // (+ 64: the sample GEMM loads whole 64-column tiles of the last row)
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
-  E.Y = cv.take<double>(S * Lg);
+  E.Yp = (int)((Lg + 15) & ~(size_t)15);
+  E.Y = cv.take<double>((((S + 127) & ~(size_t)127) + 13) * (size_t)E.Yp);  // (+ the spare rows of the sample GEMM's idle lanes)
   E.costs = cv.take<double>(S);
   E.cost_part = cv.take<double>(S * 2 * (Lg / 30 + 2));  // (15 Simpson pairs = 30 columns per tile of the scorer)
   E.best_costs = cv.take<double>((size_t)E.n_keep + 1);
@@ -931,20 +932,20 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
     case GPET_BUF_FACTOR: src = E.A; avail = (size_t)s.rank * Lg * 8; break;
     case GPET_BUF_EIGVALS: src = E.theta; avail = (size_t)s.rank * 8; break;
     case GPET_BUF_NORMALS: src = E.Z + (size_t)(s.iter % E.z_ring) * E.S * E.z_cols; avail = (size_t)E.S * E.z_cols * 8; break;
-    case GPET_BUF_SAMPLES:
-      if (E.y_f32) {  // stored as f32 (gpet_batch_set_sample_dtype): the interface stays f64, widened here
-        const size_t cnt = (size_t)E.S * Lg;
-        if (bytes > cnt * 8) bytes = cnt * 8;
-        std::vector<float> tmp(cnt);
-        HIPCHK(c, hipMemcpyAsync(tmp.data(), E.Y, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, gpet_wait(c->stream));
-        double* o = (double*)dst;
-        for (size_t i = 0; i < bytes / 8; ++i) o[i] = (double)tmp[i];
-        return GPET_OK;
+    case GPET_BUF_SAMPLES: {
+      // rows of Yp elements on the device (f32 after gpet_batch_set_sample_dtype); the interface is a dense [S][Lg] f64 matrix
+      const size_t cnt = (size_t)E.S * Lg, pitch = (size_t)E.Yp, esz = E.y_f32 ? 4 : 8;
+      if (bytes > cnt * 8) bytes = cnt * 8;
+      std::vector<char> tmp((size_t)E.S * pitch * esz);
+      HIPCHK(c, hipMemcpyAsync(tmp.data(), E.Y, tmp.size(), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
+      double* o = (double*)dst;
+      for (size_t i = 0; i < bytes / 8; ++i) {
+        const size_t at = (i / Lg) * pitch + i % Lg;
+        o[i] = E.y_f32 ? (double)((const float*)tmp.data())[at] : ((const double*)tmp.data())[at];
       }
-      src = E.Y;
-      avail = (size_t)E.S * Lg * 8;
-      break;
+      return GPET_OK;
+    }
     case GPET_BUF_COSTS: src = E.costs; avail = (size_t)E.S * 8; break;
     case GPET_BUF_BEST_IDX: src = E.best_idx; avail = (size_t)E.n_keep * 4; break;
     case GPET_BUF_BEST_COSTS: src = E.best_costs; avail = (size_t)E.n_keep * 8; break;
@@ -1038,21 +1039,23 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
       b->have_normals = true;
       break;
     }
-    case GPET_BUF_SAMPLES:
+    case GPET_BUF_SAMPLES: {
       b->have_samples = true;
-      if (E.y_f32) {  // (rounded to f32 here, as the GEMM does when it stores)
-        const size_t cnt = (size_t)E.S * Lg;
-        if (bytes > cnt * 8) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cnt * 8);
-        std::vector<float> tmp(bytes / 8);
-        const double* in = (const double*)src;
-        for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)in[i];
-        HIPCHK(c, hipMemcpyAsync(E.Y, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, gpet_wait(c->stream));
-        return GPET_OK;
+      // (dense [S][Lg] f64 in, rows of Yp elements on the device; rounded to f32 here, as the GEMM does when it stores)
+      const size_t cnt = (size_t)E.S * Lg, pitch = (size_t)E.Yp, esz = E.y_f32 ? 4 : 8, nel = bytes / 8;
+      if (bytes > cnt * 8) return fail(c, GPET_ERR_BAD_ARG, "gpet_batch_write: %zu bytes exceed capacity %zu", bytes, cnt * 8);
+      const size_t full = nel / Lg, rest = nel % Lg;
+      std::vector<char> tmp((full * pitch + rest) * esz, 0);
+      const double* in = (const double*)src;
+      for (size_t i = 0; i < nel; ++i) {
+        const size_t at = (i / Lg) * pitch + i % Lg;
+        if (E.y_f32) ((float*)tmp.data())[at] = (float)in[i];
+        else ((double*)tmp.data())[at] = in[i];
       }
-      dst = E.Y;
-      cap = (size_t)E.S * Lg * 8;
-      break;
+      if (!tmp.empty()) HIPCHK(c, hipMemcpyAsync(E.Y, tmp.data(), tmp.size(), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, gpet_wait(c->stream));
+      return GPET_OK;
+    }
     case GPET_BUF_GRAD_KDE: dst = (void*)E.grad_kde; cap = px * 4; break;
     case GPET_BUF_KDE: dst = E.kde; cap = px * 4; break;
     case GPET_BUF_COSTS: dst = E.costs; cap = (size_t)E.S * 8; break;

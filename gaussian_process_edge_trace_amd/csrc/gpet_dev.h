@@ -70,7 +70,9 @@ struct EdgeDev {
   double* pcx_cand;      // [2][4 (Lg/32 + 1)][2] per-wave pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k
   double* Z;             // [z_ring][S*z_cols]; slot of iteration k = k % z_ring
-  double* Y;             // [S*Lg] samples, row = sample; f32 in the same buffer when y_f32 is set
+  double* Y;             // [S*Yp] samples (+ rows up to the next multiple of 128 and one spare row, never read), row = sample; f32 in the same buffer when y_f32 is set
+  int Yp;                // row pitch of Y in elements: Lg rounded up to 16 (128-byte rows of f64: every 128-byte run of the
+                         // GEMM's stores is one cache line -- at a pitch of Lg = 500 every other run straddled three)
   int y_f32;             // gpet_batch_set_sample_dtype: 1 = the GEMM stores f32, consumers widen (opt-in; default f64)
   double* costs;         // [S]
   double* cost_part;     // [n_tiles][S][2] per-column-tile partial (arc length, line integral) sums
