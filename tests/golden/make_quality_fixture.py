@@ -58,11 +58,6 @@ def _oracle_one(args):
     img, edge = orc.synth_sinusoid_image(500, img_seed)
     grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
     init = edge[[0, -1], :][:, [1, 0]]
-    if conv == 1:
-        # the library keeps the gradient image in HBM as float32: its rows are made on the image rounded the same way (one
-        # of the 480 traces -- image 3, seed 179463 -- takes another path on the float64 image); the LAPACK-sign rows stay
-        # on the float64 image, as the reference computes it
-        grad = grad.astype(np.float32).astype(np.float64)
     with threadpool_limits(limits=threads):
         et, _, info = orc.trace(init, grad, seed=seed, sign_convention="harmonic" if conv == 1 else None, **README)
     return (img_seed, seed, conv, info["n_iter"]) + _metrics(et, edge)

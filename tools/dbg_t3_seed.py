@@ -1,5 +1,6 @@
 """Where a device trace leaves the oracle's (same sign convention): first iteration whose observation set differs, and what
-differs in it -- costs, kept curves, KDE, pixels.  usage: python tools/dbg_t3_seed.py [img_seed] [rng_seed]"""
+differs in it -- costs, kept curves, KDE, pixels.  usage: python tools/dbg_t3_seed.py [img_seed] [rng_seed] [orc]
+(orc: both on the ORACLE's gradient image rounded to float32 -- the fixture's -- instead of the library's own)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +15,11 @@ L = amd._lib
 ctx = L.Context(0)
 img, truth = orc.synth_sinusoid_image(500, img_seed)
 grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+if len(sys.argv) > 3 and sys.argv[3] == "orc":
+    g2 = orc.comp_grad_img(img, orc.kernel_builder((11, 5))).astype(np.float32)
+    print("gradient images: library vs oracle rounded to float32: %d of %d pixels differ, max abs %.3g"
+          % (int(np.sum(np.asarray(grad) != g2)), g2.size, float(np.max(np.abs(np.asarray(grad, dtype=np.float64) - g2)))))
+    grad = g2
 init = truth[[0, -1], :][:, [1, 0]]
 rec = []
 et_o, _, info = orc.trace(init, grad, seed=seed, record=rec, sign_convention="harmonic", **README_KW)
