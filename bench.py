@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--size", type=int, default=500)
     ap.add_argument("--pipeline-depth", type=int, default=5,
                     help="whole traces in flight = depth + 1 batch objects, each driven by its own host thread on its own HIP stream (0 = one object, nothing overlapped)")
-    ap.add_argument("--cpu-traces", type=int, default=2)
+    ap.add_argument("--cpu-traces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ctor included, 256 edges, "
                     "distinct images, configs 3 and 5)")
@@ -660,10 +660,12 @@ def main():
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                     note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
                           "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_seat" else
-                          ("bound by the samples it stores (8 S Lg bytes per edge = 4.1 GB per launch): a kernel that ONLY stores them in the "
-                           "same row-tile shape takes 1.13-1.19 ms = 3.4-3.6 TB/s (profiles/r03_gemm_store_counters.txt, "
-                           "tools/ubench/hbm_write.hip) -- the one store-only ceiling, also quoted in DESIGN.md section 6; the matrix "
-                           "instructions alone 1.12 ms; this kernel overlaps the two to 1.8 ms" if dom == "k_sample_gemm_mfma_r" else
+                          ("bound by the samples it stores (8 S Lg bytes per edge = 4.1 GB per launch, rows padded to 128 bytes): a kernel "
+                           "that ONLY stores them in the same row-tile shape takes 1.13-1.19 ms = 3.4-3.6 TB/s "
+                           "(profiles/r03_gemm_store_counters.txt, tools/ubench/hbm_write.hip) -- the one store-only ceiling, also quoted in "
+                           "DESIGN.md section 6; the matrix instructions alone 1.12 ms; this kernel overlaps the two to 1.5 ms (1.8 in round "
+                           "3: line-aligned rows, 16-byte stores of column pairs, no wait for the stores anywhere in the loop)"
+                           if dom == "k_sample_gemm_mfma_r" else
                           ("numpy's RandomState(seed).standard_normal stream, bit for bit: MT19937 + polar method, every attempt of the "
                            "S x Lg stream decided, zc of Lg columns stored; vector-ALU bound (integer; the `valu` entry), not HBM or MFMA: "
                            "DESIGN.md section 6b; the sample GEMM (next in device time) is at %.2f of the f64 MFMA peak"

@@ -191,8 +191,11 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.cov = cv.take<double>(Lg * Lg);
   E.G = cv.take<double>(rc * Lg);
   E.perm = cv.take<int>(rc);
-  E.C = cv.take<double>(rc * rc);
+  E.C = cv.take<double>(rc * rc + 16);  // (+ 16: k_jacobi_prerot reads whole K steps of the last row)
   E.W = cv.take<double>(rc * rc);
+  E.Wq = cv.take<double>(4 * (rc * rc + 16));  // two slots x (eigenvectors, their transpose), each padded: k_jacobi_prerot reads whole K steps
+  E.Cw = cv.take<double>(rc * rc);
+  E.wq_tag = cv.take<int>(2);
   E.theta = cv.take<double>(rc);
   E.order = cv.take<int>(rc);
   E.Q0 = cv.take<double>(rc * Lg);
@@ -895,6 +898,7 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.done = (n_obs >= E.algo_thresh) ? 1 : 0;
   s.status = GPET_OK;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
+  HIPCHK(c, hipMemsetAsync(E.wq_tag, 0, 2 * sizeof(int), c->stream));  // (and forgets the last trace's eigenvectors)
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
   b->norm_issued = 0;
   if (b->structured)

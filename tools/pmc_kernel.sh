@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of one kernel of the per-iteration pipeline (run through gpurun from the repo root):
-#   tools/pmc_kernel.sh <kernel-name-substring> <python script + args ...>
+#   tools/pmc_kernel.sh <kernel-name-substring[,substring...]> <python script + args ...>
 # One counter group per rocprofv3 run (never together with a trace), program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -18,7 +18,7 @@ K = sys.argv[1]
 for f in sorted(glob.glob("gpurun_out/pmck/g*/*/*_counter_collection.csv")):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if K in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in K.split(",")):
             acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kn, c), v in sorted(acc.items()):
         print("%-42s %-32s last %.4g  (n=%d)" % (kn, c, v[-1], len(v)))
