@@ -191,9 +191,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.cov = cv.take<double>(Lg * Lg);
   E.G = cv.take<double>(rc * Lg);
   E.perm = cv.take<int>(rc);
-  E.C = cv.take<double>(rc * rc + 16);  // (+ 16: k_jacobi_prerot reads whole K steps of the last row)
+  E.C = cv.take<double>(rc * rc);
   E.W = cv.take<double>(rc * rc);
-  E.Wq = cv.take<double>(4 * (rc * rc + 16));  // two slots x (eigenvectors, their transpose), each padded: k_jacobi_prerot reads whole K steps
+  E.Wq = cv.take<double>(2 * rc * rc);
   E.Cw = cv.take<double>(rc * rc);
   E.wq_tag = cv.take<int>(2);
   E.theta = cv.take<double>(rc);

@@ -55,7 +55,7 @@ struct EdgeDev {
   double *C, *W, *theta; // [r_cap*r_cap], [r_cap*r_cap], [r_cap]
   // warm start of the structured path's eigen-decomposition (k_jacobi_prerot): the eigenvectors of iteration k are kept in
   // Wq[k & 1] with the tag (k + 1) + 65536 rank in wq_tag[k & 1] (0: nothing there); Cw = Wq^T C Wq of the previous ones
-  double *Wq, *Cw;       // [2 slots][W, W^T][r_cap*r_cap + 16], [r_cap*r_cap]
+  double *Wq, *Cw;       // [2 slots][r_cap*r_cap], [r_cap*r_cap]
   int* wq_tag;           // [2]
   int* order;            // [r_cap] eigenvalue order (descending)
   // prior eigenbasis of the unit-amplitude Toeplitz correlation matrix of the grid (structured loop path)
