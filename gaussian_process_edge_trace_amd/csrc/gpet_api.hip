@@ -201,7 +201,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.Q0 = cv.take<double>(rc * Lg);
   E.lam0 = cv.take<double>(rc);
   E.beta = cv.take<double>(rc);
-  E.row_part = cv.take<double>(rc * (Lg / 64 + 1));
+  E.h0 = cv.take<double>(rc);
   E.rho_tab = cv.take<double>((size_t)E.N);
   E.eig = cv.take<EigState>(1);
   E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);

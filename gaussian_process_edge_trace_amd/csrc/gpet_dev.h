@@ -62,7 +62,7 @@ struct EdgeDev {
   double* Q0;            // [r_cap*Lg] orthonormal rows q_a^T
   double* lam0;          // [r_cap] eigenvalues of rho
   double* beta;          // [r_cap] c * lam0 * Q0[:, obs] alpha
-  double* row_part;      // [r_cap][Lg/64 + 1] per-column-tile partial sums of the sign convention
+  double* h0;            // [r_cap] structured path: h0[t] = sum_j Q0[t][j] / (j + 1), the sign convention's weights in the prior eigenbasis
   int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
   double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
   double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
