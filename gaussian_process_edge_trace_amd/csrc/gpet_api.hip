@@ -205,6 +205,8 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.rho_tab = cv.take<double>((size_t)E.N);
   E.eig = cv.take<EigState>(1);
   E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);
+  E.Ap = cv.take<double>(rc > 96 ? 2 * Lg * rc : 1);
+  E.ap_tag = cv.take<int>(2);
   E.pcx_d = cv.take<double>(Lg);
   E.pcx_cand = cv.take<double>(16 * ((size_t)E.N / 32 + 2));  // (indexed with the widest edge of the batch)
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
@@ -899,6 +901,7 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.status = GPET_OK;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
   HIPCHK(c, hipMemsetAsync(E.wq_tag, 0, 2 * sizeof(int), c->stream));  // (and forgets the last trace's eigenvectors)
+  HIPCHK(c, hipMemsetAsync(E.ap_tag, 0, 2 * sizeof(int), c->stream));
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
   b->norm_issued = 0;
   if (b->structured)

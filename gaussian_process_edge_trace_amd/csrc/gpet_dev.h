@@ -17,6 +17,7 @@ struct EigState {
   unsigned int bar;                // k_oj_persist: pair slots FINISHED so far (all rounds and sweeps of this factorisation), monotonic
   unsigned int ticket;             // k_oj_persist: pair slots HANDED OUT so far (a workgroup takes the next one when it has finished its last)
   int verdicts;                    // k_oj_persist: sweeps whose convergence verdict has been published
+  int warm;                        // warm start (k_ojw_*): 0 = cold (pivoted Cholesky), 1 = the rows come from the previous iteration's, 2 = tried and failed
   int t_slot[2], stop_slot[2];     // blocked pivoting: rows so far / finished, as block (blk & 1) must see them -- a block
                                    // writes the OTHER slot, so workgroups of one launch never read what it writes
 };
@@ -70,6 +71,8 @@ struct EdgeDev {
   int jlog_cap;          // sweeps the log holds (0: none)
   EigState* eig;         // state of the any-rank factorisation
   double* Gt;            // [Lg][r_cap] transposed copy of G kept by the multi-workgroup pivoted Cholesky (ranks > 96 only)
+  double* Ap;            // [2][r_cap*Lg] (ranks > 96 only) the factor rows of the last two iterations: slot k & 1 = iteration k's, the warm start of k + 1
+  int* ap_tag;           // [2] iteration + 1 of the rows in the slot when they are of full rank (0: nothing usable)
   double* pcx_d;         // [Lg] remaining diagonal of the multi-workgroup pivoted Cholesky (-1: pivoted)
   double* pcx_cand;      // [2][4 (Lg/32 + 1)][2] per-wave pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k

@@ -492,6 +492,7 @@ __global__ void __launch_bounds__(64) k_pcb_init(EdgeDev* edges, int nw_max) {
     st->ticket = 0u;
     st->verdicts = 0;
     st->cand_half = 0;
+    st->warm = 0;
     st->t_slot[0] = 0;
     st->stop_slot[0] = 0;
     st->t_slot[1] = 0;
@@ -552,6 +553,235 @@ __global__ void __launch_bounds__(64) k_pcx_fin(EdgeDev* edges, int steps, int n
     }
   }
   sc->rank = st->rank;
+}
+
+
+// ---- 1b. warm start: rows that are nearly orthogonal before the first rotation ----------------------------------------------
+// The posterior covariance of an iteration differs from the last one's by the few observations the iteration added.  With
+// the previous factor rows A (A^T A = Sigma_prev, rows orthogonal, |A_k|^2 = s_k) the matrix M' = A Sigma A^T is close to
+// diag(s_k^2), its Cholesky factor L' (M' = L' L'^T) close to diagonal, and
+//       X = L'^T diag(1 / s_k) A        satisfies        X^T X = A^T S^-1 (A Sigma A^T) S^-1 A = Sigma
+// (A^T S^-1 A = I for rows of full rank) with rows that are ALREADY nearly orthogonal: the one-sided Jacobi then needs about
+// half the sweeps the pivoted-Cholesky rows need (tests/analysis/onesided_warm_start.py: 10 -> 5 at 256 columns).  Three
+// products on the f64 matrix cores (k_ojw_gemm: 64 x 64 tiles, K in chunks of 32 through LDS), a blocked Cholesky
+// (k_ojw_chol_*: 64-wide panels), one copy.  Only for rows of full rank (Matern); a non-positive pivot falls back to the
+// pivoted Cholesky, whose launches are no-ops otherwise.  T = A Sigma lives in Gt, M' and L' in G, X in Gt and then G.
+int& gpet_opt_oj_warm() {
+  static int& v = option("oj_warm");
+  return v;
+}
+__device__ __forceinline__ const double* ojw_source(const EdgeDev& E, int warm) {
+  const gpet_scalars* sc = E.sc;
+  const int k = sc->iter;
+  if (!warm || k < 1 || E.Lg > E.r_cap) return nullptr;
+  const int slot = (k - 1) & 1;
+  if (E.ap_tag[slot] != k) return nullptr;
+  return E.Ap + (size_t)slot * E.r_cap * E.Lg;
+}
+// 1 / |A_k|^2 into theta, and the decision (after k_pcb_init / k_pcx_init, which reset the state)
+__global__ void __launch_bounds__(256) k_ojw_begin(EdgeDev* edges, int warm) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (eig_skip(E)) return;
+  const double* Ap = ojw_source(E, warm);
+  if (!Ap) return;
+  const int Lg = E.Lg, k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) E.eig->warm = 1;
+  if (k >= Lg) return;
+  const double* __restrict__ row = Ap + (size_t)k * Lg;
+  double s = 0.0;
+  for (int j = lane; j < Lg; j += WAVE) s += row[j] * row[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+  if (lane == 0) E.theta[k] = s > 0.0 ? 1.0 / s : 0.0;
+}
+// MODE 0: T = A Sigma (into Gt)   1: M' = T A^T (lower tiles, into G)   2: X = (diag(1 / s) L')^T A, L' the lower triangle of G (into Gt)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_ojw_gemm(EdgeDev* edges, int warm) {
+  const EdgeDev E = edges[blockIdx.z];
+  if (eig_skip(E) || E.eig->warm != 1) return;
+  const double* __restrict__ Ap = ojw_source(E, warm);
+  if (!Ap) return;
+  const int n = E.Lg;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (i0 >= n || j0 >= n) return;
+  if (MODE == 1 && j0 > i0) return;
+  const double* __restrict__ Am = MODE == 0 ? Ap : (MODE == 1 ? E.Gt : E.G);
+  const double* __restrict__ Bm = MODE == 0 ? E.cov : Ap;
+  double* __restrict__ Cm = MODE == 1 ? E.G : E.Gt;
+  const double* __restrict__ inv_s = E.theta;
+  __shared__ double sA[64][33];  // [row of C][k]
+  __shared__ double sB[32][65];  // [k][column of C]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64e acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = (MODE == 2 ? i0 : 0); k0 < n; k0 += 32) {
+    double va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u;
+      if (MODE == 2) {  // A(i, l) = L'[l][i] / s_l for l >= i
+        const int kk = e >> 6, ss = e & 63, l = k0 + kk, i = i0 + ss;
+        va[u] = (l < n && i < n && l >= i) ? Am[(size_t)l * n + i] * inv_s[l] : 0.0;
+      } else {
+        const int ss = e >> 5, kk = e & 31, i = i0 + ss, k = k0 + kk;
+        va[u] = (i < n && k < n) ? Am[(size_t)i * n + k] : 0.0;
+      }
+      if (MODE == 1) {  // B(k, j) = A[j][k]
+        const int jj = e >> 5, kk = e & 31, j = j0 + jj, k = k0 + kk;
+        vb[u] = (j < n && k < n) ? Bm[(size_t)j * n + k] : 0.0;
+      } else {
+        const int kk = e >> 6, jj = e & 63, j = j0 + jj, k = k0 + kk;
+        vb[u] = (j < n && k < n) ? Bm[(size_t)k * n + j] : 0.0;
+      }
+    }
+    __syncthreads();  // (the previous chunk's operands have been read)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u;
+      if (MODE == 2) sA[e & 63][e >> 6] = va[u];
+      else sA[e >> 5][e & 31] = va[u];
+      if (MODE == 1) sB[e & 31][e >> 5] = vb[u];
+      else sB[e >> 6][e & 63] = vb[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+      const double a = sA[16 * w + li][kk + lq];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sB[kk + lq][16 * t + li], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = i0 + 16 * w + lq + 4 * g, j = j0 + 16 * t + li;
+      if (i < n && j < n) Cm[(size_t)i * n + j] = acc[t][g];
+    }
+}
+// blocked Cholesky of the lower triangle of G (n x n, row stride n), 64-wide panels: diagonal block, rows below it, trailing update
+__global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (eig_skip(E) || E.eig->warm != 1) return;
+  const int n = E.Lg;
+  if (k0 >= n) return;
+  const int nb = n - k0 < 64 ? n - k0 : 64;
+  __shared__ double sD[64][65];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  double* __restrict__ K = E.G;
+  if (tid == 0) s_bad = 0;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    sD[i][j] = (i < nb && j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < nb; ++c) {
+    const double piv = sD[c][c];
+    if (!(piv > 0.0)) {  // (uniform: every thread reads the same value)
+      if (tid == 0) s_bad = 1;
+      break;
+    }
+    const double d = sqrt(piv), inv = 1.0 / d;
+    __syncthreads();  // (everybody has read the pivot)
+    if (tid == 0) sD[c][c] = d;
+    for (int r = c + 1 + tid; r < nb; r += 256) sD[r][c] *= inv;
+    __syncthreads();
+    // trailing update of the lower triangle: element (r, cc), c < cc <= r
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, cc = e & 63;
+      if (r < nb && cc > c && cc <= r) sD[r][cc] -= sD[r][c] * sD[cc][c];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (tid == 0) E.eig->warm = 2;  // not positive definite to rounding: the pivoted Cholesky takes over
+    return;
+  }
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    if (i < nb && j <= i) K[(size_t)(k0 + i) * n + k0 + j] = sD[i][j];
+  }
+}
+__global__ void __launch_bounds__(64) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (eig_skip(E) || E.eig->warm != 1) return;
+  const int n = E.Lg;
+  const int i0 = k0 + 64 * ((int)blockIdx.x + 1);
+  if (i0 >= n) return;
+  __shared__ double sL[64][65];
+  __shared__ double sX[64][65];
+  const int tid = threadIdx.x;
+  double* __restrict__ K = E.G;
+  for (int e = tid; e < 64 * 64; e += 64) {
+    const int i = e >> 6, j = e & 63;
+    sL[i][j] = (j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    sX[i][j] = (i0 + i < n) ? K[(size_t)(i0 + i) * n + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  // row tid: x L_kk^T = a  (forward substitution over the 64 columns)
+  for (int c = 0; c < 64; ++c) {
+    double v = sX[tid][c];
+    for (int m = 0; m < c; ++m) v -= sX[tid][m] * sL[c][m];
+    sX[tid][c] = v / sL[c][c];
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 64) {
+    const int i = e >> 6, j = e & 63;
+    if (i0 + i < n) K[(size_t)(i0 + i) * n + k0 + j] = sX[i][j];
+  }
+}
+__global__ void __launch_bounds__(256) k_ojw_chol_syrk(EdgeDev* edges, int k0) {
+  const EdgeDev E = edges[blockIdx.z];
+  if (eig_skip(E) || E.eig->warm != 1) return;
+  const int n = E.Lg;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int i0 = k0 + 64 * (bi + 1), j0 = k0 + 64 * (bj + 1);
+  if (i0 >= n) return;
+  __shared__ double sI[64][65];
+  __shared__ double sJ[64][65];
+  const int tid = threadIdx.x;
+  double* __restrict__ K = E.G;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    sI[i][j] = (i0 + i < n) ? K[(size_t)(i0 + i) * n + k0 + j] : 0.0;
+    sJ[i][j] = (j0 + i < n) ? K[(size_t)(j0 + i) * n + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  v4f64e acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 64; kk += 4) {
+    const double a = sI[16 * w + li][kk + lq];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sJ[16 * t + li][kk + lq], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = i0 + 16 * w + lq + 4 * g, j = j0 + 16 * t + li;
+      if (i < n && j <= i) K[(size_t)i * n + j] -= acc[t][g];
+    }
+}
+// X (in Gt) becomes the rows G the Jacobi works on; the pivoted Cholesky's launches see "finished"
+__global__ void __launch_bounds__(256) k_ojw_commit(EdgeDev* edges) {
+  const EdgeDev E = edges[blockIdx.y];
+  if (eig_skip(E) || E.eig->warm != 1) return;
+  const size_t cnt = (size_t)E.Lg * E.Lg;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < cnt; e += (size_t)gridDim.x * 256) E.G[e] = E.Gt[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    EigState* st = E.eig;
+    st->rank = E.Lg;
+    st->t_slot[0] = st->t_slot[1] = E.Lg;
+    st->stop_slot[0] = st->stop_slot[1] = 1;
+    st->stopped = 1;
+  }
 }
 
 // ---- 2. one-sided block Jacobi on the rows of G --------------------------------------------------------------------
@@ -1154,11 +1384,40 @@ __global__ void __launch_bounds__(256) k_oj_rows(EdgeDev* edges) {
   const double dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   const double sg = dot < 0.0 ? -1.0 : 1.0;
   double* __restrict__ dst = E.A + (size_t)k * Lg;
-  for (int j = threadIdx.x; j < Lg; j += 256) dst[j] = sg * src[j];
+  // (and into this iteration's slot of the ring the next iteration's warm start reads -- rows of full rank only)
+  const bool keep = r == Lg && Lg <= E.r_cap;
+  double* __restrict__ dst2 = E.Ap + ((size_t)(E.sc->iter & 1) * E.r_cap + k) * Lg;
+  for (int j = threadIdx.x; j < Lg; j += 256) {
+    const double v = sg * src[j];
+    dst[j] = v;
+    if (keep) dst2[j] = v;
+  }
+  if (k == 0 && threadIdx.x == 0) E.ap_tag[E.sc->iter & 1] = keep ? E.sc->iter + 1 : 0;
 }
 
 // Enqueues the whole factorisation.  Nothing is read back: a fixed budget of pivot steps and sweeps is launched and
 // the kernels turn into no-ops once the device-side tests (tolerance reached / converged) have fired.
+// the warm start's launches (after the pivoted Cholesky's init kernel, before its blocks): no-ops for an edge without
+// usable previous rows
+static void launch_oj_warm(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  const int warm = gpet_opt_oj_warm();
+  if (!warm || bd.Lg > bd.r_cap) return;
+  const int n = bd.Lg, nt = cdiv_h(n, 64);
+  hipLaunchKernelGGL(k_ojw_begin, dim3(cdiv_h(n, 4), B), dim3(256), 0, st, d_edges, warm);
+  hipLaunchKernelGGL(k_ojw_gemm<0>, dim3(nt, nt, B), dim3(256), 0, st, d_edges, warm);
+  hipLaunchKernelGGL(k_ojw_gemm<1>, dim3(nt, nt, B), dim3(256), 0, st, d_edges, warm);
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    hipLaunchKernelGGL(k_ojw_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0);
+    const int below = cdiv_h(n - k0 - 64, 64);
+    if (below > 0) {
+      hipLaunchKernelGGL(k_ojw_chol_trsm, dim3(below, B), dim3(64), 0, st, d_edges, k0);
+      hipLaunchKernelGGL(k_ojw_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0);
+    }
+  }
+  hipLaunchKernelGGL(k_ojw_gemm<2>, dim3(nt, nt, B), dim3(256), 0, st, d_edges, warm);
+  hipLaunchKernelGGL(k_ojw_commit, dim3(256, B), dim3(256), 0, st, d_edges);
+}
+
 hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const EdgeDev* h_edges) {
   (void)hipGetLastError();
   // small batches: the per-edge pointers travel in the kernel arguments (h_edges = host copy of the edge table)
@@ -1200,6 +1459,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     // blocks of up to PCB_NB pivots; rejected candidates cost extra blocks, so the budget is generous (a block that
     // finds the factorisation finished returns at once)
     hipLaunchKernelGGL(k_pcb_init, dim3(nw, B), dim3(64), 0, st, d_edges, nw);
+    launch_oj_warm(st, d_edges, B, bd);
     const int per_block = nw < PCB_NB ? nw : PCB_NB;  // (one candidate per 32-column workgroup: narrow edges offer fewer)
     const int nblocks = 2 * cdiv_h(steps, per_block) + 8;
     for (int blk = 0; blk < nblocks; ++blk) {
