@@ -230,6 +230,19 @@ def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
     one1._batch.factor()
     fac1 = one1._batch.profile_stage(1, 2)
     one1._batch.close()
+
+    # ... and the factor as every iteration but a trace's first runs it: three iterations into a trace, the covariance of the
+    # current observation set, the previous iteration's rows in the ring (warm start, option oj_warm)
+    def warm_factor(nb):
+        bt_ = pkg.GP_Edge_Tracing_Batch([init] * nb, frames[:nb], [3] * nb, _ctx=ctx, **kw)
+        bt_._batch.iterate([3] * nb, 3)
+        bt_._batch.profile_stage(0, 1)
+        ms_ = bt_._batch.profile_stage(1, 2)
+        sw_ = int(bt_._batch.scalars().lml)
+        bt_._batch.close()
+        return ms_, sw_
+    fac_w, sweeps_w = warm_factor(n_chains)
+    fac1_w, _ = warm_factor(1)
     one = pkg.SequenceTracer(frames[:2], init, n_chains=1, warm_every=16, seed=3, _ctx=ctx, **kw)
     t1 = time.time()
     one()
@@ -257,7 +270,10 @@ def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
                 per_gpu_share_note="config 5 on 8 GPUs as stated is one chain of %d frames per GPU; the prediction is this GPU's time for all "
                                    "%d frames over its time for that share alone (no collective on the path); with 16 chains of %d frames a GPU "
                                    "holds two edges per step" % (frames_per_chain, T, half),
-                factor_ms_batch_of_chains=fac, factor_ms_single_edge=fac1, factor_jacobi_sweeps=sweeps, chains=n_chains)
+                factor_ms_batch_of_chains=fac, factor_ms_single_edge=fac1, factor_jacobi_sweeps=sweeps,
+                factor_ms_batch_of_chains_warm=fac_w, factor_ms_single_edge_warm=fac1_w, factor_jacobi_sweeps_warm=sweeps_w,
+                factor_note="cold: the first iteration of a trace (pivoted Cholesky rows); warm: every later iteration (rows from the "
+                            "previous iteration's factor, k_ojw_*)", chains=n_chains)
 
 
 def main():
