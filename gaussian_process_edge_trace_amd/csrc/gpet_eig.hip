@@ -688,10 +688,13 @@ __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0) {
     if (tid == 0) sD[c][c] = d;
     for (int r = c + 1 + tid; r < nb; r += 256) sD[r][c] *= inv;
     __syncthreads();
-    // trailing update of the lower triangle: element (r, cc), c < cc <= r
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int r = e >> 6, cc = e & 63;
-      if (r < nb && cc > c && cc <= r) sD[r][cc] -= sD[r][c] * sD[cc][c];
+    // trailing update of the remaining lower triangle: element (r, cc), c < cc <= r < nb
+    {
+      const int wdt = nb - c - 1;
+      for (int e = tid; e < wdt * wdt; e += 256) {
+        const int r = c + 1 + e / wdt, cc = c + 1 + e % wdt;
+        if (cc <= r) sD[r][cc] -= sD[r][c] * sD[cc][c];
+      }
     }
     __syncthreads();
   }
@@ -705,7 +708,7 @@ __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0) {
     if (i < nb && j <= i) K[(size_t)(k0 + i) * n + k0 + j] = sD[i][j];
   }
 }
-__global__ void __launch_bounds__(64) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
+__global__ void __launch_bounds__(256) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E) || E.eig->warm != 1) return;
   const int n = E.Lg;
@@ -715,20 +718,25 @@ __global__ void __launch_bounds__(64) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
   __shared__ double sX[64][65];
   const int tid = threadIdx.x;
   double* __restrict__ K = E.G;
-  for (int e = tid; e < 64 * 64; e += 64) {
+  for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
     sL[i][j] = (j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : 0.0;
     sX[i][j] = (i0 + i < n) ? K[(size_t)(i0 + i) * n + k0 + j] : 0.0;
   }
   __syncthreads();
-  // row tid: x L_kk^T = a  (forward substitution over the 64 columns)
+  // X L_kk^T = A by columns: column c of X is final once it is divided by L[c][c]; it then leaves every later column
+  // (64 rows x (63 - c) columns of independent updates over the 256 threads; a row at a time per thread was 65 us a block)
   for (int c = 0; c < 64; ++c) {
-    double v = sX[tid][c];
-    for (int m = 0; m < c; ++m) v -= sX[tid][m] * sL[c][m];
-    sX[tid][c] = v / sL[c][c];
+    if (tid < 64) sX[tid][c] = sX[tid][c] / sL[c][c];
+    __syncthreads();
+    const int wdt = 63 - c;
+    for (int e = tid; e < 64 * wdt; e += 256) {
+      const int r = e / wdt, cc = c + 1 + e % wdt;
+      sX[r][cc] -= sX[r][c] * sL[cc][c];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int e = tid; e < 64 * 64; e += 64) {
+  for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
     if (i0 + i < n) K[(size_t)(i0 + i) * n + k0 + j] = sX[i][j];
   }
@@ -1352,19 +1360,25 @@ __global__ void __launch_bounds__(256) k_oj_norms(EdgeDev* edges) {
   if (lane == 0) E.theta[k] = s;
 }
 
-__global__ void __launch_bounds__(1024) k_oj_order(EdgeDev* edges) {
+__global__ void __launch_bounds__(256) k_oj_order(EdgeDev* edges) {  // (256 ranks per workgroup: one workgroup for all of them took 0.11 ms at 1 024 rows)
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E)) return;
   const int r = E.eig->rank;
-  for (int k = threadIdx.x; k < r; k += blockDim.x) {
-    const double v = E.theta[k];
-    int pos = 0;
-    for (int j = 0; j < r; ++j) {
-      const double u = E.theta[j];
-      pos += (u > v) || (u == v && j < k);
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double s_th[256];
+  const double v = k < r ? E.theta[k] : 0.0;
+  int pos = 0;
+  for (int j0 = 0; j0 < r; j0 += 256) {
+    __syncthreads();
+    s_th[threadIdx.x] = (j0 + (int)threadIdx.x < r) ? E.theta[j0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int lim = r - j0 < 256 ? r - j0 : 256;
+    for (int jj = 0; jj < lim; ++jj) {
+      const double u = s_th[jj];
+      pos += (u > v) || (u == v && j0 + jj < k);
     }
-    E.order[pos] = k;
   }
+  if (k < r) E.order[pos] = k;
 }
 
 // A[k, :] = +-G[order[k], :], sign convention sum_j A[k, j] / (j + 1) >= 0 (LAPACK's signs are implementation-defined)
@@ -1410,7 +1424,7 @@ static void launch_oj_warm(hipStream_t st, EdgeDev* d_edges, int B, const BatchD
     hipLaunchKernelGGL(k_ojw_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0);
     const int below = cdiv_h(n - k0 - 64, 64);
     if (below > 0) {
-      hipLaunchKernelGGL(k_ojw_chol_trsm, dim3(below, B), dim3(64), 0, st, d_edges, k0);
+      hipLaunchKernelGGL(k_ojw_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);
       hipLaunchKernelGGL(k_ojw_chol_syrk, dim3(below, below, B), dim3(256), 0, st, d_edges, k0);
     }
   }
@@ -1529,7 +1543,7 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     hipLaunchKernelGGL(k_oj_check, dim3(B), dim3(64), 0, st, d_edges, tol2);
   }
   hipLaunchKernelGGL(k_oj_norms, dim3(cdiv_h(steps, 4), B), dim3(256), 0, st, d_edges);
-  hipLaunchKernelGGL(k_oj_order, dim3(1, B), dim3(1024), 0, st, d_edges);
+  hipLaunchKernelGGL(k_oj_order, dim3(cdiv_h(steps, 256), B), dim3(256), 0, st, d_edges);
   hipLaunchKernelGGL(k_oj_rows, dim3(steps, B), dim3(256), 0, st, d_edges);
   return hipGetLastError();
 }
