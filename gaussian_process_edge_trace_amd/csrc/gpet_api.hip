@@ -206,7 +206,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.eig = cv.take<EigState>(1);
   E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);
   E.Ap = cv.take<double>(rc > 96 ? 2 * Lg * rc : 1);
-  E.ap_tag = cv.take<int>(2);
+  E.ap_tag = cv.take<int>(3);
   E.pcx_d = cv.take<double>(Lg);
   E.pcx_cand = cv.take<double>(16 * ((size_t)E.N / 32 + 2));  // (indexed with the widest edge of the batch)
   E.jb_cs = cv.take<double>(2 * (rc / 2 + 1) + 2 * 64);  // (+ 64 partial norm pairs of k_jb_norms)
@@ -881,6 +881,26 @@ static int check_device_status(gpet_batch* b) {
   return GPET_OK;
 }
 
+// The any-rank factor's rows of the trace that ends here stay usable as the FIRST warm start of the next one (a sequence's
+// next frame: the same chain, a similar covariance; option oj_warm = 2): they are in slot (iters_done - 1) & 1 of the ring if
+// its tag says "iteration iters_done - 1, full rank".  Tags of the ring itself are cleared.
+static int carry_factor_rows(gpet_batch* b, int e, int iters_done) {
+  gpet_ctx* c = b->ctx;
+  const EdgeDev& E = b->h_edges[e];
+  if (E.r_cap <= 96 || iters_done < 1) {
+    HIPCHK(c, hipMemsetAsync(E.ap_tag, 0, 3 * sizeof(int), c->stream));
+    return GPET_OK;
+  }
+  int tags[3] = {0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(tags, E.ap_tag, sizeof tags, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
+  const int slot = (iters_done - 1) & 1;
+  const int fresh[3] = {0, 0, tags[slot] == iters_done ? slot + 1 : 0};
+  HIPCHK(c, hipMemcpyAsync(E.ap_tag, fresh, sizeof fresh, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
+  return GPET_OK;
+}
+
 int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   if (!b || e < 0 || e >= b->B || n_obs < 0 || (n_obs > 0 && !obs_xy)) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -899,9 +919,13 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   s.n_obs = n_obs;
   s.done = (n_obs >= E.algo_thresh) ? 1 : 0;
   s.status = GPET_OK;
+  const int iters_done = s.iter;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
   HIPCHK(c, hipMemsetAsync(E.wq_tag, 0, 2 * sizeof(int), c->stream));  // (and forgets the last trace's eigenvectors)
-  HIPCHK(c, hipMemsetAsync(E.ap_tag, 0, 2 * sizeof(int), c->stream));
+  if (iters_done >= 1) {  // (0: gpet_batch_reset has been here already)
+    int rc3 = carry_factor_rows(b, e, iters_done);
+    if (rc3) return rc3;
+  }
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
   b->norm_issued = 0;
   if (b->structured)
@@ -1237,6 +1261,14 @@ int gpet_batch_reset(gpet_batch* b) {
   b->iters_issued = 0;
   b->norm_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));
+  if (b->bd.r_cap > 96) {  // (any-rank batches: where every edge's last factor rows are, before the iteration counters go)
+    int rc = fetch_all_scalars(b);
+    if (rc) return rc;
+    for (int e = 0; e < b->B; ++e) {
+      rc = carry_factor_rows(b, e, b->h_scalars[e].iter);
+      if (rc) return rc;
+    }
+  }
   for (int e = 0; e < b->B; ++e) {
     gpet_scalars& s0 = b->h_scalars[e];
     memset(&s0, 0, sizeof s0);

@@ -72,7 +72,8 @@ struct EdgeDev {
   EigState* eig;         // state of the any-rank factorisation
   double* Gt;            // [Lg][r_cap] transposed copy of G kept by the multi-workgroup pivoted Cholesky (ranks > 96 only)
   double* Ap;            // [2][r_cap*Lg] (ranks > 96 only) the factor rows of the last two iterations: slot k & 1 = iteration k's, the warm start of k + 1
-  int* ap_tag;           // [2] iteration + 1 of the rows in the slot when they are of full rank (0: nothing usable)
+  int* ap_tag;           // [3] [0..1]: iteration + 1 of the rows in the slot when they are of full rank (0: nothing usable);
+                         // [2]: 1 + the slot that holds the LAST trace's final rows (set by gpet_batch_set_obs: the first factor of the next trace starts from them)
   double* pcx_d;         // [Lg] remaining diagonal of the multi-workgroup pivoted Cholesky (-1: pivoted)
   double* pcx_cand;      // [2][4 (Lg/32 + 1)][2] per-wave pivot candidates (value, index) of the current / next step
   double* A;             // [a_rows_cap*Lg] factor rows sqrt(s_k) v_k

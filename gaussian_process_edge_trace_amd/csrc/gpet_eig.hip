@@ -573,7 +573,11 @@ int& gpet_opt_oj_warm() {
 __device__ __forceinline__ const double* ojw_source(const EdgeDev& E, int warm) {
   const gpet_scalars* sc = E.sc;
   const int k = sc->iter;
-  if (!warm || k < 1 || E.Lg > E.r_cap) return nullptr;
+  if (!warm || E.Lg > E.r_cap) return nullptr;
+  if (k < 1) {  // a trace's first factor: the previous trace's last rows, if gpet_batch_set_obs found them usable (oj_warm = 2)
+    const int carry = E.ap_tag[2];
+    return (warm >= 2 && carry > 0) ? E.Ap + (size_t)(carry - 1) * E.r_cap * E.Lg : nullptr;
+  }
   const int slot = (k - 1) & 1;
   if (E.ap_tag[slot] != k) return nullptr;
   return E.Ap + (size_t)slot * E.r_cap * E.Lg;
