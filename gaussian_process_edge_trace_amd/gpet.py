@@ -390,7 +390,9 @@ class GP_Edge_Tracing_Batch(object):
                 self._batch.set_obs(e, p["obs"])
 
     def reset(self):
-        """Back to the state right after construction (the warm-start observations included)."""
+        """Back to the state right after construction (the warm-start observations included).  (An any-rank -- Matern --
+        batch keeps its last factor rows as the starting point of the next trace's first factorisation, library option
+        ``oj_warm`` = 2: the factor is an iterative solve, its result does not depend on the start beyond its tolerance.)"""
         self._batch.reset()
         self._set_obs()
 
