@@ -376,3 +376,86 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
                 L.set_option("jacobi_variant", old)
         for a, b_ in zip(traces[0], traces[1]):
             assert np.array_equal(a, b_)
+
+
+def test_structured_loop_warm_started_eigen_decomposition(amd, ctx):
+    """Option jacobi_warm (k_jacobi_prerot): from the second iteration on the eigen-decomposition of the structured path
+    starts from the previous iteration's eigenvectors.  Same traces as the cold start (the factor is the same matrix's, to
+    rounding), fewer Jacobi sweeps, and repeated launches on a fixed state read a slot they do not write."""
+    L = amd._lib
+    img, truth = orc.synth_sinusoid_image(160, 2)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 30, 'length_scale': 8}, noise_y=1, N_samples=256, score_thresh=1,
+              delta_x=5, keep_ratio=0.1, pixel_thresh=4, fix_endpoints=True)
+    E = 40  # (above jlog_max_b: the LDS form of W; 4 edges below: the rotation log + k_jacobi_wpass)
+    for nb in (E, 4):
+        seeds = [5 + 997 * k for k in range(nb)]
+        res = {}
+        for warm in (0, 1):
+            old = L.set_option("jacobi_warm", warm)
+            try:
+                bt = amd.GP_Edge_Tracing_Batch([init] * nb, grad, seeds, **kw, _ctx=ctx)
+                assert bt._batch.info()["structured"] == 1
+                bt._batch.iterate(seeds, 3)
+                sweeps = [int(bt._batch.scalars(e).lml) for e in range(nb)]
+                f1 = np.array(bt._batch.read(L.BUF_FACTOR, 0))
+                # the factor stage again on the same state: now from the eigenvectors iteration 2 left (slot 0 of the ring;
+                # these launches write slot 1): the same matrix's factor, and every repetition the same bits
+                bt._batch.profile_stage(1, 1)
+                f2 = np.array(bt._batch.read(L.BUF_FACTOR, 0))
+                bt._batch.profile_stage(1, 2)
+                f3 = np.array(bt._batch.read(L.BUF_FACTOR, 0))
+                bt._batch.close()
+                traces = amd.GP_Edge_Tracing_Batch([init] * nb, grad, seeds, **kw, _ctx=ctx)()
+            finally:
+                L.set_option("jacobi_warm", old)
+            assert np.array_equal(f2, f3)
+            assert np.max(np.abs(f1 - f2)) <= 1e-7 * np.max(np.abs(f1))
+            res[warm] = (sweeps, f1, traces)
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+        assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-7 * np.max(np.abs(res[0][1]))
+        assert np.mean(res[1][0]) < np.mean(res[0][0]), (res[0][0], res[1][0])
+
+
+def test_any_rank_factor_warm_start(amd, ctx):
+    """Option oj_warm (k_ojw_*): from the second iteration on the one-sided Jacobi of a full-rank (Matern) covariance starts
+    from rows built out of the previous iteration's factor instead of a pivoted Cholesky factor.  A^T A = Sigma to rounding
+    either way, rows within the solver's tolerance of the cold start's, the same observation sets, fewer sweeps; with
+    oj_warm = 2 the first factor after gpet_batch_reset starts from the last trace's rows."""
+    L = amd._lib
+    N = 256
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=200, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    res = {}
+    for warm in (0, 1, 2):
+        old = L.set_option("oj_warm", warm)
+        try:
+            bt = amd.GP_Edge_Tracing_Batch([init] * 2, grad, [3, 4], **kw, _ctx=ctx)
+            b = bt._batch
+            b.iterate([3, 4], 3)
+            b.profile_stage(0, 1)  # covariance of the current observation set
+            b.profile_stage(1, 1)  # its factor (previous rows: iteration 2's)
+            s = b.scalars(0)
+            A = np.array(b.read(L.BUF_FACTOR, 0))
+            cov = np.array(b.read(L.BUF_COV, 0))
+            obs = b.read_obs_all()
+            first = None
+            if warm == 2:  # a second trace on the same batch: its FIRST factor is warm too
+                b.reset()
+                b.iterate([3, 4], 1)
+                first = int(b.scalars(0).lml)
+            b.close()
+        finally:
+            L.set_option("oj_warm", old)
+        assert s.status == 0 and s.rank == N
+        assert np.max(np.abs(A.T @ A - cov)) <= 1e-9 * np.max(np.abs(cov))
+        res[warm] = (int(s.lml), A, obs, first)
+    for warm in (1, 2):
+        assert res[warm][0] < res[0][0], (res[0][0], res[warm][0])
+        assert np.max(np.abs(res[warm][1] - res[0][1])) <= 1e-6 * np.max(np.abs(res[0][1]))
+        assert all(np.array_equal(a, c) for a, c in zip(res[warm][2], res[0][2]))
+    assert res[2][3] is not None and res[2][3] < res[0][0]
