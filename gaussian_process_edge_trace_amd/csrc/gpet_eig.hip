@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(256) k_ojw_gemm(EdgeDev* edges, int warm) {
     }
 }
 // blocked Cholesky of the lower triangle of G (n x n, row stride n), 64-wide panels: diagonal block, rows below it, trailing update
-__global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0) {
+__global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0, int inject_failure) {
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E) || E.eig->warm != 1) return;
   const int n = E.Lg;
@@ -675,13 +675,13 @@ __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0) {
   __shared__ int s_bad;
   const int tid = threadIdx.x;
   double* __restrict__ K = E.G;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) s_bad = inject_failure ? 1 : 0;  // (option oj_warm_fail: the tests' way into the fallback)
   for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
     sD[i][j] = (i < nb && j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : 0.0;
   }
   __syncthreads();
-  for (int c = 0; c < nb; ++c) {
+  for (int c = 0; c < nb && !inject_failure; ++c) {
     const double piv = sD[c][c];
     if (!(piv > 0.0)) {  // (uniform: every thread reads the same value)
       if (tid == 0) s_bad = 1;
@@ -1425,7 +1425,7 @@ static void launch_oj_warm(hipStream_t st, EdgeDev* d_edges, int B, const BatchD
   hipLaunchKernelGGL(k_ojw_gemm<0>, dim3(nt, nt, B), dim3(256), 0, st, d_edges, warm);
   hipLaunchKernelGGL(k_ojw_gemm<1>, dim3(nt, nt, B), dim3(256), 0, st, d_edges, warm);
   for (int k0 = 0; k0 < n; k0 += 64) {
-    hipLaunchKernelGGL(k_ojw_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0);
+    hipLaunchKernelGGL(k_ojw_chol_diag, dim3(1, B), dim3(256), 0, st, d_edges, k0, (k0 == 0 && option("oj_warm_fail")) ? 1 : 0);
     const int below = cdiv_h(n - k0 - 64, 64);
     if (below > 0) {
       hipLaunchKernelGGL(k_ojw_chol_trsm, dim3(below, B), dim3(256), 0, st, d_edges, k0);

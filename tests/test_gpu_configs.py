@@ -459,3 +459,31 @@ def test_any_rank_factor_warm_start(amd, ctx):
         assert np.max(np.abs(res[warm][1] - res[0][1])) <= 1e-6 * np.max(np.abs(res[0][1]))
         assert all(np.array_equal(a, c) for a, c in zip(res[warm][2], res[0][2]))
     assert res[2][3] is not None and res[2][3] < res[0][0]
+
+
+def test_any_rank_factor_warm_start_falls_back_to_the_pivoted_cholesky(amd, ctx):
+    """A non-positive pivot in the warm start's Cholesky (injected: option oj_warm_fail) must leave the factor to the
+    pivoted Cholesky, whose launches are enqueued anyway: exactly the cold start's rows."""
+    L = amd._lib
+    N = 192
+    img, truth = orc.synth_sinusoid_image(N, 5)
+    grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=200, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    rows = {}
+    for name, opts in (("cold", {"oj_warm": 0}), ("failed warm start", {"oj_warm": 2, "oj_warm_fail": 1})):
+        old = {k: L.set_option(k, v) for k, v in opts.items()}
+        try:
+            bt = amd.GP_Edge_Tracing_Batch([init], grad, [3], **kw, _ctx=ctx)
+            bt._batch.iterate([3], 3)
+            s = bt._batch.scalars(0)
+            rows[name] = (np.array(bt._batch.read(L.BUF_FACTOR, 0)), int(s.lml), s.status, bt._batch.read_obs_all())
+            bt._batch.close()
+        finally:
+            for k, v in old.items():
+                L.set_option(k, v)
+    a, b = rows["cold"], rows["failed warm start"]
+    assert b[2] == 0 and a[1] == b[1]
+    assert np.array_equal(a[0], b[0])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
