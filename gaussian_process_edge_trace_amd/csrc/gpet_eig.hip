@@ -30,6 +30,9 @@ namespace gpet {
 #define OJ_M 16
 #define OJ_ARGS_MAXB 8     // batches up to this size get their per-edge pointers in the kernel arguments
 #define OJ_STAGE_MAX 1024  // widest edge whose 16-row panel (16 x Lg doubles) is staged in LDS
+// a pair of blocks is left alone when its largest relative coupling is this far (squared) below the stopping tolerance:
+// 1e-4 of it, i.e. 1e-12 at the default 1e-8 -- what one more rotation would make of it is below f64 resolution anyway
+#define OJ_SKIP_REL2 1e-8
 #define OJ_PF 16  // 16-column tiles per wave whose operands are prefetched into registers (4 waves x 16 x 16 = 1024 columns)
 
 static inline int cdiv_h(int a, int b) { return (a + b - 1) / b; }
@@ -884,6 +887,32 @@ __device__ __forceinline__ void oj_report(double mr, int lane, EigState* st) {
   if (lane == 0 && mr > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr));
 }
 
+// A pair of blocks whose 120 couplings are ALL four orders below the stopping tolerance (OJ_SKIP_REL2) is left alone: no
+// inner sweep, no row update (the identity preserves G^T G = Sigma better than any rotation, and rotating a coupling of
+// 1e-12 only moves it below f64 resolution).  That is every pair of the LAST sweep -- the one that only confirms what
+// the sweep before it achieved --, whose rounds then cost the Gram matrix only.  (Skipping at the tolerance itself,
+// 1e-8, was measured too: 12.0 instead of 12.9 ms per factor, but the rows then stay 1e-8 from orthogonal, 7.6e-8 from
+// the cold start's, and the comparison with LAPACK fails its 1e-10.)  Returns the largest squared relative
+// coupling of the block pair in every lane (the measure oj_rotation reports: hardware reciprocal).
+__device__ __forceinline__ double oj_pair_coupling(const double (*s_C)[OJ_M + 1], int lane) {
+  double mr = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = lane + 64 * u, i = e >> 4, j = e & 15;
+    if (i < j) {
+      const double den = fabs(s_C[i][i] * s_C[j][j]), num = s_C[i][j] * s_C[i][j];
+      const double r2 = den > 0.0 ? num * __builtin_amdgcn_rcp(den) : 0.0;
+      mr = r2 > mr ? r2 : mr;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(mr, o, WAVE);
+    mr = ov > mr ? ov : mr;
+  }
+  return mr;
+}
+
 // K index of matrix instruction jj, lane group lg -> row of the 16-row panel.  Lane groups 0/1 (and 2/3) share an
 // LDS cycle: their rows are 8 apart, which with a row stride of 2 (mod 32) doubles puts them on disjoint banks.
 __device__ __forceinline__ int oj_krow(int jj, int lg) { return 8 * (lg & 1) + 4 * (lg >> 1) + jj; }
@@ -906,7 +935,7 @@ struct OjArgs {
 };
 
 template <bool STAGED, bool ARGS>
-__global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, int round, int nblk) {
+__global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, int round, int nblk, double tol2) {
   OjEdge D;
   if (ARGS) {
     D = args.e[blockIdx.y];
@@ -1039,8 +1068,19 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
     s_C[i][j] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);
   }
   __syncthreads();
-  if (w == 0) oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+  __shared__ int s_skip;
+  if (w == 0) {
+    const double mr0 = oj_pair_coupling(s_C, lane);
+    const bool skip = mr0 <= tol2 * OJ_SKIP_REL2;  // (uniform over the wave)
+    if (lane == 0) s_skip = skip ? 1 : 0;
+    if (skip) {
+      if (lane == 0 && mr0 > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr0));
+    } else {
+      oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+    }
+  }
   __syncthreads();
+  if (s_skip) return;  // (the rows stay as they are)
   // -- rows <- R^T rows on the matrix cores: out[a][c] = sum_b R[b][a] X[b][c]; a wave owns whole 16-column tiles
   {
     double ra[4];
@@ -1176,6 +1216,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
   const unsigned int nslots = (unsigned int)(nblk / 2), per_sweep = nslots * (unsigned int)(nblk - 1);
   unsigned int nbar = 0;  // (slots served by this workgroup)
   __shared__ unsigned int s_ticket;
+  __shared__ int s_skip;
 #ifdef GPET_OJ_PROF
   long long pt[6] = {0, 0, 0, 0, 0, 0};
 #define OJ_T(i) { const long long t_ = clock64(); pt[i] += t_ - tl; tl = t_; }
@@ -1264,11 +1305,20 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
         }
         __syncthreads();
         OJ_T(1)
-        if (w == 0) oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+        if (w == 0) {
+          const double mr0 = oj_pair_coupling(s_C, lane);
+          const bool skip = mr0 <= tol2 * OJ_SKIP_REL2;  // (uniform over the wave)
+          if (lane == 0) s_skip = skip ? 1 : 0;
+          if (skip) {
+            if (lane == 0 && mr0 > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr0));
+          } else {
+            oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+          }
+        }
         __syncthreads();
         OJ_T(2)
-        // -- rows <- R^T rows
-        {
+        // -- rows <- R^T rows (not for a pair that is within the tolerance already: oj_pair_coupling)
+        if (!s_skip) {
           double ra[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_krow(jj, lg)][lr];
@@ -1538,11 +1588,11 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int round = 0; round < nblk - 1; ++round) {
       if (staged && use_args)
-        hipLaunchKernelGGL((k_oj_round<true, true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk);
+        hipLaunchKernelGGL((k_oj_round<true, true>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk, tol2);
       else if (staged)
-        hipLaunchKernelGGL((k_oj_round<true, false>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk);
+        hipLaunchKernelGGL((k_oj_round<true, false>), dim3(nblk / 2, B), dim3(256), stage_lds, st, oj_args, d_edges, round, nblk, tol2);
       else
-        hipLaunchKernelGGL((k_oj_round<false, false>), dim3(nblk / 2, B), dim3(256), 0, st, oj_args, d_edges, round, nblk);
+        hipLaunchKernelGGL((k_oj_round<false, false>), dim3(nblk / 2, B), dim3(256), 0, st, oj_args, d_edges, round, nblk, tol2);
     }
     hipLaunchKernelGGL(k_oj_check, dim3(B), dim3(64), 0, st, d_edges, tol2);
   }
