@@ -668,6 +668,10 @@ __global__ void __launch_bounds__(256) k_ojw_gemm(EdgeDev* edges, int warm) {
     }
 }
 // blocked Cholesky of the lower triangle of G (n x n, row stride n), 64-wide panels: diagonal block, rows below it, trailing update
+// (both kernels: thread = (row r = tid & 63, column class tid >> 6: columns class, class + 4, ...): the other factor of an
+//  update, A[cc][c], is the same address for the 64 lanes of a wave -- an LDS broadcast --, rows are 65 doubles apart -- no bank
+//  conflicts --, and no index needs a division; ONE barrier per column.  The first forms (element e -> e / width, e % width with
+//  a run-time width; a thread per row in the substitution) took 62 and 56 us per call, 2 ms per factorisation.)
 __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0, int inject_failure) {
   const EdgeDev E = edges[blockIdx.y];
   if (eig_skip(E) || E.eig->warm != 1) return;
@@ -675,44 +679,35 @@ __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0, i
   if (k0 >= n) return;
   const int nb = n - k0 < 64 ? n - k0 : 64;
   __shared__ double sD[64][65];
-  __shared__ int s_bad;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
   double* __restrict__ K = E.G;
-  if (tid == 0) s_bad = inject_failure ? 1 : 0;  // (option oj_warm_fail: the tests' way into the fallback)
   for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
-    sD[i][j] = (i < nb && j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+    sD[i][j] = (i < nb && j <= i) ? K[(size_t)(k0 + i) * n + k0 + j] : ((i == j) ? 1.0 : 0.0);  // (identity beyond the matrix)
   }
   __syncthreads();
-  for (int c = 0; c < nb && !inject_failure; ++c) {
+  // outer-product form without square roots: A[r][cc] -= A[r][c] A[cc][c] / A[c][c] for c < cc <= r; L[r][c] = A[r][c] / sqrt(A[c][c])
+  // at the end.  A non-positive pivot (every thread sees the same one) ends the warm start.
+  bool bad = inject_failure != 0;  // (option oj_warm_fail: the tests' way into the fallback)
+  for (int c = 0; c < 63 && !bad; ++c) {
     const double piv = sD[c][c];
-    if (!(piv > 0.0)) {  // (uniform: every thread reads the same value)
-      if (tid == 0) s_bad = 1;
+    if (!(piv > 0.0)) {
+      bad = true;
       break;
     }
-    const double d = sqrt(piv), inv = 1.0 / d;
-    __syncthreads();  // (everybody has read the pivot)
-    if (tid == 0) sD[c][c] = d;
-    for (int r = c + 1 + tid; r < nb; r += 256) sD[r][c] *= inv;
-    __syncthreads();
-    // trailing update of the remaining lower triangle: element (r, cc), c < cc <= r < nb
-    {
-      const int wdt = nb - c - 1;
-      for (int e = tid; e < wdt * wdt; e += 256) {
-        const int r = c + 1 + e / wdt, cc = c + 1 + e % wdt;
-        if (cc <= r) sD[r][cc] -= sD[r][c] * sD[cc][c];
-      }
-    }
+    const double f = sD[r][c] / piv;  // (r > c only matters)
+    for (int cc = cq + 4 * ((c + 1 - cq + 3) >> 2); cc <= r; cc += 4)
+      if (cc > c) sD[r][cc] -= f * sD[cc][c];
     __syncthreads();
   }
-  __syncthreads();
-  if (s_bad) {
+  if (!bad && !(sD[63][63] > 0.0)) bad = true;
+  if (bad) {
     if (tid == 0) E.eig->warm = 2;  // not positive definite to rounding: the pivoted Cholesky takes over
     return;
   }
   for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
-    if (i < nb && j <= i) K[(size_t)(k0 + i) * n + k0 + j] = sD[i][j];
+    if (i < nb && j <= i) K[(size_t)(k0 + i) * n + k0 + j] = (i == j) ? sqrt(sD[j][j]) : sD[i][j] / sqrt(sD[j][j]);
   }
 }
 __global__ void __launch_bounds__(256) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
@@ -723,7 +718,7 @@ __global__ void __launch_bounds__(256) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
   if (i0 >= n) return;
   __shared__ double sL[64][65];
   __shared__ double sX[64][65];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, r = tid & 63, cq = tid >> 6;
   double* __restrict__ K = E.G;
   for (int e = tid; e < 64 * 64; e += 256) {
     const int i = e >> 6, j = e & 63;
@@ -731,15 +726,16 @@ __global__ void __launch_bounds__(256) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
     sX[i][j] = (i0 + i < n) ? K[(size_t)(i0 + i) * n + k0 + j] : 0.0;
   }
   __syncthreads();
-  // X L_kk^T = A by columns: column c of X is final once it is divided by L[c][c]; it then leaves every later column
-  // (64 rows x (63 - c) columns of independent updates over the 256 threads; a row at a time per thread was 65 us a block)
-  for (int c = 0; c < 64; ++c) {
-    if (tid < 64) sX[tid][c] = sX[tid][c] / sL[c][c];
-    __syncthreads();
-    const int wdt = 63 - c;
-    for (int e = tid; e < 64 * wdt; e += 256) {
-      const int r = e / wdt, cc = c + 1 + e % wdt;
-      sX[r][cc] -= sX[r][c] * sL[cc][c];
+  // X L_kk^T = A by columns: x[r][c] = a[r][c] / L[c][c] is final once every earlier column has left it; the thread that owns
+  // (r, c + 1) divides it right after its update, so the next trip finds it final
+  if (cq == 0) sX[r][0] = sX[r][0] / sL[0][0];
+  __syncthreads();
+  for (int c = 0; c < 63; ++c) {
+    const double x = sX[r][c];
+    for (int cc = cq + 4 * ((c + 1 - cq + 3) >> 2); cc < 64; cc += 4) {
+      double v = sX[r][cc] - x * sL[cc][c];
+      if (cc == c + 1) v = v / sL[cc][cc];
+      sX[r][cc] = v;
     }
     __syncthreads();
   }
