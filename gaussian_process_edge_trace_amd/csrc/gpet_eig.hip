@@ -696,8 +696,20 @@ __global__ void __launch_bounds__(256) k_ojw_chol_diag(EdgeDev* edges, int k0, i
       break;
     }
     const double f = sD[r][c] / piv;  // (r > c only matters)
-    for (int cc = cq + 4 * ((c + 1 - cq + 3) >> 2); cc <= r; cc += 4)
-      if (cc > c) sD[r][cc] -= f * sD[cc][c];
+    // (a fixed trip count: the 16 pairs of LDS reads of a thread are in flight together -- with run-time bounds every
+    //  update waited for its own loads, ~150 cycles each)
+    double o[16], a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int cc = cq + 4 * m;
+      o[m] = sD[cc][c];
+      a[m] = sD[r][cc];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int cc = cq + 4 * m;
+      if (cc > c && cc <= r) sD[r][cc] = a[m] - f * o[m];
+    }
     __syncthreads();
   }
   if (!bad && !(sD[63][63] > 0.0)) bad = true;
@@ -732,11 +744,21 @@ __global__ void __launch_bounds__(256) k_ojw_chol_trsm(EdgeDev* edges, int k0) {
   __syncthreads();
   for (int c = 0; c < 63; ++c) {
     const double x = sX[r][c];
-    for (int cc = cq + 4 * ((c + 1 - cq + 3) >> 2); cc < 64; cc += 4) {
-      double v = sX[r][cc] - x * sL[cc][c];
-      if (cc == c + 1) v = v / sL[cc][cc];
-      sX[r][cc] = v;
+    const double dn = sL[c + 1][c + 1];
+    double o[16], a[16];  // (fixed trip count: all the LDS reads of a trip in flight together)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int cc = cq + 4 * m;
+      o[m] = sL[cc][c];
+      a[m] = sX[r][cc];
     }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int cc = cq + 4 * m;
+      if (cc > c) sX[r][cc] = a[m] - x * o[m];
+    }
+    // (the owner of column c + 1 finishes it: one division per thread and trip, not one per element)
+    if (cq == ((c + 1) & 3)) sX[r][c + 1] = sX[r][c + 1] / dn;
     __syncthreads();
   }
   for (int e = tid; e < 64 * 64; e += 256) {
