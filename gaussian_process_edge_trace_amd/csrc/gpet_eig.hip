@@ -1267,8 +1267,45 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
       int bI, bJ;
       oj_rr_pair(nblk - 1, round, slot, bI, bJ);
       if (bI * OJ_B < rank) {  // (bI < bJ: otherwise both blocks are empty)
-        // -- stage: thread t takes columns t, t + 256, ... of every row
-        {
+        // -- stage.  Even widths: thread t takes the column PAIRS 2 t, 2 t + 512 of every row as 16-byte agent-scope loads
+        //    (global_load_dwordx4 ... sc1: __hip_atomic_load has no 16-byte form, so the loads and their wait are inline
+        //    assembly -- the wait names every destination register, so nothing that uses one can be scheduled above it):
+        //    half the load instructions and requests of the 8-byte form, which was 35 % of a slot's time.
+        //    Odd widths: thread t takes columns t, t + 256, ... of every row.
+        if ((Lg & 1) == 0) {
+          typedef double oj_d2 __attribute__((ext_vector_type(2)));
+          oj_d2 qv[16][2];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int gi = oj_row(bI, bJ, r);
+            const bool live = gi < rank;
+            gi = gi < D.r_cap ? gi : D.r_cap - 1;
+            const double* __restrict__ xrow = D.G + (size_t)gi * Lg;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int k = 2 * tid + 512 * i;
+              qv[r][i] = (oj_d2){0.0, 0.0};
+              if (live && k < Lg) {
+                const double* p = xrow + k;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(qv[r][i]) : "v"(p) : "memory");
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r += 4)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(qv[r][0]), "+v"(qv[r][1]), "+v"(qv[r + 1][0]), "+v"(qv[r + 1][1]), "+v"(qv[r + 2][0]), "+v"(qv[r + 2][1]),
+                           "+v"(qv[r + 3][0]), "+v"(qv[r + 3][1])
+                         :
+                         : "memory");
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int k = 2 * tid + 512 * i;
+              if (k < kmax) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + k]) = qv[r][i];
+            }
+        } else {
           double v[16][4];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
