@@ -106,12 +106,13 @@ def test_host_start_points_are_the_reference_restarts():
 
 
 def test_committed_bench_line_keeps_the_driver_contract():
-    """profiles/r03_bench_n1.json is a bench.py output committed this round: it must carry every field of the
-    driver's contract (metric/value/unit/..., roofline{...}, cpu_baseline{...}) with sane types."""
+    """profiles/rNN_bench_n1.json (the latest round's) is a bench.py output committed with the code: it must carry every
+    field of the driver's contract (metric/value/unit/..., roofline{...}, cpu_baseline{...}) with sane types."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r03_bench_n1.json")))
+    import glob
+    d = json.load(open(sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench_n1.json")))[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
