@@ -23,6 +23,7 @@ OK, ERR_BAD_ARG, ERR_HIP, ERR_NOT_PD, ERR_ITER_CAP, ERR_RANK_CAP, ERR_UNSUPPORTE
 
 KERNEL_RBF, KERNEL_MATERN = 0, 1
 GRAD_ON_DEVICE = 1  # gpet_batch_create2 / gpet_batch_set_images flag: the gradient image pointers are device pointers
+IMAGES_NEXT_FRAME = 2  # gpet_batch_set_images: the images continue the sequences just traced
 
 
 class GpetParams(C.Structure):
@@ -249,19 +250,21 @@ class Batch:
         self.share_image = bool(share_image)
         self._keep = (grads, inits)
 
-    def set_images(self, grads=None, device_ptrs=None):
-        """Next frame(s) of an image sequence for the same edges: new gradient image(s), gradient KDE recomputed,
-        loop state reset (gpet_batch_set_images)."""
+    def set_images(self, grads=None, device_ptrs=None, next_frame=False):
+        """New gradient image(s) for the same edges, gradient KDE recomputed, loop state reset (gpet_batch_set_images).
+        ``next_frame``: the images are the next frames of the sequences just traced, so an any-rank factor may start from
+        the last trace's rows (GPET_IMAGES_NEXT_FRAME); otherwise nothing of an earlier trace is used."""
         n_img = 1 if self.share_image else self.B
+        nf = IMAGES_NEXT_FRAME if next_frame else 0
         if device_ptrs is not None:
             assert len(device_ptrs) == n_img
             gp = (_P * n_img)(*[int(p) for p in device_ptrs])
-            self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, GRAD_ON_DEVICE))
+            self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, GRAD_ON_DEVICE | nf))
             return
         grads = [np.ascontiguousarray(g, dtype=np.float32) for g in grads]
         assert len(grads) == n_img and all(g.shape == (self.M, self.N) for g in grads)
         gp = (_P * n_img)(*[g.ctypes.data for g in grads])
-        self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, 0))
+        self.ctx.check(self.lib.gpet_batch_set_images(self.h, gp, nf))
 
     def _max_info(self, key):
         """max over the edges of a creation-time constant of gpet_batch_info (cached)."""

@@ -215,7 +215,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.A = cv.take<double>((size_t)E.a_rows_cap * Lg + 64);  // (+ 64: the sample GEMM loads whole 64-column tiles of the last row)
   E.Z = cv.take<double>((size_t)E.z_ring * S * (size_t)E.z_cols);
   E.Yp = (int)((Lg + 15) & ~(size_t)15);
-  E.Y = cv.take<double>((((S + 127) & ~(size_t)127) + 13) * (size_t)E.Yp);  // (+ the spare rows of the sample GEMM's idle lanes)
+  // (+ the spare region of the sample GEMM's idle lanes: they write 16 bytes at (Sround + 4 g) Yp + 2 lane doubles, g < 4, lane < 64 --
+  //  up to 128 doubles into row Sround + 12 whatever the pitch is, so the slack is sized in elements, not in rows)
+  E.Y = cv.take<double>((((S + 127) & ~(size_t)127) + 12) * (size_t)E.Yp + 128 + (size_t)E.Yp);
   E.costs = cv.take<double>(S);
   E.cost_part = cv.take<double>(S * 2 * (Lg / 30 + 2));  // (15 Simpson pairs = 30 columns per tile of the scorer)
   E.best_costs = cv.take<double>((size_t)E.n_keep + 1);
@@ -881,23 +883,33 @@ static int check_device_status(gpet_batch* b) {
   return GPET_OK;
 }
 
-// The any-rank factor's rows of the trace that ends here stay usable as the FIRST warm start of the next one (a sequence's
-// next frame: the same chain, a similar covariance; option oj_warm = 2): they are in slot (iters_done - 1) & 1 of the ring if
-// its tag says "iteration iters_done - 1, full rank".  Tags of the ring itself are cleared.
-static int carry_factor_rows(gpet_batch* b, int e, int iters_done) {
+// The any-rank factor's rows of the trace that ends here may serve as the FIRST warm start of the next one -- only when
+// the caller says the next trace is the next frame of a sequence (gpet_batch_set_images with GPET_IMAGES_NEXT_FRAME: the
+// same chain, a similar covariance).  They are in slot (iters_done - 1) & 1 of the ring if its tag says "iteration
+// iters_done - 1, full rank, converged".  Every other restart (gpet_batch_reset, gpet_batch_set_obs) clears all tags: a
+// trace is then a function of (image, seed, observations) alone, whatever the batch object ran before.
+static int clear_factor_rows(gpet_batch* b, int e) {
   gpet_ctx* c = b->ctx;
-  const EdgeDev& E = b->h_edges[e];
-  if (E.r_cap <= 96 || iters_done < 1) {
-    HIPCHK(c, hipMemsetAsync(E.ap_tag, 0, 3 * sizeof(int), c->stream));
-    return GPET_OK;
+  HIPCHK(c, hipMemsetAsync(b->h_edges[e].ap_tag, 0, 3 * sizeof(int), c->stream));
+  return GPET_OK;
+}
+
+// all edges at once: one wait for the tags, one for their replacements (iters[e] = iterations the edge's last trace ran)
+static int carry_factor_rows_all(gpet_batch* b, const std::vector<int>& iters) {
+  gpet_ctx* c = b->ctx;
+  const int B = b->B;
+  std::vector<int> tags((size_t)3 * B, 0);
+  for (int e = 0; e < B; ++e)
+    HIPCHK(c, hipMemcpyAsync(&tags[3 * e], b->h_edges[e].ap_tag, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, gpet_wait(c->stream));
+  for (int e = 0; e < B; ++e) {
+    const int it = iters[e], slot = (it - 1) & 1;
+    const int keep = (b->h_edges[e].r_cap > 96 && it >= 1 && tags[3 * e + slot] == it) ? slot + 1 : 0;
+    tags[3 * e] = tags[3 * e + 1] = 0;
+    tags[3 * e + 2] = keep;
+    HIPCHK(c, hipMemcpyAsync(b->h_edges[e].ap_tag, &tags[3 * e], 3 * sizeof(int), hipMemcpyHostToDevice, c->stream));
   }
-  int tags[3] = {0, 0, 0};
-  HIPCHK(c, hipMemcpyAsync(tags, E.ap_tag, sizeof tags, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, gpet_wait(c->stream));
-  const int slot = (iters_done - 1) & 1;
-  const int fresh[3] = {0, 0, tags[slot] == iters_done ? slot + 1 : 0};
-  HIPCHK(c, hipMemcpyAsync(E.ap_tag, fresh, sizeof fresh, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, gpet_wait(c->stream));
+  HIPCHK(c, gpet_wait(c->stream));  // (tags is a local)
   return GPET_OK;
 }
 
@@ -922,8 +934,8 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
   const int iters_done = s.iter;
   s.iter = 0;            // a new observation set restarts the edge's loop (gpet.py:820-828)
   HIPCHK(c, hipMemsetAsync(E.wq_tag, 0, 2 * sizeof(int), c->stream));  // (and forgets the last trace's eigenvectors)
-  if (iters_done >= 1) {  // (0: gpet_batch_reset has been here already)
-    int rc3 = carry_factor_rows(b, e, iters_done);
+  if (iters_done >= 1) {  // (0: gpet_batch_reset / gpet_batch_set_images has been here already and decided what stays)
+    int rc3 = clear_factor_rows(b, e);
     if (rc3) return rc3;
   }
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
@@ -1255,18 +1267,24 @@ int gpet_select_pixels(gpet_batch* b) {
   return check_device_status(b);
 }
 
-int gpet_batch_reset(gpet_batch* b) {
-  if (!b) return GPET_ERR_BAD_ARG;
+static int batch_reset(gpet_batch* b, bool next_frame) {
   gpet_ctx* c = b->ctx;
   b->iters_issued = 0;
   b->norm_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));
-  if (b->bd.r_cap > 96) {  // (any-rank batches: where every edge's last factor rows are, before the iteration counters go)
-    int rc = fetch_all_scalars(b);
-    if (rc) return rc;
-    for (int e = 0; e < b->B; ++e) {
-      rc = carry_factor_rows(b, e, b->h_scalars[e].iter);
+  if (b->bd.r_cap > 96) {  // (any-rank batches keep the last factor rows in a ring)
+    if (next_frame && option("oj_warm")) {  // where every edge's last rows are, before the iteration counters go
+      int rc = fetch_all_scalars(b);
       if (rc) return rc;
+      std::vector<int> iters((size_t)b->B);
+      for (int e = 0; e < b->B; ++e) iters[e] = b->h_scalars[e].iter;
+      rc = carry_factor_rows_all(b, iters);
+      if (rc) return rc;
+    } else {
+      for (int e = 0; e < b->B; ++e) {
+        int rc = clear_factor_rows(b, e);
+        if (rc) return rc;
+      }
     }
   }
   for (int e = 0; e < b->B; ++e) {
@@ -1280,6 +1298,11 @@ int gpet_batch_reset(gpet_batch* b) {
   return GPET_OK;
 }
 
+int gpet_batch_reset(gpet_batch* b) {
+  if (!b) return GPET_ERR_BAD_ARG;
+  return batch_reset(b, false);
+}
+
 int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int flags) {
   if (!b || !grad) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -1290,7 +1313,7 @@ int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int 
   // gradient KDE of every distinct image (gpet.py:127), then the state of a fresh constructor
   HIPCHK(c, launch_kde(c->stream, b->d_edges, b->share_image ? 1 : b->B, b->bd, 1));
   b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = false;
-  return gpet_batch_reset(b);
+  return batch_reset(b, (flags & GPET_IMAGES_NEXT_FRAME) != 0);
 }
 
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {

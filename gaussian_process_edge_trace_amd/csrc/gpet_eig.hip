@@ -577,9 +577,10 @@ __device__ __forceinline__ const double* ojw_source(const EdgeDev& E, int warm) 
   const gpet_scalars* sc = E.sc;
   const int k = sc->iter;
   if (!warm || E.Lg > E.r_cap) return nullptr;
-  if (k < 1) {  // a trace's first factor: the previous trace's last rows, if gpet_batch_set_obs found them usable (oj_warm = 2)
+  if (k < 1) {  // a trace's first factor: the previous FRAME's last rows, if the host carried them over (gpet_batch_set_images
+                // with GPET_IMAGES_NEXT_FRAME; every other restart clears the tag)
     const int carry = E.ap_tag[2];
-    return (warm >= 2 && carry > 0) ? E.Ap + (size_t)(carry - 1) * E.r_cap * E.Lg : nullptr;
+    return carry > 0 ? E.Ap + (size_t)(carry - 1) * E.r_cap * E.Lg : nullptr;
   }
   const int slot = (k - 1) & 1;
   if (E.ap_tag[slot] != k) return nullptr;
@@ -1413,7 +1414,11 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
       }
       OJ_T(3)
       ++nbar;
-      __syncthreads();  // (every wave's row stores and the coupling report are out: hipcc's barrier waits for vmcnt(0))
+      // Every wave's row stores (write-through, sc1) must have COMPLETED before thread 0 counts the slot finished: the
+      // workgroup barrier orders nothing in global memory and the compiler puts no vmcnt wait in front of it (the shipped
+      // object had none -- tests/test_abi.py greps the ISA for this one), so each wave drains its own stores here.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (tid == 0) {
         s_ticket = atomicAdd(&st->ticket, 1u);  // (the next trip's; read after the barrier at the top)
         const unsigned int d = atomicAdd(&st->bar, 1u) + 1u;
@@ -1508,7 +1513,9 @@ __global__ void __launch_bounds__(256) k_oj_rows(EdgeDev* edges) {
   const double sg = dot < 0.0 ? -1.0 : 1.0;
   double* __restrict__ dst = E.A + (size_t)k * Lg;
   // (and into this iteration's slot of the ring the next iteration's warm start reads -- rows of full rank only)
-  const bool keep = r == Lg && Lg <= E.r_cap;
+  // -- and only rows of a CONVERGED Jacobi: the warm start's identity X^T X = Sigma needs A^T S^-1 A = I, i.e. mutually
+  //    orthogonal rows; a factorisation that ran out of sweeps (oj_max_sweeps) leaves rows that are not.
+  const bool keep = r == Lg && Lg <= E.r_cap && E.eig->converged != 0;
   double* __restrict__ dst2 = E.Ap + ((size_t)(E.sc->iter & 1) * E.r_cap + k) * Lg;
   for (int j = threadIdx.x; j < Lg; j += 256) {
     const double v = sg * src[j];

@@ -28,7 +28,7 @@ const OptionDef kDefs[] = {
     {"jacobi_logw", 1, 0, 1, "batches that have a rotation log (<= jlog_max_b edges): eigenvectors by a separate pass over the logged rotations"},
     {"jlog_max_b", 32, 0, 4096, "largest batch that gets a rotation log (read when a batch is created): measured per step of a batch alone -- 32 edges 21.5 against 23.1 ms, 64 edges 27.1 either way, 1 024 edges slower (3.15 against 1.73 ms per launch)"},
     {"scalar_jacobi", 0, 0, 1, "1: ranks above 96 by round 1's whole-GPU scalar Jacobi (cross-check of gpet_eig.hip)"},
-    {"oj_warm", 2, 0, 2, "any-rank factor: rows of full rank start from the previous iteration's rows (k_ojw_*: A Sigma A^T, its Cholesky factor, one product) instead of the pivoted Cholesky; 2: the first factor after gpet_batch_set_obs starts from the previous trace's last rows too (image sequences)"},
+    {"oj_warm", 1, 0, 1, "any-rank factor: rows of full rank start from the previous iteration's rows (k_ojw_*: A Sigma A^T, its Cholesky factor, one product) instead of the pivoted Cholesky (across the frames of a sequence only where the caller asks: gpet_batch_set_images with GPET_IMAGES_NEXT_FRAME)"},
     {"oj_warm_fail", 0, 0, 1, "testing: the warm start's Cholesky reports a non-positive pivot, so that the factor falls back to the pivoted Cholesky"},
     {"oj_persist", 1, 0, 1, "any-rank Jacobi: rounds and sweeps in one launch, pair slots handed out by ticket (k_oj_persist); 0: one launch per round"},
     {"oj_stage", 1, 0, 1, "any-rank Jacobi: a pair's 16 rows staged in LDS; 0: operands from global memory"},

@@ -390,23 +390,25 @@ class GP_Edge_Tracing_Batch(object):
                 self._batch.set_obs(e, p["obs"])
 
     def reset(self):
-        """Back to the state right after construction (the warm-start observations included).  (An any-rank -- Matern --
-        batch keeps its last factor rows as the starting point of the next trace's first factorisation, library option
-        ``oj_warm`` = 2: the factor is an iterative solve, its result does not depend on the start beyond its tolerance.)"""
+        """Back to the state right after construction (the warm-start observations included): nothing of the trace the
+        object ran before is used by the next one."""
         self._batch.reset()
         self._set_obs()
 
-    def set_frame(self, grad_imgs=None, obs=None, seeds=None, grad_device_ptrs=None):
+    def set_frame(self, grad_imgs=None, obs=None, seeds=None, grad_device_ptrs=None, next_frame=True):
         """The next frame of an image sequence for the same edges (gpet.py:57-61: the previous trace warm-starts the
         next through ``obs``): new gradient image(s) -- host arrays, or device addresses with ``grad_device_ptrs`` --
         new warm-start observations and, optionally, new seeds.  Geometry, kernel and every other parameter stay, so
-        what depends only on them (arena, streams, the prior eigenbasis of the structured loop path) is reused."""
+        what depends only on them (arena, streams, the prior eigenbasis of the structured loop path) is reused.
+        ``next_frame`` (default): the images continue the sequences just traced, so the any-rank (Matern) factor of the
+        new trace's first iteration may start from the last trace's rows -- an iterative solve, the same rows to its
+        tolerance.  ``next_frame=False``: unrelated images; the trace is what a fresh object would compute, bit for bit."""
         if grad_device_ptrs is not None:
             self._batch.set_images(device_ptrs=list(grad_device_ptrs) if isinstance(grad_device_ptrs, (list, tuple))
-                                   else [grad_device_ptrs])
+                                   else [grad_device_ptrs], next_frame=next_frame)
         else:
             imgs = list(grad_imgs) if isinstance(grad_imgs, (list, tuple)) else [grad_imgs]
-            self._batch.set_images([np.asarray(g).astype(np.float32) for g in imgs])
+            self._batch.set_images([np.asarray(g).astype(np.float32) for g in imgs], next_frame=next_frame)
         obs = [np.array([])] * self.B if obs is None else list(obs)
         for e, p in enumerate(self._ps):
             p["obs"] = np.asarray(obs[e]).reshape(-1, 2).astype(np.int64)

@@ -183,6 +183,12 @@ int gpet_batch_reset(gpet_batch* b);
  * gpet_batch_reset.  The per-edge work that depends only on the geometry and the kernel (the prior eigenbasis of the
  * structured loop path) is kept. */
 int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int flags);
+/* flags: GPET_GRAD_ON_DEVICE as above, and GPET_IMAGES_NEXT_FRAME: the new images are the NEXT FRAMES of the sequences
+ * the edges have just been traced through (gpet.py:57-61), so the any-rank factor of the new trace's first iteration may
+ * start from the last trace's factor rows (an iterative solve: the same rows to its tolerance, 4e-9 relative).  Without the
+ * flag -- and after gpet_batch_reset / gpet_batch_set_obs always -- nothing of an earlier trace is used: a trace depends
+ * on (image, seed, observations) only, like the reference's single-use object. */
+#define GPET_IMAGES_NEXT_FRAME 2u
 
 /* set / get the observation set (xy int64) of edge e (gpet.py:100,820,857). */
 int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs);

@@ -107,3 +107,54 @@ def test_option_registry_round_trip_and_documented():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in opts:
         assert "| `%s` |" % name in doc, name
+
+
+def _device_disassembly(tmp_path):
+    """gfx950 disassembly of every code object in the shipped library (llvm-objdump --offloading writes the bundles next to
+    its input, so it works on a copy)."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    so = tmp_path / "lib.so"
+    shutil.copy(ge.LIB, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    text = []
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" in f:
+            text.append(subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout)
+    return "\n".join(text)
+
+
+def _functions(dis, name_part):
+    out, cur, name = {}, None, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            name = m.group(1)
+            cur = out.setdefault(name, []) if name_part in name else None
+            continue
+        if cur is not None and line.startswith("\t"):
+            cur.append(re.sub(r"\s+", " ", line.strip().split("//")[0].strip()))
+    return out
+
+
+def test_isa_every_wave_drains_its_row_stores_before_a_pair_slot_is_published(tmp_path):
+    """k_oj_persist (csrc/gpet_eig.hip): a pair slot is counted finished by thread 0 after a workgroup barrier; the rows the
+    other three waves wrote (write-through stores, another workgroup on another XCD reads them next) must have COMPLETED by
+    then.  A workgroup barrier orders nothing in global memory and the compiler puts no wait in front of it on its own
+    (round 4's shipped object had none -- advisor finding): every wave executes s_waitcnt vmcnt(0) between its last row
+    store and the barrier.  Checked in the ISA of both template variants."""
+    fns = _functions(_device_disassembly(tmp_path), "k_oj_persist")
+    assert len(fns) == 2, list(fns)
+    for name, ins in fns.items():
+        stores = [i for i, s in enumerate(ins) if re.match(r"(global_store_dwordx2 \S+ a\[\d+:\d+\], off|flat_store_dwordx2 \S+ a\[\d+:\d+\]) sc1$", s)]
+        assert len(stores) >= 16, (name, len(stores))  # the row stores of the update (16 per wave and column batch)
+        last = stores[-1]
+        bar = next(i for i in range(last, len(ins)) if ins[i].startswith("s_barrier"))
+        between = ins[last + 1:bar]
+        assert any(s.startswith("s_waitcnt") and "vmcnt(0)" in s for s in between), (name, between)
+        assert not any(s.startswith(("global_store", "flat_store", "buffer_store")) for s in between), (name, between)

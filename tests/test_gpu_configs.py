@@ -421,8 +421,10 @@ def test_structured_loop_warm_started_eigen_decomposition(amd, ctx):
 def test_any_rank_factor_warm_start(amd, ctx):
     """Option oj_warm (k_ojw_*): from the second iteration on the one-sided Jacobi of a full-rank (Matern) covariance starts
     from rows built out of the previous iteration's factor instead of a pivoted Cholesky factor.  A^T A = Sigma to rounding
-    either way, rows within the solver's tolerance of the cold start's, the same observation sets, fewer sweeps; with
-    oj_warm = 2 the first factor after gpet_batch_reset starts from the last trace's rows."""
+    either way, rows within the solver's tolerance of the cold start's, the same observation sets, fewer sweeps.  Across
+    traces only where the caller says the images continue a sequence (set_frame(next_frame=True) =
+    gpet_batch_set_images with GPET_IMAGES_NEXT_FRAME): the first factor of the new trace then starts warm; after a
+    plain reset() it starts cold -- exactly the sweeps of a fresh object."""
     L = amd._lib
     N = 256
     img, truth = orc.synth_sinusoid_image(N, 5)
@@ -431,34 +433,80 @@ def test_any_rank_factor_warm_start(amd, ctx):
     kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
               N_samples=200, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
     res = {}
-    for warm in (0, 1, 2):
+    for warm in (0, 1):
         old = L.set_option("oj_warm", warm)
         try:
             bt = amd.GP_Edge_Tracing_Batch([init] * 2, grad, [3, 4], **kw, _ctx=ctx)
             b = bt._batch
-            b.iterate([3, 4], 3)
+            b.iterate([3, 4], 1)
+            first_fresh = int(b.scalars(0).lml)  # sweeps of a trace's first factor on a fresh object: always cold
+            b.iterate([3, 4], 2)
             b.profile_stage(0, 1)  # covariance of the current observation set
             b.profile_stage(1, 1)  # its factor (previous rows: iteration 2's)
             s = b.scalars(0)
             A = np.array(b.read(L.BUF_FACTOR, 0))
             cov = np.array(b.read(L.BUF_COV, 0))
             obs = b.read_obs_all()
-            first = None
-            if warm == 2:  # a second trace on the same batch: its FIRST factor is warm too
-                b.reset()
+            first_reset = first_frame = None
+            if warm:
+                b.reset()  # an unrelated second trace: nothing carried over
                 b.iterate([3, 4], 1)
-                first = int(b.scalars(0).lml)
+                first_reset = int(b.scalars(0).lml)
+                b.iterate([3, 4], 2)
+                bt.set_frame(grad, None, [3, 4], next_frame=True)  # the next frame of a sequence: first factor warm
+                b.iterate([3, 4], 1)
+                first_frame = int(b.scalars(0).lml)
             b.close()
         finally:
             L.set_option("oj_warm", old)
         assert s.status == 0 and s.rank == N
         assert np.max(np.abs(A.T @ A - cov)) <= 1e-9 * np.max(np.abs(cov))
-        res[warm] = (int(s.lml), A, obs, first)
-    for warm in (1, 2):
-        assert res[warm][0] < res[0][0], (res[0][0], res[warm][0])
-        assert np.max(np.abs(res[warm][1] - res[0][1])) <= 1e-6 * np.max(np.abs(res[0][1]))
-        assert all(np.array_equal(a, c) for a, c in zip(res[warm][2], res[0][2]))
-    assert res[2][3] is not None and res[2][3] < res[0][0]
+        res[warm] = (int(s.lml), A, obs, first_fresh, first_reset, first_frame)
+    assert res[1][0] < res[0][0], (res[0][0], res[1][0])
+    assert np.max(np.abs(res[1][1] - res[0][1])) <= 1e-6 * np.max(np.abs(res[0][1]))
+    assert all(np.array_equal(a, c) for a, c in zip(res[1][2], res[0][2]))
+    assert res[1][3] == res[0][3] == res[1][4], res  # fresh object and reset object: the cold start's sweeps
+    assert res[1][5] < res[1][3], res                 # next frame: warm
+
+
+def test_matern_trace_on_a_reused_batch_equals_a_fresh_object(amd, ctx):
+    """A trace is a function of (image, seed, observations) only: a Matern batch object that has just traced image A and
+    is then given image B (set_frame(next_frame=False)) or reset() must produce, bit for bit, the observation sets,
+    iteration counts and traces of a FRESH object on B -- and the oracle's.  (Round 4's default carried the last trace's
+    factor rows into the next trace's first factorisation.)"""
+    N = 128
+    kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
+              N_samples=200, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    grads, inits = [], []
+    for seed in (5, 9):
+        img, truth = orc.synth_sinusoid_image(N, seed)
+        grads.append(amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
+        inits.append(truth[[0, -1], :][:, [1, 0]])
+    init = inits[0]
+    seeds = [3, 4]
+
+    def run(bt):
+        traces = bt()
+        return [np.array(t) for t in traces], list(bt.timings["iters"]), [np.array(o) for o in bt._batch.read_obs_all()]
+
+    fresh = amd.GP_Edge_Tracing_Batch([init] * 2, grads[1], seeds, **kw, _ctx=ctx)
+    want = run(fresh)
+    fresh._batch.close()
+    used = amd.GP_Edge_Tracing_Batch([init] * 2, grads[0], [11, 12], **kw, _ctx=ctx)
+    run(used)  # image A, other seeds
+    used.set_frame(grads[1], None, seeds, next_frame=False)
+    got = run(used)
+    used.reset()
+    again = run(used)
+    used._batch.close()
+    for res in (got, again):
+        assert res[1] == want[1]
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], want[0]))
+        assert all(np.array_equal(a, b) for a, b in zip(res[2], want[2]))
+    for e in range(2):
+        et_o, _, info = orc.trace(init, grads[1], seed=seeds[e], sign_convention="harmonic", **kw)
+        assert info["n_iter"] == want[1][e]
+        assert np.array_equal(want[0][e], et_o)
 
 
 def test_any_rank_factor_warm_start_falls_back_to_the_pivoted_cholesky(amd, ctx):
@@ -472,7 +520,7 @@ def test_any_rank_factor_warm_start_falls_back_to_the_pivoted_cholesky(amd, ctx)
     kw = dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 0.15 * N, 'length_scale': 0.04 * N}, noise_y=1,
               N_samples=200, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
     rows = {}
-    for name, opts in (("cold", {"oj_warm": 0}), ("failed warm start", {"oj_warm": 2, "oj_warm_fail": 1})):
+    for name, opts in (("cold", {"oj_warm": 0}), ("failed warm start", {"oj_warm": 1, "oj_warm_fail": 1})):
         old = {k: L.set_option(k, v) for k, v in opts.items()}
         try:
             bt = amd.GP_Edge_Tracing_Batch([init], grad, [3], **kw, _ctx=ctx)
