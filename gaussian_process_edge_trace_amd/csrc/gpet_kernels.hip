@@ -5,6 +5,7 @@
 #include "gpet_lbfgsb_dev.h"
 
 #include <atomic>
+#include <type_traits>
 #include <math.h>
 #include <stdlib.h>
 

@@ -22,7 +22,7 @@ const OptionDef kDefs[] = {
     {"fin_prepare_serial", 0, 0, 1, "1: training sets of the converged fits by one thread per edge (cross-check of the one-wave-per-edge kernel)"},
     {"lml_mfma", 1, 0, 1, "objective of the converged fits on the f64 matrix cores (k_lml16) where the training set allows it; 0: register-tile kernels k_lml / k_lml2"},
     {"lml_two_tiles_from", 600, 1, 0x3fffffff, "problems per launch from which k_lml2 (two 4x4 tiles per thread) replaces k_lml"},
-    {"jacobi_variant", 1, 0, 1, "LDS Jacobi of ranks <= 96: 1 = seated form (k_jacobi_seat), 0 = addressed by row index (k_jacobi_lds: the cross-check)"},
+    {"jacobi_variant", 2, 0, 2, "LDS Jacobi of ranks <= 96: 2 = seated, rotation parameters one round ahead, one barrier per round (k_jacobi_ahead); 1 = seated, three barriers per round (k_jacobi_seat: the cross-check); 0 = addressed by row index (k_jacobi_lds)"},
     {"jacobi_warm", 1, 0, 1, "structured loop: the eigen-decomposition of an iteration starts from the previous iteration's eigenvectors (k_jacobi_prerot) instead of the identity"},
     {"jacobi_wreg", 6, 0, 8, "k_jacobi_seat: 7 x this many rows of the eigenvector matrix in the worker waves' registers instead of LDS (0, 4, 6, 8)"},
     {"jacobi_logw", 1, 0, 1, "batches that have a rotation log (<= jlog_max_b edges): eigenvectors by a separate pass over the logged rotations"},

@@ -10,7 +10,13 @@ a trace's iteration count share normal streams), image seeds {1, 3}:
   * ``oracle_quality``  -- the oracle (oracle/gpet_oracle.py) on all 240 seeds: convention 0 = LAPACK's own eigenvector
                            signs with one BLAS thread (= ``ref_quality_t1`` row by row: asserted here), 1 = the library's
                            "harmonic" sign convention (what the device reproduces bit for bit), 2 = LAPACK's signs with
-                           EIGHT BLAS threads on the first 60 seeds (= ``ref_quality``'s spaced rows: counted here).
+                           EIGHT BLAS threads on the first 60 seeds (= ``ref_quality``'s spaced rows: counted here);
+                           3 / 4 = the harmonic convention again with TWO / FOUR BLAS threads on all 240 seeds: the
+                           oracle perturbed by nothing but its own rounding (another partition of every dot product,
+                           another draw of LAPACK's noise in the ~430 numerically-zero singular directions).  A seed
+                           whose rows 1, 3 and 4 are identical is DECIDED: the GPU test demands the device's trace to
+                           be that row, no exception; on the few others the trace hangs on a near-tie that rounding
+                           noise settles, and the device must give one of the three answers.
 LAPACK's singular-vector signs are implementation-defined -- and they depend on the THREAD COUNT of the BLAS underneath:
 the same reference code on the same seed traces a different edge with 1, 4 and 8 threads (image 1, seed 1000: MSE 907,
 522, 6 490).  A sign convention is therefore not something the reference has; its traces are one draw per environment.
@@ -52,14 +58,13 @@ def _metrics(et, edge):
 
 def _oracle_one(args):
     img_seed, seed, conv = args
-    threads = 8 if conv == 2 else 1
-    from threadpoolctl import threadpool_limits
+    threads = {0: 1, 1: 1, 2: 8, 3: 2, 4: 4}[conv]
     from oracle import gpet_oracle as orc
     img, edge = orc.synth_sinusoid_image(500, img_seed)
     grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
     init = edge[[0, -1], :][:, [1, 0]]
-    with threadpool_limits(limits=threads):
-        et, _, info = orc.trace(init, grad, seed=seed, sign_convention="harmonic" if conv == 1 else None, **README)
+    et, _, info = orc.trace(init, grad, seed=seed, sign_convention="harmonic" if conv in (1, 3, 4) else None, blas_threads=threads,
+                            **README)
     return (img_seed, seed, conv, info["n_iter"]) + _metrics(et, edge)
 
 
@@ -95,7 +100,7 @@ def main():
     def save(ref, orc_rows):
         np.savez_compressed(path, ref_quality=ref_old, columns=np.array(["img_seed", "seed", "n_iter", "mse", "dice", "relarea"]),
                             ref_quality_t1=ref, oracle_quality=orc_rows,
-                            oracle_columns=np.array(["img_seed", "seed", "convention (0 LAPACK 1 thread, 1 harmonic, 2 LAPACK 8 threads)",
+                            oracle_columns=np.array(["img_seed", "seed", "convention (0 LAPACK 1 thread, 1 harmonic 1 thread, 2 LAPACK 8 threads, 3 harmonic 2 threads, 4 harmonic 4 threads)",
                                                      "n_iter", "mse", "dice", "relarea"]),
                             kde_standin=1)
 
@@ -103,6 +108,8 @@ def main():
     done_orc = {(int(r[0]), int(r[1]), int(r[2])) for r in have_orc}
     jobs_ref = [(a, b) for a in IMG_SEEDS for b in SPACED[:60] if (a, b) not in done_ref]
     jobs_orc = [(a, b, c) for c in (1, 0) for a in IMG_SEEDS for b in SPACED if (a, b, c) not in done_orc]
+    # (two / four BLAS threads per run: fewer workers at a time)
+    jobs_orc_mt = [(a, b, c) for c in (3, 4) for a in IMG_SEEDS for b in SPACED if (a, b, c) not in done_orc]
     # (eight BLAS threads per run: one run at a time, on the 60-seed subset -- five such workers oversubscribe this machine)
     jobs_orc8 = [(a, b, 2) for a in IMG_SEEDS for b in SPACED[:60] if (a, b, 2) not in done_orc]
     print("reference runs to do: %d, oracle runs: %d (+ %d with 8 BLAS threads), %d workers"
@@ -119,6 +126,12 @@ def main():
             ref = np.asarray(sorted([tuple(r) for r in ref] + rows), dtype=np.float64).reshape(-1, 6)
             save(ref, orc_rows)
             print("reference runs done: %d" % min(len(jobs_ref), i0 + 30), flush=True)
+    with mp.get_context("fork").Pool(max(1, workers // 3)) as pool:
+        for i0 in range(0, len(jobs_orc_mt), 60):
+            rows = pool.map(_oracle_one, jobs_orc_mt[i0:i0 + 60], chunksize=2)
+            orc_rows = np.asarray(sorted([tuple(r) for r in orc_rows] + rows), dtype=np.float64).reshape(-1, 7)
+            save(ref, orc_rows)
+            print("oracle runs with 2 / 4 BLAS threads done: %d of %d" % (min(len(jobs_orc_mt), i0 + 60), len(jobs_orc_mt)), flush=True)
     for i0 in range(0, len(jobs_orc8), 20):
         rows = [_oracle_one(j) for j in jobs_orc8[i0:i0 + 20]]
         orc_rows = np.asarray(sorted([tuple(r) for r in orc_rows] + rows), dtype=np.float64).reshape(-1, 7)
@@ -141,6 +154,11 @@ def main():
     both = [k for k in lut0 if k in lut2]
     t1_vs_t8 = sum(1 for k in both if np.array_equal(lut0[k], lut2[k]))
     print("LAPACK signs, 1 thread vs 8 threads: the same trace quality on %d of %d (image, seed) pairs" % (t1_vs_t8, len(both)))
+    for a in IMG_SEEDS:
+        rows = {c: {int(r[1]): tuple(r[3:]) for r in orc_rows if int(r[0]) == a and int(r[2]) == c} for c in (1, 3, 4)}
+        if rows[3] and rows[4]:
+            und = [sd for sd in rows[1] if not (rows[1][sd] == rows[3].get(sd) == rows[4].get(sd))]
+            print("image seed %d: harmonic rows with 1 / 2 / 4 BLAS threads identical on %d of %d seeds; undecided: %s" % (a, len(rows[1]) - len(und), len(rows[1]), und))
     for a in IMG_SEEDS:
         for c in (0, 2, 1):
             r = orc_rows[(orc_rows[:, 0] == a) & (orc_rows[:, 2] == c)]

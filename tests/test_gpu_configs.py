@@ -318,8 +318,9 @@ def test_config4_batch_equals_single_edge_runs_at_bench_shape(amd, ctx):
 
 
 def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
-    """The two LDS Jacobi kernels for ranks <= 96 -- by row index (round 1) and seated (blocks by seat, upper triangle,
-    in place, two workgroups per CU) -- run the same rotations in the same order, so their factors agree to rounding
+    """The LDS Jacobi kernels for ranks <= 96 -- by row index (round 1: variant 0), seated (blocks by seat, upper triangle,
+    in place, three barriers per round: 1) and seated with the rotation parameters one round ahead and one barrier per round
+    (k_jacobi_ahead: 2, the default) -- run the same rotations in the same order, so their factors agree to rounding
     (not bitwise: a pair's roles can be swapped, which changes the order of the additions).  Generic path (stage API:
     covariance -> pivoted Cholesky -> Gram -> Jacobi -> rows) over widths and length scales that give odd, even, tiny and
     capacity-sized ranks; then whole traces through the structured loop path, which must not move by a pixel."""
@@ -334,7 +335,7 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
         kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 0.15 * N, 'length_scale': ell}, noise_y=1, N_samples=64,
                   score_thresh=1, delta_x=3, keep_ratio=0.1, pixel_thresh=3, seed=1, fix_endpoints=True)
         out = {}
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             old = L.set_option("jacobi_variant", variant)
             try:
                 tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
@@ -347,16 +348,21 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
                 out[variant] = (b.read(L.BUF_FACTOR), b.read(L.BUF_EIGVALS), b.read(L.BUF_COV), b.scalars().rank)
             finally:
                 L.set_option("jacobi_variant", old)
-        (A0, ev0, cov, r0), (A1, ev1, _, r1) = out[0], out[1]
-        assert r0 == r1 and A0.shape == A1.shape and r0 <= 96  # (above 96 the any-rank factor of csrc/gpet_eig.hip takes over)
+        A0, ev0, cov, r0 = out[0]
+        assert r0 <= 96  # (above 96 the any-rank factor of csrc/gpet_eig.hip takes over)
         seen.add(r0)
         scale = ev0[0]
-        np.testing.assert_allclose(ev1, ev0, rtol=0, atol=1e-12 * scale)
-        np.testing.assert_allclose(A1.T @ A1, cov, rtol=0, atol=1e-9 * scale)
         # rows of well separated singular values agree row by row (a near-degenerate pair may come out rotated in either form)
         gap = np.minimum(np.abs(np.diff(ev0, prepend=np.inf)), np.abs(np.diff(ev0, append=-np.inf)))
         sep = gap > 1e-6 * scale
-        np.testing.assert_allclose(A1[sep], A0[sep], rtol=0, atol=1e-7 * np.sqrt(scale))
+        for v in (1, 2):
+            A1, ev1, _, r1 = out[v]
+            assert r0 == r1 and A0.shape == A1.shape
+            np.testing.assert_allclose(ev1, ev0, rtol=0, atol=1e-12 * scale)
+            np.testing.assert_allclose(A1.T @ A1, cov, rtol=0, atol=1e-9 * scale)
+            np.testing.assert_allclose(A1[sep], A0[sep], rtol=0, atol=1e-7 * np.sqrt(scale))
+        # the two seated forms run the same rotations: one round-off apart
+        np.testing.assert_allclose(out[2][0][sep], out[1][0][sep], rtol=0, atol=1e-10 * np.sqrt(scale))
     assert any(r % 2 for r in seen) and any(r % 2 == 0 for r in seen) and min(seen) <= 8 and max(seen) >= 60, seen
     # whole traces, structured loop path (the bench configuration at 128 columns and at the README size)
     for N, S, ell, sf in [(128, 200, 8.0, 20.0), (500, 1000, 20.0, 75.0)]:
@@ -366,7 +372,7 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
         kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': sf, 'length_scale': ell}, noise_y=1, N_samples=S,
                   score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
         traces = {}
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             old = L.set_option("jacobi_variant", variant)
             try:
                 bt = amd.GP_Edge_Tracing_Batch([init] * 4, grad, [1, 2, 3, 4], **kw, _ctx=ctx)
@@ -374,8 +380,9 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
                 traces[variant] = bt()
             finally:
                 L.set_option("jacobi_variant", old)
-        for a, b_ in zip(traces[0], traces[1]):
-            assert np.array_equal(a, b_)
+        for v in (1, 2):
+            for a, b_ in zip(traces[0], traces[v]):
+                assert np.array_equal(a, b_)
 
 
 def test_structured_loop_warm_started_eigen_decomposition(amd, ctx):

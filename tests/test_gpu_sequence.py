@@ -237,8 +237,10 @@ def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
     README configuration on image seeds {1, 3} x 240 RNG seeds 997 apart (iteration k of seed s draws from
     RandomState(s + k + 1), so closer seeds share normal streams).
       * The device is the oracle under the library's sign convention, trace for trace: iterations, MSE and DICE of the
-        480 traces are IDENTICAL to the fixture's "harmonic" rows -- except where the oracle itself, run on this host,
-        leaves its fixture row (a near-tie moved by the BLAS thread count: at most 3 per image, each checked live).
+        480 traces are IDENTICAL to the fixture's "harmonic" rows (made with ONE BLAS thread: oracle.trace pins it) on every
+        seed that the oracle itself decides -- whose harmonic row is the same with 1, 2 and 4 BLAS threads (fixture rows
+        3 / 4: the oracle's own rounding noise as the perturbation); no tolerance there.  On the others (1 of 480) the device
+        must give one of the oracle's answers.
       * The reference itself has no sign convention: LAPACK's singular-vector signs are implementation-defined and
         change with the BLAS thread count -- the fixture holds the oracle under LAPACK's signs with 1 and with 8 threads
         (the first equal to the unmodified reference with one thread, seed by seed), and those two disagree on most
@@ -246,11 +248,11 @@ def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
         coin that every convention flips differently, so only the DISTRIBUTION is comparable: the device's good-branch
         fraction lies within 3 standard errors of each LAPACK variant (and the two LAPACK variants of each other), the
         good-branch median MSE, median DICE and iterations agree.
-    The table goes to gpurun_out/r04_t3_quality.json (kept as profiles/r04_t3_quality.json)."""
+    The table goes to gpurun_out/r05_t3_quality.json (kept as profiles/r05_t3_quality.json)."""
     import json
     import os
     fx = golden("quality_rbf500")
-    orq = fx["oracle_quality"]  # img_seed, seed, convention (0 LAPACK 1 thread, 1 harmonic, 2 LAPACK 8 threads), n_iter, mse, dice, relarea
+    orq = fx["oracle_quality"]  # img_seed, seed, convention (0 LAPACK 1 thread, 1 harmonic 1 thread, 2 LAPACK 8 threads, 3 / 4 harmonic 2 / 4 threads), n_iter, mse, dice, relarea
     kw = CTOR["stage_rbf500"]
     seeds = sorted(set(int(v) for v in orq[orq[:, 2] == 1][:, 1]))
     assert len(seeds) >= 200 and min(np.diff(seeds)) >= 64
@@ -282,24 +284,29 @@ def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
             assert [int(v) for v in r[:, 1]] == (seeds if conv < 2 else seeds[:len(r)]) and len(r) >= 60
             rows[conv] = r[:, 3:6]
         n8 = len(rows[2])
-        # The device IS the oracle under the harmonic convention, seed by seed -- up to the oracle's own dependence on its
-        # host: the fixture's rows were made with one BLAS thread in the build container, and numpy's products round
-        # differently with another thread count, which moves a near-tie once in a few hundred traces (image 3, seed 179463:
-        # the oracle on the GPU host equals the device, iteration by iteration -- tools/dbg_t3_seed.py -- and not its own
-        # fixture row).  So: at most 3 of the 240 traces may differ from the fixture, and on each of those the oracle run
-        # HERE (default threads, or one thread) must give the device's numbers.
-        bad = [int(v) for v in np.unique(np.argwhere(dev != rows[1])[:, 0])]
-        assert len(bad) <= 3, bad
-        for k in bad:
-            from threadpoolctl import threadpool_limits
-            live = []
-            for lim in (None, 1):
-                with threadpool_limits(limits=lim):
-                    et_o, _, info = orc.trace(init, np.asarray(grad, dtype=np.float64), seed=seeds[k], sign_convention="harmonic", **kwb)
-                live.append([info["n_iter"], amd.gpet_utils.trace_MSE(et_o, truth), amd.gpet_utils.trace_dicecoef(et_o, truth)])
-            print("image seed %d, RNG seed %d: device %s, fixture %s, oracle here %s" % (img_seed, seeds[k], dev[k].tolist(), rows[1][k].tolist(), live))
-            assert any(np.array_equal(dev[k], np.array(v)) for v in live), (seeds[k], dev[k], live)
-        report.setdefault("traces_not_equal_to_the_fixture_row", {})[str(img_seed)] = [seeds[k] for k in bad]
+        # The device IS the oracle under the harmonic convention, seed by seed, with NO exception on every seed whose trace the
+        # oracle's own arithmetic decides: the fixture holds the harmonic rows with one (the oracle's pinned default), two
+        # and four BLAS threads -- the oracle perturbed by nothing but another partition of its dot products and another draw
+        # of LAPACK's noise in the ~430 numerically-zero singular directions (~1e-6 px each, ~1e-7 relative on a curve's cost).
+        # Where the three agree (479 of 480 traces here) the device must give exactly that row.  Where they do not, the trace
+        # hangs on a near-tie below that noise (image 3, seed 179463: two costs 6e-7 apart at the N_keep cut of iteration 9)
+        # and the device must give one of the oracle's answers.
+        alt = {}
+        for conv in (3, 4):
+            rr = orq[(orq[:, 0] == img_seed) & (orq[:, 2] == conv)]
+            rr = rr[np.argsort(rr[:, 1])]
+            assert [int(v) for v in rr[:, 1]] == seeds
+            alt[conv] = rr[:, 3:6]
+        decided = np.all(rows[1] == alt[3], axis=1) & np.all(rows[1] == alt[4], axis=1)
+        assert decided.sum() >= len(seeds) - 3, int(decided.sum())
+        same = np.all(dev == rows[1], axis=1)
+        assert np.all(same[decided]), [seeds[k] for k in np.nonzero(~same & decided)[0]]
+        for k in np.nonzero(~decided)[0]:
+            print("image seed %d, RNG seed %d is undecided in the oracle itself: 1 / 2 / 4 BLAS threads %s / %s / %s; device %s"
+                  % (img_seed, seeds[k], rows[1][k].tolist(), alt[3][k].tolist(), alt[4][k].tolist(), dev[k].tolist()))
+            assert any(np.array_equal(dev[k], v[k]) for v in (rows[1], alt[3], alt[4])), (seeds[k], dev[k])
+        report.setdefault("seeds_the_oracle_itself_leaves_undecided", {})[str(img_seed)] = [seeds[k] for k in np.nonzero(~decided)[0]]
+        report.setdefault("device_equals_the_oracle_on_decided_seeds", {})[str(img_seed)] = "%d of %d" % (int(same[decided].sum()), int(decided.sum()))
         sd, s0, s2 = summary(dev), summary(rows[0]), summary(rows[2])
         report["images"][str(img_seed)] = {"device = oracle, harmonic signs": sd, "oracle = reference, LAPACK signs, 1 BLAS thread": s0,
                                            "oracle, LAPACK signs, 8 BLAS threads": s2,
@@ -320,7 +327,7 @@ def test_t3_quality_distribution_vs_reference(amd, ctx, golden):
     lut = {(int(r[0]), int(r[1])): r[3:] for r in orq if int(r[2]) == 0}
     assert len(ref) >= 100 and all(np.array_equal(lut[(int(r[0]), int(r[1]))], r[2:]) for r in ref)
     out = os.environ.get("GPET_T3_OUT", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
-                                                     "r04_t3_quality.json"))
+                                                     "r05_t3_quality.json"))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump(report, f, indent=1)

@@ -22,6 +22,6 @@ et = tr()
 print("device: %d iterations, MSE %.6f" % (tr._n_iter, amd.gpet_utils.trace_MSE(et, truth)))
 for lim in (1, 2, 4, 8, None):
     with threadpool_limits(limits=lim):
-        et_o, _, info = orc.trace(init, np.asarray(grad, dtype=np.float64), seed=seed, sign_convention="harmonic", _pinned=True, **README_KW)
+        et_o, _, info = orc.trace(init, np.asarray(grad, dtype=np.float64), seed=seed, sign_convention="harmonic", blas_threads=None, **README_KW)
     print("oracle, %s BLAS thread(s): %d iterations, MSE %.6f, equal to the device: %s"
           % (lim, info["n_iter"], amd.gpet_utils.trace_MSE(et_o, truth), np.array_equal(et, et_o)))
