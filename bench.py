@@ -153,6 +153,107 @@ def timed_steps(tracers, n_steps, depth, executor, fit_walls, loop_walls=None):
     return sum(map(sum, lw)) / W, sum(map(sum, fw)) / W, iters_, traces_
 
 
+def job_ms(objs, pool, reps=4):
+    """Wall time (ms, median of `reps` after one warm-up) of ONE job: every batch object in `objs` traces its edges once --
+    reset -> device loop -> converged fits -- all of them in flight together, one host thread and one HIP stream each."""
+    def one(o):
+        o.reset()
+        return o.finish(o.run_loop())
+    ts = []
+    for _ in range(reps + 1):
+        for o in objs:
+            o._ctx.sync()
+        ta = time.time()
+        list(pool.map(one, objs))
+        for o in objs:
+            o._ctx.sync()
+        ts.append(1e3 * (time.time() - ta))
+    return float(np.median(ts[1:])) if reps > 0 else ts[0]
+
+
+def config4_literal(pkg, L, dev_index, make_tracer, seeds, n_total=256, n_gpus=8):
+    """BASELINE config 4 AS STATED -- 256 independent 500x500 edges over 8 GPUs -- the way it would run: the whole job on one
+    GPU as k batch objects in flight (k = 1, 4, 8: a job of 256 edges is small enough for the tail of one loop to leave the
+    GPU idle, several smaller loops fill it), and the per-GPU share of 256 / 8 = 32 edges as 1 x 32, 2 x 16 and 4 x 8
+    objects in flight.  predicted_speedup_8_gpus = best t(256) / best t(32): what eight GPUs can reach on that job (no
+    collective on the path; the broadcast of the 1 MB image is bcast_grad_ms at N > 1)."""
+    from concurrent.futures import ThreadPoolExecutor
+    share = n_total // n_gpus
+    pool = ThreadPoolExecutor(max_workers=8)
+    ctxs = [L.Context(dev_index) for _ in range(8)]
+    out = {"edges": n_total, "gpus": n_gpus, "share_edges": share, "whole_job_ms": {}, "share_ms": {}}
+
+    def split(n, k):
+        objs, per = [], n // k
+        for j in range(k):
+            objs.append(make_tracer(per, ctxs[j], sds=seeds[j * per:(j + 1) * per]))
+        return objs
+    for k in (1, 4, 8):
+        objs = split(n_total, k)
+        out["whole_job_ms"]["%d x %d" % (k, n_total // k)] = job_ms(objs, pool)
+        for o in objs:
+            o._batch.close()
+    for k in (1, 2, 4):
+        objs = split(share, k)
+        out["share_ms"]["%d x %d" % (k, share // k)] = job_ms(objs, pool)
+        for o in objs:
+            o._batch.close()
+    pool.shutdown()
+    out["best_whole_job_ms"] = min(out["whole_job_ms"].values())
+    out["best_share_ms"] = min(out["share_ms"].values())
+    out["predicted_speedup_8_gpus"] = out["best_whole_job_ms"] / out["best_share_ms"]
+    out["note"] = ("one job = every object traces its edges once (device loop + converged fits), all objects in flight together, "
+                   "median of 4; constructor excluded; the same seeds however the edges are split")
+    return out
+
+
+def readme_literal(pkg, L, dev_index, ctx, init, grad, seeds, with_cpu=True):
+    """The README's own call (README.md:75-76) predates the pixel_thresh parameter: its positional arguments bind seed = 1 to
+    pixel_thresh (clamped to 2), return_std = True to seed (= 1) and fix_endpoints to return_std (quirk Q6) -- 29 iterations
+    instead of 14.  One edge (latency), a batch of 1 024 edges (three objects in flight) and one trace of the CPU port."""
+    from concurrent.futures import ThreadPoolExecutor
+    kw = dict(README_KW)
+    kw["pixel_thresh"] = 2
+    one = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **kw, _ctx=ctx)
+    one()
+    one.reset()
+    runs = []
+    for _ in range(5):
+        ts = time.time()
+        one()
+        runs.append(time.time() - ts)
+        one.reset()
+    iters_one = list(one.timings["iters"])
+    one._batch.close()
+    E = 1024
+    objs = [pkg.GP_Edge_Tracing_Batch([init] * E, grad, seeds[:E] if k == 0 else [sd + 7 * k for sd in seeds[:E]], **kw,
+                                      _ctx=(ctx if k == 0 else L.Context(dev_index))) for k in range(3)]
+    pool = ThreadPoolExecutor(max_workers=3)
+    t_job = job_ms(objs, pool, reps=3)
+    its = sorted(set(objs[0]._iters()))
+    for o in objs:
+        o._batch.close()
+    pool.shutdown()
+    out = dict(config="README.md:75-76 as written: pixel_thresh = 2 (Q6), seed = 1; otherwise the headline's edge",
+               single_edge_ms_per_trace=1e3 * float(np.median(runs)), single_edge_iterations=iters_one,
+               batch_traces_per_s=3 * E / (1e-3 * t_job), batch_ms_per_1024=t_job / 3, batch_iterations=[its[0], its[-1]],
+               note="batch: three objects of 1 024 edges in flight, each one whole trace (loop + converged fits), median of 3 jobs")
+    if with_cpu:
+        from oracle import gpet_oracle as orc
+        from threadpoolctl import threadpool_limits
+        img, edge = orc.synth_sinusoid_image(grad.shape[0], 3)
+        g_o = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+        i_o = edge[[0, -1], :][:, [1, 0]]
+        with threadpool_limits(limits=1):
+            t0 = time.time()
+            _, _, info = orc.trace(i_o, g_o, per_curve=True, seed=1, **kw)
+            dt = time.time() - t0
+        out["cpu_port"] = dict(s_per_trace=dt, traces_per_s=1.0 / dt, iterations=info["n_iter"], cores=1,
+                               note="oracle/gpet_oracle.py, one BLAS thread, one trace, constructor included")
+        out["batch_speedup_vs_cpu_port"] = out["batch_traces_per_s"] * dt
+    return out
+
+
 def secondary_config3(pkg, ctx, n_edges=1):
     """BASELINE config 3's shape: 2048x2048 image, 1498 observations (+2 inits = 1500 training points), N_samples=4000:
     ms of one GP iteration (fit + predict + covariance, factor, sample GEMM) and of the scoring, per stage, timed with
@@ -407,6 +508,36 @@ def main():
     total_traces = E * world * args.steps
     value = total_traces / elapsed
 
+    # ---- N > 1: BASELINE config 4 as stated (256 edges over the ranks) measured for real: every rank traces its 256 / world
+    #      edges -- as 1, 2 or 4 objects in flight, the best of them -- between two barriers; the job is the slowest rank's time
+    c4_measured = None
+    if dist is not None and world > 1 and 256 % world == 0:
+        from concurrent.futures import ThreadPoolExecutor as _TPE
+        share = 256 // world
+        pool4 = _TPE(max_workers=4)
+        best = None
+        for k in (1, 2, 4):
+            if share % k or share // k < 1:
+                continue
+            per = share // k
+            objs = [make_tracer(per, tracers[j]._ctx, sds=[1 + SEED_STRIDE * (rank * share + j * per + e) for e in range(per)]) for j in range(k)]
+            job_ms(objs, pool4, reps=1)  # (warm-up)
+            barrier()
+            ta = time.time()
+            job_ms(objs, pool4, reps=0)
+            barrier()
+            tj = torch.tensor([time.time() - ta], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tj, op=dist.ReduceOp.MAX)
+            for o in objs:
+                o._batch.close()
+            if best is None or float(tj.item()) < best[0]:
+                best = (float(tj.item()), k)
+        pool4.shutdown()
+        if best is not None:
+            c4_measured = dict(edges=256, ranks=world, share_edges=share, job_ms=1e3 * best[0], objects_in_flight_per_rank=best[1],
+                               traces_per_s=256 / best[0],
+                               note="BASELINE config 4 as stated, strong scaling: max over ranks between two barriers, best of 1 / 2 / 4 "
+                                    "objects in flight per rank; compare with secondary.config4_literal.best_whole_job_ms of the N = 1 line")
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -560,6 +691,13 @@ def main():
         secondary["config5"] = secondary_config5(pkg, ctx)
         log("secondary: config 5 %.2f frames/s (8 chains), single chain %.3f s per frame"
             % (secondary["config5"]["frames_per_s"], secondary["config5"]["single_chain_s_per_frame"]))
+        secondary["config4_literal"] = config4_literal(pkg, L, dev_index, make_tracer, seeds)
+        log("secondary: config 4 as stated: 256 edges %s ms, 32-edge share %s ms -> predicted %.2f x on 8 GPUs"
+            % (secondary["config4_literal"]["whole_job_ms"], secondary["config4_literal"]["share_ms"],
+               secondary["config4_literal"]["predicted_speedup_8_gpus"]))
+        secondary["readme_literal"] = readme_literal(pkg, L, dev_index, ctx, init, grad, seeds, with_cpu=not args.no_cpu_baseline)
+        log("secondary: README-literal call (pixel_thresh 2): single edge %.2f ms, batch %.0f traces/s"
+            % (secondary["readme_literal"]["single_edge_ms_per_trace"], secondary["readme_literal"]["batch_traces_per_s"]))
 
     # ---- one step alone (nothing else on the GPU): device time of the LML kernel launches of its converged fits,
     #      hipEvents around every launch on the fit stream (gpet_lml_stats)
@@ -729,7 +867,7 @@ def main():
                          "note": "wall times of a step's device loop and converged fits while the other objects' steps run beside them"},
         "single_edge": {"traces_per_s": 1.0 / single_s, "ms_per_trace": 1e3 * single_s,
                         "runs_ms": [round(1e3 * v, 3) for v in single_runs], "note": "median of five traces of one edge"},
-        "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b,
+        "trace_mse_vs_truth": mse, "bcast_grad_ms": 1e3 * t_b, "config4_literal_measured": c4_measured,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     if cpu:
