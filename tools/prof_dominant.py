@@ -1,7 +1,7 @@
 """Runs the dominant loop kernel alone, at bench.py's mid-trace state, for a rocprofv3 --kernel-trace run:
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_dom -- python3 tools/prof_dominant.py 256 122 20
-    python tools/summarise_trace.py gpurun_out/prof_dom k_jacobi_lds 20 profiles/r03_dominant_kernel.json
+    python tools/summarise_trace.py gpurun_out/prof_dom gpet::k_jacobi_ahead 20 profiles/r05_dominant_kernel.json
 
 (stage id as in include/gpet_hip.h; the last `reps` launches of the trace are the profiled ones)."""
 import sys, os

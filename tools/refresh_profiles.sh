@@ -1,11 +1,11 @@
 #!/bin/bash
-# Regenerates profiles/<round>_* on the GPU box (run through gpurun from the repo root; round tag = $2, default r04):
+# Regenerates profiles/<round>_* on the GPU box (run through gpurun from the repo root; round tag = $2, default r05):
 #   bench line, rocprofv3 --kernel-trace --stats of the same command, the dominant kernel alone, PMC traffic.
 # Every rocprofv3 pass is its own run (PMC passes never share a run with a trace), program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 E=${1:-1024}
-R=${2:-r04}
+R=${2:-r05}
 O=gpurun_out/prof
 rm -rf $O gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 mkdir -p $O
@@ -49,10 +49,12 @@ cp $O/pmc_rng4.log gpurun_out/profiles_new/${R}_k_mt_normals4_counters.txt
 DOM=$(grep '^{' $O/bench.json | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel'])")
 echo "dominant kernel: $DOM"
 if [ "$DOM" = "k_lml" ]; then
-  NL=$(python3 -c "import csv,glob; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum('k_lml' in r['Kernel_Name'] for r in csv.DictReader(open(f)))//3)")
-  python3 tools/summarise_trace.py $O/lml_trace k_lml $NL gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the LML launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
+  # the objective kernel of the bench's batches is gpet::k_lml16 (exact name: k_lml16_fit and the register-tile kernel k_lml are
+  # other kernels); the last third of its launches = the last of prof_final.py's three repetitions
+  NL=$(python3 -c "import csv,glob,re; f=glob.glob('$O/lml_trace/*/*_kernel_trace.csv')[0]; print(sum(re.sub(r'^void\\s+','',r['Kernel_Name'].strip('\"')).split('(')[0].split('<')[0]=='gpet::k_lml16' for r in csv.DictReader(open(f)))//3)")
+  python3 tools/summarise_trace.py $O/lml_trace gpet::k_lml16 $NL gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace of tools/prof_final.py $E 0: the gpet::k_lml16 launches of one batch's converged fits ($E edges x 13 restarts), nothing else on the GPU"
 else
-  python3 tools/summarise_trace.py $O/stage_trace $DOM 5 gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
+  python3 tools/summarise_trace.py $O/stage_trace gpet::$DOM 5 gpurun_out/profiles_new/${R}_dominant_kernel.json "rocprofv3 --kernel-trace --stats of tools/prof_stages.py $E 5: the kernel alone on $E edges at the bench's mid-trace state (7 iterations in)"
 fi
 rm -rf $O/bench_trace $O/stage_trace $O/lml_trace $O/eig_trace $O/c3_trace $O/se_trace gpurun_out/pmc_l16 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_lml_f gpurun_out/pmc_lml_w
 ls -la gpurun_out/profiles_new
