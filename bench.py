@@ -28,9 +28,9 @@ STAGES = ["fit_predict_cov", "factor", "normals", "sample_gemm", "score_topk", "
 # gpet_profile_stage ids of the single kernels of one iteration (include/gpet_hip.h)
 # structured loop path (prior eigenbasis; what gpet_trace_iterate runs for on-grid batches): 120-123;
 # generic path (per-stage API, off-grid observations, option struct_path = 0): 100-113
-KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_seat", 123: "k_struct_rows"}
+KERNEL_IDS_STRUCT = {120: "k_fit", 121: "k_struct_H", 122: "k_jacobi_ahead", 123: "k_struct_rows"}
 KERNEL_IDS_GENERIC = {100: "k_fit", 101: "k_predict", 102: "k_cov_mfma", 110: "k_pchol_reg", 111: "k_gram",
-                      112: "k_jacobi_seat", 113: "k_factor_rows"}
+                      112: "k_jacobi_ahead", 113: "k_factor_rows"}
 KERNEL_IDS_COMMON = {130: "k_sample_gemm_mfma_r", 140: "k_score", 141: "k_topk", 150: "k_kde_prep",
                      151: "k_kde_fused", 160: "k_pix_columns"}  # (152 k_kde_normalise: stage API only; the loop normalises inside the pixel kernels)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -750,7 +750,7 @@ def main():
         "k_gram": dict(flops=1.0 * r * r * Lg, bytes=8.0 * (r * Lg + r * r)),
         "k_factor_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
         "k_struct_H": dict(flops=1.0 * n_ * n_ * r + 2.0 * r * r * n_ + 2.0 * r * Lg, bytes=8.0 * (n_ * n_ / 2 + r * r + r * Lg)),
-        "k_jacobi_seat": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
+        "k_jacobi_ahead": dict(flops=6.0 * sweeps_mid * r ** 3, bytes=8.0 * (3 * r * r)),
         "k_struct_rows": dict(flops=2.0 * r * r * Lg, bytes=8.0 * (2 * r * Lg + r * r)),
         "k_sample_gemm_mfma_r": dict(flops=2.0 * S * Lg * r, bytes=8.0 * (S * r + r * Lg + S * Lg)),
         "k_score": dict(flops=60.0 * S * Lg, bytes=8.0 * S * Lg + 4.0 * M_ * N),
@@ -813,7 +813,7 @@ def main():
                     launches_per_step=(lml["launches"] if dom == "k_lml" else iters_per_trace),
                     device_ms_per_step={k: v for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
                     note=("f64 vector/matrix peak (equal on MI355X); this kernel is an LDS-resident eigen-solver: its practical "
-                          "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_seat" else
+                          "bound is LDS store bandwidth and barrier latency, see DESIGN.md section 6" if dom == "k_jacobi_ahead" else
                           ("bound by the samples it stores (8 S Lg bytes per edge = 4.1 GB per launch, rows padded to 128 bytes): a kernel "
                            "that ONLY stores them in the same row-tile shape takes 1.13-1.19 ms = 3.4-3.6 TB/s "
                            "(profiles/r03_gemm_store_counters.txt, tools/ubench/hbm_write.hip) -- the one store-only ceiling, also quoted in "

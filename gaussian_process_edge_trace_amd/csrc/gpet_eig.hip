@@ -823,74 +823,108 @@ __device__ __forceinline__ int oj_row(int bI, int bJ, int t) { return t < OJ_B ?
 
 // rotation (c, s) that annihilates the coupling apq of a symmetric 2x2 block [app apq; apq aqq]: the smaller angle
 // (c >= 1/sqrt 2).  With rho = sqrt(d^2 + 4 apq^2), d = aqq - app:  c^2 = (rho + |d|) / (2 rho),
-// s = +-apq / (rho c)  -- two reciprocal square roots (hardware seed + two Newton steps each), no division.
+// s = +-apq / (rho c)  -- two reciprocal square roots (hardware seed + two Newton steps each), no division.  Branchless:
+// the "nothing to rotate" test selects at the end (a dependent f64 instruction costs 8.4 cycles and an exec-mask branch as
+// much again: tools/ubench/f64_chain.hip, jac_params_chain.hip; this chain is the inner round's critical path).
 __device__ __forceinline__ void oj_rotation(double app, double apq, double aqq, double& c, double& s, double& rel2) {
-  c = 1.0;
-  s = 0.0;
   const double den = fabs(app * aqq), num = apq * apq;
   rel2 = den > 0.0 ? num * __builtin_amdgcn_rcp(den) : 0.0;  // (hardware reciprocal: a convergence measure, not arithmetic)
-  if (num > 1e-34 * den && fabs(apq) > 1e-300) {
-    const double d = aqq - app, hh = 2.0 * apq;
-    const double rho2 = d * d + hh * hh;
-    double y = __builtin_amdgcn_rsq(rho2);  // 1 / rho
-    y = y * (1.5 - 0.5 * rho2 * y * y);
-    y = y * (1.5 - 0.5 * rho2 * y * y);
-    const double x = 0.5 + 0.5 * fabs(d) * y;  // c^2 in [1/2, 1]
-    double z = __builtin_amdgcn_rsq(x);        // 1 / c
-    z = z * (1.5 - 0.5 * x * z * z);
-    z = z * (1.5 - 0.5 * x * z * z);
-    c = x * z;
-    s = (d >= 0.0 ? hh : -hh) * (0.5 * y) * z;
-  }
+  const bool on = num > 1e-34 * den && fabs(apq) > 1e-300;
+  const double d = aqq - app, hh = 2.0 * apq;
+  const double rho2 = d * d + hh * hh;
+  double y = __builtin_amdgcn_rsq(rho2);  // 1 / rho
+  y = y * (1.5 - 0.5 * rho2 * y * y);
+  y = y * (1.5 - 0.5 * rho2 * y * y);
+  const double x = 0.5 + 0.5 * fabs(d) * y;  // c^2 in [1/2, 1]
+  double z = __builtin_amdgcn_rsq(x);        // 1 / c
+  z = z * (1.5 - 0.5 * x * z * z);
+  z = z * (1.5 - 0.5 * x * z * z);
+  c = on ? x * z : 1.0;
+  s = on ? (d >= 0.0 ? hh : -hh) * (0.5 * y) * z : 0.0;
 }
 
-// One cyclic sweep (15 rounds of 8 disjoint rotations) on the symmetric 16x16 matrix s_C, executed by ONE wave:
-// lane = 2x2 block (a_, b_) of the current pairing, upper triangle of blocks active, mirrored writes; the accumulated
-// rotation goes to s_R (s_R <- s_R J).  Wave-synchronous LDS traffic only -- no workgroup barrier inside.
-__device__ __forceinline__ double oj_inner_sweep(double (*s_C)[OJ_M + 1], double (*s_R)[OJ_M + 1], int lane) {
+// One cyclic sweep (15 rounds of 8 disjoint rotations) on the symmetric 16x16 matrix s_C, executed by ONE wave: lane = 2x2
+// block (a_, b_) of the pairing, upper triangle of blocks active, mirrored writes; the accumulated rotation goes to s_R
+// (s_R <- s_R J).  Wave-synchronous LDS traffic only -- no workgroup barrier inside.
+// SEATED (round 5; the scheme of k_jacobi_seat): the matrix is addressed by seat, not by player -- the players of pair k
+// always sit in seats 2 k and 2 k + 1, and after a round everybody on the circle moves one seat on (the circle method of
+// oj_rr_pair: the same pairs in the same order).  A lane's block, its two pairs' diagonal blocks and its two rows of s_R
+// are then at FIXED addresses (four ds_read2_b64 + four more for the diagonals and s_R instead of fourteen reads at
+// addresses recomputed every round), and its results go to fixed places of the next round's layout, computed once per
+// kernel (OjSeat).  After the 15 rounds everybody is back in the seat he started from.  The callers keep s_C and s_R in
+// SEAT order (oj_seat_of: local row -> seat): 21.5 k -> ~8 k cycles per sweep, which was 42 % of a pair slot.
+__device__ __forceinline__ int oj_seat_of(int t) { return t < 8 ? 2 * t : 31 - 2 * t; }  // local row 0..15 -> its seat in round 0
+__device__ __forceinline__ int oj_seat_next(int slot) {  // where the player of `slot` sits next round (16 players, 15 rounds)
+  const int k = slot >> 1;
+  if (slot == 1) return 1;  // the pivot
+  int seat = (slot & 1) ? 15 - k : k;
+  seat = seat == 0 ? 14 : seat - 1;
+  if (seat == 0) return 0;
+  return seat < 8 ? 2 * seat : 2 * (15 - seat) + 1;
+}
+struct OjSeat {  // per-lane element offsets into s_C / s_R (row stride OJ_M + 1)
+  int rc, rda, rdb, rr;  // reads: the lane's block, the diagonal blocks of its row / column pair, its two rows of s_R
+  int wc[4], wm[4], wr[2];  // writes: the block's four entries, their mirror images, the two columns of s_R
+  bool act, offd;
+};
+__device__ __forceinline__ void oj_seat_init(OjSeat& T, int lane) {
+  constexpr int ld = OJ_M + 1;
+  const int a_ = lane >> 3, b_ = lane & 7, i0 = lane >> 3;
+  T.act = a_ <= b_;
+  T.offd = a_ != b_;
+  T.rc = 2 * a_ * ld + 2 * b_;
+  T.rda = 2 * a_ * ld + 2 * a_;
+  T.rdb = 2 * b_ * ld + 2 * b_;
+  T.rr = i0 * ld + 2 * b_;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i2 = oj_seat_next(2 * a_ + (q >> 1)), j2 = oj_seat_next(2 * b_ + (q & 1));
+    T.wc[q] = i2 * ld + j2;
+    T.wm[q] = j2 * ld + i2;
+  }
+  T.wr[0] = i0 * ld + oj_seat_next(2 * b_);
+  T.wr[1] = i0 * ld + oj_seat_next(2 * b_ + 1);
+}
+__device__ __forceinline__ double oj_inner_sweep(double (*s_C)[OJ_M + 1], double (*s_R)[OJ_M + 1], const OjSeat& T) {
+  constexpr int ld = OJ_M + 1;
   double mr = 0.0;  // largest squared relative coupling rotated away (this lane's pairs)
-  const int a_ = lane >> 3, b_ = lane & 7;
-  const bool act = a_ <= b_;
-  const int i0 = lane >> 3;
+  double* C = &s_C[0][0];
+  double* R = &s_R[0][0];
+#pragma unroll 1
   for (int rnd = 0; rnd < OJ_M - 1; ++rnd) {
-    int pa, qa, pb, qb;
-    oj_rr_pair(OJ_M - 1, rnd, a_, pa, qa);
-    oj_rr_pair(OJ_M - 1, rnd, b_, pb, qb);
-    // both rotations of this lane's block are computed here (two independent dependency chains that interleave: the
-    // same latency as one, and no cross-lane traffic); lanes that share a pair compute identical values
+    // every read of the round first; both rotations of this lane's block are computed here (two independent dependency
+    // chains that interleave: the same latency as one, and no cross-lane traffic); lanes that share a pair compute
+    // identical values
+    const double a00 = C[T.rda], a01 = C[T.rda + 1], a11 = C[T.rda + ld + 1];
+    const double d00 = C[T.rdb], d01 = C[T.rdb + 1], d11 = C[T.rdb + ld + 1];
+    const double b00 = C[T.rc], b01 = C[T.rc + 1], b10 = C[T.rc + ld], b11 = C[T.rc + ld + 1];
+    const double r0p = R[T.rr], r0q = R[T.rr + 1], r1p = R[T.rr + 8 * ld], r1q = R[T.rr + 8 * ld + 1];
     double ca, sa, cb, sb, ra2, rb2;
-    oj_rotation(s_C[pa][pa], s_C[pa][qa], s_C[qa][qa], ca, sa, ra2);
-    oj_rotation(s_C[pb][pb], s_C[pb][qb], s_C[qb][qb], cb, sb, rb2);
+    oj_rotation(a00, a01, a11, ca, sa, ra2);
+    oj_rotation(d00, d01, d11, cb, sb, rb2);
     mr = rb2 > mr ? rb2 : mr;  // (every pair is some lane's b_)
     (void)ra2;
-    double n00 = 0.0, n01 = 0.0, n10 = 0.0, n11 = 0.0;
-    if (act) {
-      const double b00 = s_C[pa][pb], b01 = s_C[pa][qb], b10 = s_C[qa][pb], b11 = s_C[qa][qb];
-      const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
-      const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
-      n00 = ca * t00 - sa * t10;
-      n10 = sa * t00 + ca * t10;
-      n01 = ca * t01 - sa * t11;
-      n11 = sa * t01 + ca * t11;
-    }
-    const double r0p = s_R[i0][pb], r0q = s_R[i0][qb], r1p = s_R[i0 + 8][pb], r1q = s_R[i0 + 8][qb];
+    const double t00 = cb * b00 - sb * b01, t01 = sb * b00 + cb * b01;
+    const double t10 = cb * b10 - sb * b11, t11 = sb * b10 + cb * b11;
+    const double n00 = ca * t00 - sa * t10, n10 = sa * t00 + ca * t10;
+    const double n01 = ca * t01 - sa * t11, n11 = sa * t01 + ca * t11;
     __builtin_amdgcn_wave_barrier();  // every read of this round precedes its writes
-    if (act) {
-      s_C[pa][pb] = n00;
-      s_C[qa][pb] = n10;
-      s_C[pa][qb] = n01;
-      s_C[qa][qb] = n11;
-      if (a_ != b_) {
-        s_C[pb][pa] = n00;
-        s_C[pb][qa] = n10;
-        s_C[qb][pa] = n01;
-        s_C[qb][qa] = n11;
+    if (T.act) {
+      C[T.wc[0]] = n00;
+      C[T.wc[1]] = n01;
+      C[T.wc[2]] = n10;
+      C[T.wc[3]] = n11;
+      if (T.offd) {
+        C[T.wm[0]] = n00;
+        C[T.wm[1]] = n01;
+        C[T.wm[2]] = n10;
+        C[T.wm[3]] = n11;
       }
     }
-    s_R[i0][pb] = cb * r0p - sb * r0q;
-    s_R[i0][qb] = sb * r0p + cb * r0q;
-    s_R[i0 + 8][pb] = cb * r1p - sb * r1q;
-    s_R[i0 + 8][qb] = sb * r1p + cb * r1q;
+    R[T.wr[0]] = cb * r0p - sb * r0q;
+    R[T.wr[1]] = sb * r0p + cb * r0q;
+    R[T.wr[0] + 8 * ld] = cb * r1p - sb * r1q;
+    R[T.wr[1] + 8 * ld] = sb * r1p + cb * r1q;
     __builtin_amdgcn_wave_barrier();
   }
   return mr;
@@ -985,6 +1019,8 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
   __shared__ double s_R[OJ_M][OJ_M + 1];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
+  OjSeat seat;  // (the inner sweep's per-lane addresses: once per kernel)
+  oj_seat_init(seat, lane);
   const int nch = (Lg + 15) >> 4;  // 16-column chunks = 16-column tiles of the update below
   const int ldx = ((Lg + 31) & ~31) + 2;
   double v[STAGED ? 16 : 1][4];
@@ -1084,7 +1120,7 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
   __syncthreads();
   {
     const int i = tid >> 4, j = tid & 15;
-    s_C[i][j] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);
+    s_C[oj_seat_of(i)][oj_seat_of(j)] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);  // (seat order: oj_inner_sweep)
   }
   __syncthreads();
   __shared__ int s_skip;
@@ -1095,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
     if (skip) {
       if (lane == 0 && mr0 > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr0));
     } else {
-      oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+      oj_report(oj_inner_sweep(s_C, s_R, seat), lane, st);
     }
   }
   __syncthreads();
@@ -1104,7 +1140,7 @@ __global__ void __launch_bounds__(256) k_oj_round(OjArgs args, EdgeDev* edges, i
   {
     double ra[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_krow(jj, lg)][lr];  // A[M = a = lr][K -> row b]
+    for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_seat_of(oj_krow(jj, lg))][oj_seat_of(lr)];  // A[M = a = lr][K -> row b] (s_R is in seat order)
     double* xo[4];
     bool vo[4];
 #pragma unroll
@@ -1229,6 +1265,8 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
+  OjSeat seat;  // (the inner sweep's per-lane addresses: once per kernel)
+  oj_seat_init(seat, lane);
   const int nch = (Lg + 15) >> 4;
   const int ldx = ((Lg + 31) & ~31) + 2;
   const int kmax = nch * 16;
@@ -1268,44 +1306,57 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
       int bI, bJ;
       oj_rr_pair(nblk - 1, round, slot, bI, bJ);
       if (bI * OJ_B < rank) {  // (bI < bJ: otherwise both blocks are empty)
-        // -- stage.  Even widths: thread t takes the column PAIRS 2 t, 2 t + 512 of every row as 16-byte agent-scope loads
-        //    (global_load_dwordx4 ... sc1: __hip_atomic_load has no 16-byte form, so the loads and their wait are inline
-        //    assembly -- the wait names every destination register, so nothing that uses one can be scheduled above it):
-        //    half the load instructions and requests of the 8-byte form, which was 35 % of a slot's time.
-        //    Odd widths: thread t takes columns t, t + 256, ... of every row.
+        // -- stage + Gram matrix.  Even widths: thread t takes the column PAIRS 2 t, 2 t + 512 of every row as 16-byte
+        //    agent-scope loads -- raw buffer loads with the sc1 policy (__hip_atomic_load has no 16-byte form; the builtin is one
+        //    the compiler's wait-count insertion tracks, unlike round 4's inline assembly, and a dead row or a column beyond
+        //    the edge is simply an offset beyond the buffer: it reads zero, no branch).  All 32 loads of a thread are issued at
+        //    once, columns [0, 512) first: the Gram matrix of that half runs on the matrix cores while the other half is still
+        //    in flight (a slot's staging is bound by what ONE CU pulls from beyond its XCD's L2, ~15 k cycles for 128 KB;
+        //    the Gram products are 8 k).  Same chunks per wave in the same order as one pass over all columns: the same bits.
+        //    Odd widths: thread t takes columns t, t + 256, ... of every row, one pass.
+        v4f64e acc[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+        const double* xr = s_X + lr * ldx + lg;
+        auto gram_chunks = [&](int c_lo, int c_hi) {  // 16-column chunks c_lo + w + 4 u + 16 k < c_hi of this wave
+          for (int ch0 = c_lo + w; ch0 < c_hi; ch0 += 16) {
+            double x[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < c_hi) ? xr[(ch0 + 4 * u) * 16 + 4 * jj] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][jj], x[u][jj], acc[jj], 0, 0, 0);
+          }
+        };
         if ((Lg & 1) == 0) {
           typedef double oj_d2 __attribute__((ext_vector_type(2)));
-          oj_d2 qv[16][2];
+          typedef unsigned int oj_u4 __attribute__((ext_vector_type(4)));
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)D.G, 0, (int)((size_t)D.r_cap * (size_t)Lg * sizeof(double)), 0x00020000);
+          oj_u4 qv[2][16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int gi = oj_row(bI, bJ, r);
-            const bool live = gi < rank;
-            gi = gi < D.r_cap ? gi : D.r_cap - 1;
-            const double* __restrict__ xrow = D.G + (size_t)gi * Lg;
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int k = 2 * tid + 512 * i;
-              qv[r][i] = (oj_d2){0.0, 0.0};
-              if (live && k < Lg) {
-                const double* p = xrow + k;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(qv[r][i]) : "v"(p) : "memory");
-              }
+            for (int r = 0; r < 16; ++r) {
+              const int gi = oj_row(bI, bJ, r), k = 2 * tid + 512 * i;
+              const unsigned int off = (gi < rank && k < Lg) ? (unsigned int)(((size_t)gi * Lg + k) * sizeof(double)) : 0xFFFFFFF0u;
+              qv[i][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);  // (aux 16 = sc1: agent scope)
             }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && Lg <= 512) break;  // (uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int k = 2 * tid + 512 * h;
+              if (k < kmax) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + k]) = __builtin_bit_cast(oj_d2, qv[h][r]);
+            }
+            __syncthreads();
+            OJ_T(0)
+            gram_chunks(32 * h, nch < 32 * h + 32 ? nch : 32 * h + 32);
+            OJ_T(1)
           }
-#pragma unroll
-          for (int r = 0; r < 16; r += 4)
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(qv[r][0]), "+v"(qv[r][1]), "+v"(qv[r + 1][0]), "+v"(qv[r + 1][1]), "+v"(qv[r + 2][0]), "+v"(qv[r + 2][1]),
-                           "+v"(qv[r + 3][0]), "+v"(qv[r + 3][1])
-                         :
-                         : "memory");
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int k = 2 * tid + 512 * i;
-              if (k < kmax) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + k]) = qv[r][i];
-            }
         } else {
           double v[16][4];
 #pragma unroll
@@ -1327,29 +1378,13 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
               const int k = tid + 256 * i;
               if (k < kmax) s_X[r * ldx + k] = v[r][i];
             }
+          __syncthreads();
+          OJ_T(0)
+          gram_chunks(0, nch);
+          OJ_T(1)
         }
-        __syncthreads();
-        OJ_T(0)
-        // -- Gram matrix
-        {
-          v4f64e acc[4];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[jj] = (v4f64e){0.0, 0.0, 0.0, 0.0};
-          const double* xr = s_X + lr * ldx + lg;
-          for (int ch0 = w; ch0 < nch; ch0 += 16) {
-            double x[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < nch) ? xr[(ch0 + 4 * u) * 16 + 4 * jj] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][jj], x[u][jj], acc[jj], 0, 0, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) s_part[w][lg + 4 * i][lr] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
-        }
+        for (int i = 0; i < 4; ++i) s_part[w][lg + 4 * i][lr] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
         {
           const int i = tid >> 4, j = tid & 15;
           s_R[i][j] = (i == j) ? 1.0 : 0.0;
@@ -1357,7 +1392,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
         __syncthreads();
         {
           const int i = tid >> 4, j = tid & 15;
-          s_C[i][j] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);
+          s_C[oj_seat_of(i)][oj_seat_of(j)] = (s_part[0][i][j] + s_part[1][i][j]) + (s_part[2][i][j] + s_part[3][i][j]);  // (seat order: oj_inner_sweep)
         }
         __syncthreads();
         OJ_T(1)
@@ -1368,7 +1403,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
           if (skip) {
             if (lane == 0 && mr0 > 0.0) atomicMax(&st->maxrel_bits, (unsigned long long)__double_as_longlong(mr0));
           } else {
-            oj_report(oj_inner_sweep(s_C, s_R, lane), lane, st);
+            oj_report(oj_inner_sweep(s_C, s_R, seat), lane, st);
           }
         }
         __syncthreads();
@@ -1377,7 +1412,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
         if (!s_skip) {
           double ra[4];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_krow(jj, lg)][lr];
+          for (int jj = 0; jj < 4; ++jj) ra[jj] = s_R[oj_seat_of(oj_krow(jj, lg))][oj_seat_of(lr)];  // (s_R is in seat order)
           double* xo[4];
           bool vo[4];
 #pragma unroll
