@@ -100,7 +100,6 @@ SYMBOLS = {
     "gpet_final_optimize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int32)]),
     "gpet_batch_set_sample_dtype": (C.c_int, [_P, C.c_int]),
     "gpet_batch_set_rng": (C.c_int, [_P, C.c_int]),
-    "gpet_batch_keep_samples": (C.c_int, [_P, C.c_int]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
 }
 
@@ -402,12 +401,6 @@ class Batch:
         if rng not in (None, "mt19937", "philox"):
             raise ValueError("rng must be 'mt19937' or 'philox'")
         self.ctx.check(self.lib.gpet_batch_set_rng(self.h, 1 if rng == "philox" else 0))
-
-    def keep_samples(self, on):
-        """True: every loop iteration leaves ALL posterior samples in BUF_SAMPLES also under set_option("fused_score", 1)
-        (gpet_batch_keep_samples; what ``return_lines=True`` hands back).  Without that option -- the default -- the loop
-        always stores the whole sample matrix.  Costs, best curves and traces are identical either way."""
-        self.ctx.check(self.lib.gpet_batch_keep_samples(self.h, 1 if on else 0))
 
     def set_sample_dtype(self, dtype):
         """Storage type of the posterior samples: "f64" (default, the reference's) or "f32" (gpet_batch_set_sample_dtype:

@@ -47,7 +47,6 @@ struct gpet_batch {
   long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
-  int keep_samples = 0;                // gpet_batch_keep_samples: 1 = the loop leaves the whole sample matrix behind (separate GEMM + scorer)
   int rng_mode = 0;                    // 0: MT19937 + polar method = numpy's RandomState stream; 1: Philox4x32-10 + Box-Muller (opt-in)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
   double* d_fin_stage = nullptr;       // staging of the converged fits' training sets (x | y | w blocks)
@@ -1142,12 +1141,6 @@ int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
   return GPET_OK;
 }
 
-int gpet_batch_keep_samples(gpet_batch* b, int on) {
-  if (!b) return GPET_ERR_BAD_ARG;
-  b->keep_samples = on ? 1 : 0;
-  return GPET_OK;
-}
-
 int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
   if (!b || e < 0 || e >= b->B) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
@@ -1347,13 +1340,6 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
       case 110: case 111: case 112: case 113:
         HIPCHK(c, launch_factor(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 110))); break;
       case 130: HIPCHK(c, launch_sample(c->stream, b->d_edges, b->B, b->bd, b->structured ? b->bd.r0_max : 0)); break;
-      // 131: samples scored out of the accumulators (+ the combine of the tile partials), 132: the kept rows -- the loop's form
-      case 131: case 132: {
-        const int rm = b->structured ? b->bd.r0_max : 0;
-        if (!sample_score_fused_applies(b->bd, rm)) return fail(c, GPET_ERR_UNSUPPORTED, "gpet_profile_stage: the fused sample + score kernel does not apply to this batch");
-        HIPCHK(c, launch_sample_score(c->stream, b->d_edges, b->B, b->bd, rm, stage == 131 ? 1u : 4u));
-        break;
-      }
       case 140: case 141: HIPCHK(c, launch_score(c->stream, b->d_edges, b->B, b->bd, 1u << (stage - 140))); break;
       case 150: case 151: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 1u << (stage - 150), 1)); break;
       case 152: HIPCHK(c, launch_kde(c->stream, b->d_edges, b->B, b->bd, 0, 4u, 0)); break;  // (stage-API form only)
@@ -1939,16 +1925,13 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         HIPCHK(c, launch_factor(c->stream, edges_l, B_l, b->bd, ~0u, edges_l == b->d_edges ? b->h_edges.data() : b->h_edges_act.data()));
       }
       HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_norm[cur % 16], 0));
-      // samples + scores: the GEMM writes all S rows and the scorer reads them back; or (gpet_set_option "fused_score", off
-      // by default: slower at the bench shape) one kernel scores the samples out of the matrix-core accumulators and a
-      // second one stores the n_keep best rows, where that applies (even grid lengths, rank <= 72) and nobody asked for
-      // the whole sample matrix (gpet_batch_keep_samples)
+      // samples + scores: the GEMM writes all S rows and the scorer reads them back (two fused forms that never wrote the sample
+      // matrix were built in rounds 3 and 4, bit-identical, and measured slower: an f64 matrix instruction and f64 vector
+      // work do not overlap, DESIGN.md history)
       const int rank_max = b->structured ? b->bd.r0_max : 0;
-      const bool fused = gpet_opt_fused_score() && !b->keep_samples && sample_score_fused_applies(b->bd, rank_max);
-      if (fused) HIPCHK(c, launch_sample_score(c->stream, edges_l, B_l, b->bd, rank_max));
-      else HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, rank_max));
+      HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, rank_max));
       HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
-      if (!fused) HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
+      HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
       // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
       HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
       HIPCHK(c, launch_pixels(c->stream, edges_l, B_l, b->bd, 1));

@@ -38,7 +38,6 @@ const OptionDef kDefs[] = {
     {"pcx_one_pivot", 0, 0, 1, "1: multi-workgroup pivoted Cholesky one pivot per launch (cross-check of the blocked candidate selection)"},
     {"solve_mw", 1, 0, 1, "blocked fit: alpha by one workgroup per 64-row block and direction (k_chol_solve_mw); 0: one workgroup per edge"},
     {"diag_in_syrk", 1, 0, 1, "blocked fit: the trailing update's first workgroup factors the next diagonal block; 0: a launch of its own"},
-    {"fused_score", 0, 0, 2, "sample GEMM and scorer in one kernel, the sample matrix never written: 1 = column-tile-stationary (k_sample_score, round 3: measured slower), 2 = curve-stationary (k_sample_score2, round 4)"},
     {"topk_rank", 0, 0, 1, "1: argsort of the costs by rank counting (k_topk) also where the bitonic sort applies"},
     {"struct_path", 1, 0, 1, "structured loop path (prior eigenbasis of the pixel grid) where it applies; 0: the generic kernels"},
     {"shared_basis", 1, 0, 1, "edges of one geometry share one prior eigenbasis; 0: every edge its own copy"},

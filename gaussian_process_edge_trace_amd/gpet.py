@@ -275,7 +275,6 @@ class GP_Edge_Tracing(object):
         alg_st = t.time()
         b = self._batch
         b.set_obs(0, self.obs)
-        b.keep_samples(bool(return_lines))  # (the reference's return_lines hands back every sample of every iteration)
         n_iter = 0
         while not b.scalars().done:
             if n_iter >= max_iter:

@@ -284,16 +284,6 @@ int gpet_batch_set_rng(gpet_batch* b, int mode);
  * sample_y (oracle mode sample_dtype="f32").  Call between traces, not while a loop is enqueued. */
 int gpet_batch_set_sample_dtype(gpet_batch* b, int f32);
 
-/* What gpet_trace_iterate leaves in GPET_BUF_SAMPLES.  The reference keeps every posterior sample of an iteration
- * (gpet.py:836-841 hands `y_samples` to get_best_curves and, with return_lines, back to the caller), but only the N_keep
- * best curves are used after the scoring (gpet.py:443-451).  By default every iteration stores all N_samples rows.  With
- * gpet_set_option("fused_score", 1) (an opt-in experiment, slower at the bench shape) the loop scores the samples out of
- * the matrix-core accumulators where it applies (even edge lengths, factor rank <= 72) and stores only the rows
- * best_idx[0..N_keep) -- the other rows of GPET_BUF_SAMPLES then hold older data; costs, best indices, kept rows and traces
- * are identical either way.  on = 1 keeps the whole matrix also in that mode (`return_lines=True` of the Python class asks
- * for it).  The per-stage entry points (gpet_gp_sample, gpet_score_curves) always work on the whole matrix. */
-int gpet_batch_keep_samples(gpet_batch* b, int on);
-
 /* The optimiser alone, for a caller's own training sets (GaussianProcessRegressor.fit with optimizer="fmin_l_bfgs_b",
  * sklearn_gpr.py:254-295, 587-607): L-BFGS-B from n_starts start points per edge (starts [B][n_starts][3], theta = log
  * (constant, length_scale, noise_level)) inside bounds [3][2] = (lo, hi) per component, on the training sets of
