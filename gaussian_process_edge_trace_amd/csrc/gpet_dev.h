@@ -65,8 +65,6 @@ struct EdgeDev {
   double* beta;          // [r_cap] c * lam0 * Q0[:, obs] alpha
   double* h0;            // [r_cap] structured path: h0[t] = sum_j Q0[t][j] / (j + 1), the sign convention's weights in the prior eigenbasis
   int r0, structured;    // rank of rho at 1e-14; 1 when the structured path is usable for this edge
-  double* jb_cs;         // [2 * (r_cap/2 + 1)] rotation (c, s) of the current round (large-rank Jacobi)
-  double* jb_norm;       // [2] off-diagonal and diagonal square sums of the current sweep
   double* jlog;          // [JS_LOG_SWEEPS][m - 1][m / 2][2] rotations (c, s) of the LDS Jacobi, round by round (small batches only, else 1 entry)
   int jlog_cap;          // sweeps the log holds (0: none)
   EigState* eig;         // state of the any-rank factorisation

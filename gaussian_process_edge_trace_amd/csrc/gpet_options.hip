@@ -22,12 +22,11 @@ const OptionDef kDefs[] = {
     {"fin_prepare_serial", 0, 0, 1, "1: training sets of the converged fits by one thread per edge (cross-check of the one-wave-per-edge kernel)"},
     {"lml_mfma", 1, 0, 1, "objective of the converged fits on the f64 matrix cores (k_lml16) where the training set allows it; 0: register-tile kernels k_lml / k_lml2"},
     {"lml_two_tiles_from", 600, 1, 0x3fffffff, "problems per launch from which k_lml2 (two 4x4 tiles per thread) replaces k_lml"},
-    {"jacobi_variant", 2, 0, 2, "LDS Jacobi of ranks <= 96: 2 = seated, rotation parameters one round ahead, one barrier per round (k_jacobi_ahead); 1 = seated, three barriers per round (k_jacobi_seat: the cross-check); 0 = addressed by row index (k_jacobi_lds)"},
+    {"jacobi_variant", 1, 0, 1, "LDS Jacobi of ranks <= 96: 1 = seated, rotation parameters one round ahead, one barrier per round (k_jacobi_ahead); 0 = seated, three barriers per round (k_jacobi_seat: the cross-check)"},
     {"jacobi_warm", 1, 0, 1, "structured loop: the eigen-decomposition of an iteration starts from the previous iteration's eigenvectors (k_jacobi_prerot) instead of the identity"},
     {"jacobi_wreg", 6, 0, 8, "k_jacobi_seat: 7 x this many rows of the eigenvector matrix in the worker waves' registers instead of LDS (0, 4, 6, 8)"},
     {"jacobi_logw", 1, 0, 1, "batches that have a rotation log (<= jlog_max_b edges): eigenvectors by a separate pass over the logged rotations"},
     {"jlog_max_b", 32, 0, 4096, "largest batch that gets a rotation log (read when a batch is created): measured per step of a batch alone -- 32 edges 21.5 against 23.1 ms, 64 edges 27.1 either way, 1 024 edges slower (3.15 against 1.73 ms per launch)"},
-    {"scalar_jacobi", 0, 0, 1, "1: ranks above 96 by round 1's whole-GPU scalar Jacobi (cross-check of gpet_eig.hip)"},
     {"oj_warm", 1, 0, 1, "any-rank factor: rows of full rank start from the previous iteration's rows (k_ojw_*: A Sigma A^T, its Cholesky factor, one product) instead of the pivoted Cholesky (across the frames of a sequence only where the caller asks: gpet_batch_set_images with GPET_IMAGES_NEXT_FRAME)"},
     {"oj_warm_fail", 0, 0, 1, "testing: the warm start's Cholesky reports a non-positive pivot, so that the factor falls back to the pivoted Cholesky"},
     {"oj_persist", 1, 0, 1, "any-rank Jacobi: rounds and sweeps in one launch, pair slots handed out by ticket (k_oj_persist); 0: one launch per round"},

@@ -177,8 +177,8 @@ def _matern_frame(amd, ctx, N=1024, S=300):
 def test_any_rank_factor_full_rank_matern_vs_lapack(amd, ctx):
     """The default factor of a full-rank posterior (pivoted Cholesky over the GPU + one-sided block Jacobi on its
     rows, gpet_eig.hip) on a 1024-wide Matern-5/2 covariance: reconstruction, LAPACK's eigenvalues, orthogonal rows,
-    and -- what the tracer sees -- the samples Z A against Z F with F = LAPACK's sqrt(s) v rows (same sign convention)
-    and against the round-1 scalar Jacobi (gpet_set_option("scalar_jacobi", 1)), in pixels."""
+    and -- what the tracer sees -- the samples Z A against Z F with F = LAPACK's sqrt(s) v rows (same sign convention), in
+    pixels.  (LAPACK on the host is this solver's independent cross-check.)"""
     L = amd._lib
     init, grad, warm, kw = _matern_frame(amd, ctx)
     tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx)
@@ -200,17 +200,8 @@ def test_any_rank_factor_full_rank_matern_vs_lapack(amd, ctx):
     Z = orc.legacy_standard_normal(11, 64 * 1024).reshape(64, 1024)
     y_s = s.y_s
     d_lapack = np.abs(Z @ A - Z @ F).max() * y_s
-    old = L.set_option("scalar_jacobi", 1)
-    try:
-        b.factor()
-    finally:
-        L.set_option("scalar_jacobi", old)
-    A1 = b.read(L.BUF_FACTOR)
-    d_scalar = np.abs(Z @ A - Z @ A1).max() * y_s
-    d_scalar_lapack = np.abs(Z @ A1 - Z @ F).max() * y_s
-    print("max sample difference (pixels): new vs LAPACK %.3g, new vs scalar Jacobi %.3g, scalar Jacobi vs LAPACK %.3g"
-          % (d_lapack, d_scalar, d_scalar_lapack))
-    assert d_lapack < 1e-5 and d_scalar < 0.05  # (measured: 2.7e-7 px; the scalar rounds are 4e-3 px from LAPACK)
+    print("max sample difference against LAPACK's factor: %.3g px" % d_lapack)
+    assert d_lapack < 1e-5  # (measured: 2.7e-7 px; round 1's whole-GPU scalar Jacobi, removed in round 5, was 4e-3 px from LAPACK)
 
 
 @pytest.mark.parametrize("opts", [{}, {"pcx_one_pivot": 1}, {"oj_stage": 0}, {"oj_args": 0}, {"oj_persist": 0},
@@ -318,9 +309,9 @@ def test_config4_batch_equals_single_edge_runs_at_bench_shape(amd, ctx):
 
 
 def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
-    """The LDS Jacobi kernels for ranks <= 96 -- by row index (round 1: variant 0), seated (blocks by seat, upper triangle,
-    in place, three barriers per round: 1) and seated with the rotation parameters one round ahead and one barrier per round
-    (k_jacobi_ahead: 2, the default) -- run the same rotations in the same order, so their factors agree to rounding
+    """The two LDS Jacobi kernels for ranks <= 96 -- seated with three barriers per round (k_jacobi_seat: variant 0, the
+    cross-check) and seated with the rotation parameters one round ahead and one barrier per round (k_jacobi_ahead: 1, the
+    default) -- run the same rotations in the same order, so their factors agree to rounding
     (not bitwise: a pair's roles can be swapped, which changes the order of the additions).  Generic path (stage API:
     covariance -> pivoted Cholesky -> Gram -> Jacobi -> rows) over widths and length scales that give odd, even, tiny and
     capacity-sized ranks; then whole traces through the structured loop path, which must not move by a pixel."""
@@ -335,7 +326,7 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
         kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 0.15 * N, 'length_scale': ell}, noise_y=1, N_samples=64,
                   score_thresh=1, delta_x=3, keep_ratio=0.1, pixel_thresh=3, seed=1, fix_endpoints=True)
         out = {}
-        for variant in (0, 1, 2):
+        for variant in (0, 1):
             old = L.set_option("jacobi_variant", variant)
             try:
                 tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
@@ -349,20 +340,18 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
             finally:
                 L.set_option("jacobi_variant", old)
         A0, ev0, cov, r0 = out[0]
-        assert r0 <= 96  # (above 96 the any-rank factor of csrc/gpet_eig.hip takes over)
+        A1, ev1, _, r1 = out[1]
+        assert r0 == r1 and A0.shape == A1.shape and r0 <= 96  # (above 96 the any-rank factor of csrc/gpet_eig.hip takes over)
         seen.add(r0)
         scale = ev0[0]
-        # rows of well separated singular values agree row by row (a near-degenerate pair may come out rotated in either form)
+        np.testing.assert_allclose(ev1, ev0, rtol=0, atol=1e-12 * scale)
+        for A_ in (A0, A1):
+            np.testing.assert_allclose(A_.T @ A_, cov, rtol=0, atol=1e-9 * scale)
+        # the same rotations in the same order, one round-off apart: rows of well separated singular values agree row by row
+        # (a near-degenerate pair may come out rotated within its plane)
         gap = np.minimum(np.abs(np.diff(ev0, prepend=np.inf)), np.abs(np.diff(ev0, append=-np.inf)))
         sep = gap > 1e-6 * scale
-        for v in (1, 2):
-            A1, ev1, _, r1 = out[v]
-            assert r0 == r1 and A0.shape == A1.shape
-            np.testing.assert_allclose(ev1, ev0, rtol=0, atol=1e-12 * scale)
-            np.testing.assert_allclose(A1.T @ A1, cov, rtol=0, atol=1e-9 * scale)
-            np.testing.assert_allclose(A1[sep], A0[sep], rtol=0, atol=1e-7 * np.sqrt(scale))
-        # the two seated forms run the same rotations: one round-off apart
-        np.testing.assert_allclose(out[2][0][sep], out[1][0][sep], rtol=0, atol=1e-10 * np.sqrt(scale))
+        np.testing.assert_allclose(A1[sep], A0[sep], rtol=0, atol=1e-10 * np.sqrt(scale))
     assert any(r % 2 for r in seen) and any(r % 2 == 0 for r in seen) and min(seen) <= 8 and max(seen) >= 60, seen
     # whole traces, structured loop path (the bench configuration at 128 columns and at the README size)
     for N, S, ell, sf in [(128, 200, 8.0, 20.0), (500, 1000, 20.0, 75.0)]:
@@ -372,7 +361,7 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
         kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': sf, 'length_scale': ell}, noise_y=1, N_samples=S,
                   score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
         traces = {}
-        for variant in (0, 1, 2):
+        for variant in (0, 1):
             old = L.set_option("jacobi_variant", variant)
             try:
                 bt = amd.GP_Edge_Tracing_Batch([init] * 4, grad, [1, 2, 3, 4], **kw, _ctx=ctx)
@@ -380,9 +369,8 @@ def test_lds_jacobi_forms_agree_over_ranks(amd, ctx):
                 traces[variant] = bt()
             finally:
                 L.set_option("jacobi_variant", old)
-        for v in (1, 2):
-            for a, b_ in zip(traces[0], traces[v]):
-                assert np.array_equal(a, b_)
+        for a, b_ in zip(traces[0], traces[1]):
+            assert np.array_equal(a, b_)
 
 
 def test_structured_loop_warm_started_eigen_decomposition(amd, ctx):

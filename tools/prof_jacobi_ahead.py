@@ -14,10 +14,10 @@ grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)),
 seeds = [1 + 997 * k for k in range(E)]
 tr = amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx)
 b = tr._batch
-L.set_option("jacobi_variant", 1)
+L.set_option("jacobi_variant", 0)
 b.iterate(seeds, 7)
 L.set_option("jacobi_warm", 0)
-for variant in (1, 2):
+for variant in (0, 1):
     L.set_option("jacobi_variant", variant)
     ms = b.profile_stage(122, 1)
     print("variant %d, %d edge(s): eigen stage %.4f ms, sweeps %d" % (variant, E, ms, int(b.scalars(0).lml)), flush=True)

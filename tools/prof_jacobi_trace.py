@@ -1,5 +1,5 @@
 """For rocprofv3 --kernel-trace --stats: cold eigen-decompositions (stage 122, warm start off) of the bench edge's mid-trace
-matrix with k_jacobi_seat (variant 1) and k_jacobi_ahead (2).  usage: python tools/prof_jacobi_trace.py [edges] [reps]"""
+matrix with k_jacobi_seat (variant 0) and k_jacobi_ahead (1).  usage: python tools/prof_jacobi_trace.py [edges] [reps]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ tr = amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx)
 b = tr._batch
 b.iterate(seeds, 7)
 L.set_option("jacobi_warm", 0)
-for variant in (1, 2):
+for variant in (0, 1):
     L.set_option("jacobi_variant", variant)
     ms = b.profile_stage(122, reps)
     print("variant %d, %d edge(s): eigen stage %.4f ms, sweeps %d" % (variant, E, ms, int(b.scalars(0).lml)), flush=True)

@@ -1,4 +1,4 @@
-"""k_jacobi_ahead (jacobi_variant 2: parameters one round ahead, one barrier per round) against k_jacobi_seat (1) on the bench
+"""k_jacobi_ahead (jacobi_variant 1: parameters one round ahead, one barrier per round) against k_jacobi_seat (0) on the bench
 edge at its mid-trace state: time of the eigen-decomposition stage (pre-rotation + Jacobi + rotation-log pass where the batch
 has one), eigenvalues, factor rows and whole traces.  usage: python tools/time_jacobi_ahead.py [edges ...]"""
 import os
@@ -18,7 +18,7 @@ grad = amd.gpet_utils.comp_grad_img(img, amd.gpet_utils.kernel_builder((11, 5)),
 for E in [int(v) for v in sys.argv[1:]] or [1, 32, 1024]:
     seeds = [1 + 997 * k for k in range(E)]
     res = {}
-    for variant in (1, 2):
+    for variant in (0, 1):
         old = L.set_option("jacobi_variant", variant)
         try:
             tr = amd.GP_Edge_Tracing_Batch([init] * E, grad, seeds, **README_KW, _ctx=ctx)
@@ -43,6 +43,6 @@ for E in [int(v) for v in sys.argv[1:]] or [1, 32, 1024]:
             b.close()
         finally:
             L.set_option("jacobi_variant", old)
-    f1, f2 = res[1][1], res[2][1]
+    f1, f2 = res[0][1], res[1][1]
     print("E=%d: factor rows max |diff| %.3e (scale %.3e); traces identical: %d of %d; iterations identical: %s"
-          % (E, np.abs(f1 - f2).max(), np.abs(f1).max(), sum(np.array_equal(a, c) for a, c in zip(res[1][2], res[2][2])), E, res[1][3] == res[2][3]), flush=True)
+          % (E, np.abs(f1 - f2).max(), np.abs(f1).max(), sum(np.array_equal(a, c) for a, c in zip(res[0][2], res[1][2])), E, res[0][3] == res[1][3]), flush=True)
