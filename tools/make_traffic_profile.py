@@ -26,13 +26,15 @@ def last(path, name):
 
 def mean_of(path, name, kernel):
     f = glob.glob(os.path.join(ROOT, path, "*", "*_counter_collection.csv"))[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and kernel in r["Kernel_Name"]]
+    # (exact kernel: "gpet::k_lml16(" does not pick up k_lml16_fit or the register-tile kernels k_lml / k_lml2)
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+         if r["Counter_Name"] == name and r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0] == kernel]
     return sum(v) / len(v), len(v)
 
 
 def main():
     E, N = int(sys.argv[1]), int(sys.argv[2])
-    R = sys.argv[3] if len(sys.argv) > 3 else "r04"
+    R = sys.argv[3] if len(sys.argv) > 3 else "r05"
     fe, wr = last("gpurun_out/pmc_fetch", "FETCH_SIZE"), last("gpurun_out/pmc_write", "WRITE_SIZE")
     out = dict(edges=E, image=[N, N], source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/prof_stages.py",
                correction="HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024", kernels={})
@@ -44,7 +46,7 @@ def main():
     # over `tools/prof_final.py E 0` (gpurun_out/pmc_lml_f, pmc_lml_w), averaged over all its launches
     old_path = os.path.join(ROOT, "profiles", R + "_pmc_traffic.json")
     if glob.glob(os.path.join(ROOT, "gpurun_out/pmc_lml_f", "*", "*_counter_collection.csv")):
-        lf, lw = mean_of("gpurun_out/pmc_lml_f", "FETCH_SIZE", "k_lml"), mean_of("gpurun_out/pmc_lml_w", "WRITE_SIZE", "k_lml")
+        lf, lw = mean_of("gpurun_out/pmc_lml_f", "FETCH_SIZE", "gpet::k_lml16"), mean_of("gpurun_out/pmc_lml_w", "WRITE_SIZE", "gpet::k_lml16")
         out["kernels"]["k_lml"] = dict(fetch_size_kb=lf[0], write_size_kb=lw[0], launches=lf[1],
                                        hbm_bytes_per_launch=(2.0 * lf[0] + lw[0]) * 1024.0,
                                        source="tools/prof_final.py %d 0: mean over the LML launches of one batch's converged fits" % E)
