@@ -1,6 +1,6 @@
 """Warm start of the any-rank factor (option oj_warm): the factor stage on a Matern-5/2 batch three iterations into its trace
 (covariance of the current observation set, rows of the previous iteration in the ring), with and without it.
-usage: python tools/time_matern_warm.py [N] [B] [reps]"""
+usage: python tools/time_matern_warm.py [N] [B] [reps] [modes, e.g. 1 = the warm path only (for rocprofv3), default 01]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,7 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    modes = [int(c) for c in (sys.argv[4] if len(sys.argv) > 4 else "01")]
     import gaussian_process_edge_trace_amd as pkg
     from bench import synth_image
     L = pkg._lib
@@ -22,7 +23,7 @@ def main():
               N_samples=1000, score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
     seeds = [3 + e for e in range(B)]
     ref = None
-    for warm in (0, 1):
+    for warm in modes:
         old = L.set_option("oj_warm", warm)
         bt = pkg.GP_Edge_Tracing_Batch([init] * B, grad, seeds, **kw, _ctx=ctx)
         b = bt._batch
