@@ -44,7 +44,7 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.h0 = cv.take<double>(rc);
   E.rho_tab = cv.take<double>((size_t)E.N);
   E.eig = cv.take<EigState>(1);
-  E.Gt = cv.take<double>(rc > 96 ? Lg * rc : 1);
+  E.Gt = cv.take<double>((rc > 96 || Lg > 1024) ? Lg * rc : 1);  // (transposed copy of G: the multi-workgroup pivoted Cholesky)
   E.Ap = cv.take<double>(rc > 96 ? 2 * Lg * rc : 1);
   E.ap_tag = cv.take<int>(3);
   E.pcx_d = cv.take<double>(Lg);

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) k_pcx_step(PcxArgs args, EdgeDev* edges, 
 #define PCB_NB 16
 #define PCB_CH 128
 template <bool ARGS>
-__global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges, int blk, int nw_max) {
+__global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges, int blk, int nw_max, double accept_ratio) {
   PcxEdge E;
   if (ARGS) {
     E = args.e[blockIdx.y];
@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
     for (int m = 0; m < PCB_NB; ++m) li[m] = 0.0;
     int na = 0;
     bool going = true;
+    double first_piv = 0.0;
 #pragma unroll
     for (int a = 0; a < PCB_NB; ++a) {
       if (going && a < nc) {
@@ -404,7 +405,10 @@ __global__ void __launch_bounds__(256) k_pcb_block(PcxArgs args, EdgeDev* edges,
           }
         }
         const int k = bi;
-        if (!(bv > tol) || !(bv > 0.0)) {
+        // (accept_ratio > 0: a block ends where the next pivot falls under that fraction of its first -- the global maximum --
+        //  so that the order stays within a constant of the greedy one: factors that end at the rank cap)
+        if (a == 0) first_piv = bv;
+        if (!(bv > tol) || !(bv > 0.0) || bv < accept_ratio * first_piv) {
           going = false;
         } else {
           const double piv = sqrt(bv);
@@ -1583,6 +1587,40 @@ static void launch_oj_warm(hipStream_t st, EdgeDev* d_edges, int B, const BatchD
   hipLaunchKernelGGL(k_ojw_commit, dim3(256, B), dim3(256), 0, st, d_edges);
 }
 
+// The pivoted Cholesky of a WIDE edge of low rank (BASELINE config 3: 2 048 columns, rank <= 96) over the GPU instead of
+// k_pchol's one workgroup (1.2 ms of that factor's 2.2: every pivot streams all previous rows through one CU).  The pivot
+// ORDER matters here: these factors end at the rank CAP, and the blocked candidate selection of the any-rank path, which is
+// free to take pivots out of order when every pivot will be taken anyway, leaves 1e-7 of the largest entry at rank 96 where
+// the greedy order leaves 1e-12 (measured).  Option "pchol_multi": 2 = k_pcb_block with a block ending where the next pivot
+// falls under a tenth of the block's first (the global maximum): the order stays within a constant of the greedy one;
+// 1 = one pivot per launch in the greedy order itself (k_pcx_step); 0 = k_pchol.  The rows' last bits differ from k_pchol's
+// either way, so the prior eigenbasis of the structured loop (whose bits every trace inherits) and edges of up to 1 024
+// columns stay on k_pchol.
+bool pchol_multi_applies(const BatchDims& bd) {
+  const int mode = option("pchol_multi");
+  return bd.Lg > 1024 && bd.r_cap <= 96 && mode != 0 && (mode == 1 || cdiv_h(bd.Lg, PCX_COLS) <= 64);
+}
+hipError_t launch_pchol_multi(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd) {
+  (void)hipGetLastError();
+  const int nw = cdiv_h(bd.Lg, PCX_COLS);
+  const int steps = bd.r_cap < bd.Lg ? bd.r_cap : bd.Lg;
+  PcxArgs px_args;
+  memset(&px_args, 0, sizeof px_args);
+  if (option("pchol_multi") == 1) {
+    hipLaunchKernelGGL(k_pcx_init, dim3(nw, B), dim3(256), 0, st, d_edges, nw);
+    for (int t = 0; t < steps; ++t) hipLaunchKernelGGL((k_pcx_step<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, t, nw);
+    hipLaunchKernelGGL(k_pcx_fin, dim3(B), dim3(64), 0, st, d_edges, steps, nw);
+  } else {
+    // (every block takes at least its first candidate: `steps` blocks always suffice; one that finds the factorisation
+    //  finished returns at once)
+    hipLaunchKernelGGL(k_pcb_init, dim3(nw, B), dim3(64), 0, st, d_edges, nw);
+    for (int blk = 0; blk < steps; ++blk)
+      hipLaunchKernelGGL((k_pcb_block<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw, 0.1);
+    hipLaunchKernelGGL(k_pcb_fin, dim3(B), dim3(64), 0, st, d_edges, nw);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const BatchDims& bd, const EdgeDev* h_edges) {
   (void)hipGetLastError();
   // small batches: the per-edge pointers travel in the kernel arguments (h_edges = host copy of the edge table)
@@ -1628,8 +1666,8 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
     const int per_block = nw < PCB_NB ? nw : PCB_NB;  // (one candidate per 32-column workgroup: narrow edges offer fewer)
     const int nblocks = 2 * cdiv_h(steps, per_block) + 8;
     for (int blk = 0; blk < nblocks; ++blk) {
-      if (use_args) hipLaunchKernelGGL((k_pcb_block<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
-      else hipLaunchKernelGGL((k_pcb_block<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw);
+      if (use_args) hipLaunchKernelGGL((k_pcb_block<true>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw, 0.0);
+      else hipLaunchKernelGGL((k_pcb_block<false>), dim3(nw, B), dim3(256), 0, st, px_args, d_edges, blk, nw, 0.0);
     }
     hipLaunchKernelGGL(k_pcb_fin, dim3(B), dim3(64), 0, st, d_edges, nw);
   } else {
