@@ -101,7 +101,20 @@ SYMBOLS = {
     "gpet_batch_set_sample_dtype": (C.c_int, [_P, C.c_int]),
     "gpet_batch_set_rng": (C.c_int, [_P, C.c_int]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
+    "gpet_comm_unique_id": (C.c_int, [_P]),
+    "gpet_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gpet_comm_destroy": (None, [_P]),
+    "gpet_comm_rank": (C.c_int, [_P]),
+    "gpet_comm_world": (C.c_int, [_P]),
+    "gpet_comm_block": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gpet_bcast_grad": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "gpet_dev_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "gpet_dev_free": (C.c_int, [_P, _P]),
+    "gpet_dev_copy": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+    "gpet_allgather_i64": (C.c_int, [_P, _P, _P, _P]),
+    "gpet_gather_traces": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -200,6 +213,86 @@ class Context:
     def close(self):
         if getattr(self, "h", None):
             self.lib.gpet_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    """gpet_comm_unique_id: the 128 bytes rank 0 ships to every rank (any transport) before Comm(ctx, id, world, rank)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().gpet_comm_unique_id(buf)
+    if rc:
+        raise GpetError(rc, "gpet_comm_unique_id failed (is RCCL installed?)")
+    return buf.raw
+
+
+class Comm:
+    """gpet_comm: the C ABI's RCCL communicator of one rank (one process per GPU) and its two collectives --
+    the broadcast of the shared gradient image(s) into device memory and the gather of the finished traces."""
+
+    def __init__(self, ctx: Context, unique_id, world, rank):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = _P()
+        idbuf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES) if unique_id is not None else None
+        ctx.check(self.lib.gpet_comm_create(ctx.h, idbuf, int(world), int(rank), C.byref(h)))
+        self.h = h
+        self.world, self.rank = int(world), int(rank)
+        self._bufs = []
+
+    def block(self, n_units):
+        lo, hi = C.c_int64(), C.c_int64()
+        self.ctx.check(self.lib.gpet_comm_block(self.h, int(n_units), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def bcast_grad(self, grad, shape, root=0):
+        """Broadcast float32 image(s) of ``shape`` from ``root`` (``grad`` is read there only); returns the DEVICE pointer the
+        collective filled, for GP_Edge_Tracing_Batch(..., grad_device_ptrs=[ptr], grad_shape=...) -- no trip through host memory
+        on the receiving ranks.  The buffer lives until close()."""
+        count = int(np.prod(shape))
+        d = _P()
+        self.ctx.check(self.lib.gpet_dev_alloc(self.ctx.h, count * 4, C.byref(d)))
+        self._bufs.append(d)
+        if self.rank == root:
+            a = np.ascontiguousarray(grad, dtype=np.float32).reshape(-1)
+            assert a.size == count
+            self.ctx.check(self.lib.gpet_dev_copy(self.ctx.h, d, a.ctypes.data, count * 4, 0))
+        self.ctx.check(self.lib.gpet_bcast_grad(self.h, d, count, int(root)))
+        return d.value
+
+    def download(self, dev_ptr, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        self.ctx.check(self.lib.gpet_dev_copy(self.ctx.h, out.ctypes.data, _P(dev_ptr), out.nbytes, 1))
+        return out
+
+    def gather_traces(self, local, n_edges, edge_len):
+        """(n_local, edge_len, 2) int64 traces of this rank's block -> (n_edges, edge_len, 2) in global order on every rank."""
+        loc = np.ascontiguousarray(np.asarray(local, dtype=np.int64).reshape(-1, int(edge_len), 2))
+        lo, hi = self.block(n_edges)
+        assert loc.shape[0] == hi - lo, (loc.shape, lo, hi)
+        out = np.empty((int(n_edges), int(edge_len), 2), dtype=np.int64)
+        self.ctx.check(self.lib.gpet_gather_traces(self.h, loc.ctypes.data if loc.size else None, int(n_edges), int(edge_len),
+                                                   out.ctypes.data))
+        return out
+
+    def allgather_i64(self, local, counts):
+        loc = np.ascontiguousarray(np.asarray(local, dtype=np.int64).reshape(-1))
+        cn = np.ascontiguousarray(np.asarray(counts, dtype=np.int64))
+        assert cn.size == self.world and loc.size == cn[self.rank]
+        out = np.empty(int(cn.sum()), dtype=np.int64)
+        self.ctx.check(self.lib.gpet_allgather_i64(self.h, loc.ctypes.data if loc.size else None, cn.ctypes.data, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            for d in self._bufs:
+                self.lib.gpet_dev_free(self.ctx.h, d)
+            self._bufs = []
+            self.lib.gpet_comm_destroy(self.h)
             self.h = None
 
     def __del__(self):

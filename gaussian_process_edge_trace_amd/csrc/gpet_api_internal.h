@@ -6,6 +6,7 @@
 //   gpet_api_stages.hip  the per-stage entry points (a2-a7, f1) and gpet_profile_stage
 //   gpet_api_final.hip   the converged fit (f2): objective, device L-BFGS-B, posterior at the optimum
 //   gpet_api_loop.hip    the device-resident loop (a8): gpet_trace_iterate
+//   gpet_api_comm.hip    multi-GPU helpers on RCCL (8e): communicator, broadcast of the gradient image, gather of the traces
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

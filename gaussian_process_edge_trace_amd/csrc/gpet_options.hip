@@ -34,6 +34,7 @@ const OptionDef kDefs[] = {
     {"oj_args", 1, 0, 1, "any-rank factor: per-edge pointers of small batches in the kernel arguments; 0: through the edge table"},
     {"oj_tol_exp", 8, 4, 15, "any-rank Jacobi stops after a sweep whose pairs were all orthogonal to 10^-x relative"},
     {"oj_max_sweeps", 16, 1, 64, "sweep budget of the any-rank Jacobi"},
+    {"comm_force_rccl", 0, 0, 1, "testing: gpet_comm_create builds an RCCL communicator also for a world of one (whose collectives are otherwise plain copies)"},
     {"pchol_multi", 2, 0, 2, "edges wider than 1 024 columns of rank <= 96: pivoted Cholesky over the GPU instead of one workgroup (k_pchol): 2 = blocks of pivots within a tenth of the block's first (k_pcb_block), 1 = one pivot per launch in the greedy order (k_pcx_step)"},
     {"pcx_one_pivot", 0, 0, 1, "1: multi-workgroup pivoted Cholesky one pivot per launch (cross-check of the blocked candidate selection)"},
     {"solve_mw", 1, 0, 1, "blocked fit: alpha by one workgroup per 64-row block and direction (k_chol_solve_mw); 0: one workgroup per edge"},

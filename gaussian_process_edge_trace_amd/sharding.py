@@ -76,6 +76,23 @@ def trace_sharded(grad, grad_shape, inits, seeds, tracer, dist=None, device="cpu
     return gather_traces(local, n, edge_len, dist, device)
 
 
+def trace_sharded_cabi(grad, grad_shape, inits, seeds, comm, **ctor_kwargs):
+    """``trace_sharded`` with no torch in the process: the C ABI's own RCCL call sites (``_lib.Comm``: gpet_comm_create,
+    gpet_bcast_grad, gpet_gather_traces; include/gpet_hip.h "collectives") -- what a non-Python host of the reference would
+    call.  ``grad`` is needed on rank 0 only; the broadcast image is consumed where RCCL put it (device pointer ->
+    gpet_batch_create2 / GPET_GRAD_ON_DEVICE).  Returns the (n_edges, edge_len, 2) traces in global order on every rank."""
+    from .gpet import GP_Edge_Tracing_Batch
+    n = len(inits)
+    ptr = comm.bcast_grad(grad, grad_shape, root=0)
+    lo, hi = comm.block(n)
+    local = []
+    if hi > lo:
+        local = GP_Edge_Tracing_Batch(list(inits[lo:hi]), None, list(seeds[lo:hi]), grad_device_ptrs=[ptr],
+                                      grad_shape=tuple(grad_shape), _ctx=comm.ctx, **ctor_kwargs)()
+    edge_len = int(abs(int(inits[0][-1][0]) - int(inits[0][0][0])) + 1)
+    return comm.gather_traces(local, n, edge_len)
+
+
 def sequence_partition(n_frames, n_chains, world, rank):
     """Frames of an image sequence owned by ``rank``: the sequence is cut into ``n_chains`` chains of consecutive
     frames (``sequence.chain_slices``; the first frame of a chain starts cold, later ones warm-start from the

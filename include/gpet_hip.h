@@ -296,6 +296,36 @@ int gpet_final_optimize(gpet_batch* b, int n_starts, const double* starts, const
  * number of objective evaluations and of launches; any of the outputs may be NULL.  (bench.py's roofline leg.) */
 int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches);
 
+/* ---- collectives: one process per GPU ---------------------------------------------------------------
+ * The reference has no multi-GPU path; independent edges (and whole chains of an image sequence) shard over ranks with no
+ * collective on a trace's data path: ONE broadcast of the shared gradient image(s) and ONE gather of the finished traces.
+ * These are the RCCL call sites for a host that is not Python (the Python package does the same through torch.distributed,
+ * sharding.py).  RCCL is bound at run time (dlopen); a world of 1 needs none.
+ *   rank 0: gpet_comm_unique_id(id)  -> ship the GPET_COMM_ID_BYTES bytes to every rank by any means (file, socket, MPI)
+ *   all:    gpet_comm_create(ctx, id, world, rank, &comm)        (ncclCommInitRank on the context's device)
+ *           gpet_comm_block(comm, n_edges, &lo, &hi)             this rank's contiguous block of edges [lo, hi)
+ *           gpet_bcast_grad(comm, d_grad, count, root)           in place on DEVICE memory, on the context's stream; hand
+ *                                                                d_grad to gpet_batch_create2(..., GPET_GRAD_ON_DEVICE)
+ *           gpet_gather_traces(comm, local, n_edges, len, all)   host int64 [n_local][len][2] -> [n_edges][len][2] on every
+ *                                                                rank, in global edge order (blocks as gpet_comm_block)
+ *           gpet_allgather_i64(comm, local, counts, all)         the same for blocks of counts[r] int64 per rank (sequences) */
+typedef struct gpet_comm gpet_comm;
+#define GPET_COMM_ID_BYTES 128
+int gpet_comm_unique_id(void* id128);
+int gpet_comm_create(gpet_ctx* ctx, const void* id128, int world, int rank, gpet_comm** out);
+void gpet_comm_destroy(gpet_comm* comm);
+int gpet_comm_rank(const gpet_comm* comm);
+int gpet_comm_world(const gpet_comm* comm);
+int gpet_comm_block(const gpet_comm* comm, int64_t n_units, int64_t* lo, int64_t* hi);
+int gpet_bcast_grad(gpet_comm* comm, float* d_grad, size_t count, int root);
+/* device memory on the context's device for the broadcast buffer (hosts that do not call the HIP runtime themselves);
+ * gpet_dev_copy: host -> device (to_host = 0) or device -> host (1), on the context's stream, complete on return */
+int gpet_dev_alloc(gpet_ctx* ctx, size_t bytes, void** out);
+int gpet_dev_free(gpet_ctx* ctx, void* ptr);
+int gpet_dev_copy(gpet_ctx* ctx, void* dst, const void* src, size_t bytes, int to_host);
+int gpet_allgather_i64(gpet_comm* comm, const int64_t* h_local, const int64_t* counts, int64_t* h_all);
+int gpet_gather_traces(gpet_comm* comm, const int64_t* h_local, int64_t n_edges, int64_t edge_len, int64_t* h_all);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Enqueue one stage `reps` times between two hipEvents on the context's stream and return the
  * mean milliseconds per repetition.  stage: 0 fit+predict+cov, 1 factor, 2 normals, 3 sample

@@ -11,6 +11,6 @@ python3 -c "import __graft_entry__ as g; g.build()"   # objects of the other sou
 mkdir -p gpurun_scratch
 C=gaussian_process_edge_trace_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $C/gpet_kernels.hip -o gpurun_scratch/gpet_kernels_prof.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_scratch/libgpet_prof.so $C/build/gpet_api_ctx.hip.o $C/build/gpet_api_batch.hip.o $C/build/gpet_api_stages.hip.o $C/build/gpet_api_final.hip.o $C/build/gpet_api_loop.hip.o \
-  gpurun_scratch/gpet_kernels_prof.o $C/build/gpet_eig.hip.o $C/build/gpet_lbfgsb.hip.o $C/build/gpet_rng.hip.o $C/build/gpet_options.hip.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_scratch/libgpet_prof.so $C/build/gpet_api_ctx.hip.o $C/build/gpet_api_batch.hip.o $C/build/gpet_api_stages.hip.o $C/build/gpet_api_final.hip.o $C/build/gpet_api_loop.hip.o $C/build/gpet_api_comm.hip.o \
+  gpurun_scratch/gpet_kernels_prof.o $C/build/gpet_eig.hip.o $C/build/gpet_lbfgsb.hip.o $C/build/gpet_rng.hip.o $C/build/gpet_options.hip.o -ldl
 ls -la gpurun_scratch/libgpet_prof.so
