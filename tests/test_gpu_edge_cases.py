@@ -463,3 +463,31 @@ def test_two_edges_of_one_image_batch_vs_oracle(amd, ctx, ltype):
         print("%s, edge %d: MSE vs its own truth %.1f, vs the other edge %.1f, %d iterations" % (ltype, e, mine, other, info["n_iter"]))
         # (no quality gate: the second edge has the stronger gradient and attracts the first edge's tracer in the reference
         #  algorithm itself -- the oracle's MSE vs its own / the other edge here: 708 / 291 and 438 / 1105; parity is the point)
+
+
+@pytest.mark.parametrize("N,S", [(64, 1000), (96, 300), (112, 1000)])
+def test_sample_gemm_of_a_narrow_edge_leaves_the_neighbouring_buffers_alone(amd, ctx, N, S):
+    """The sample GEMM's idle lanes store to a spare region behind the sample matrix (rows of fewer than 128 bytes x 8: a
+    narrow edge, S not a multiple of a row block).  The costs are carved right behind it in the arena: computed once, they
+    must survive a second sample GEMM untouched, and so must the samples' own last rows."""
+    L = amd._lib
+    grad, truth = _image(N, 4)
+    init = truth[[0, -1], :][:, [1, 0]]
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 8, 'length_scale': 6}, noise_y=1, N_samples=S, score_thresh=1,
+              delta_x=4, keep_ratio=0.1, pixel_thresh=2, seed=3, fix_endpoints=True)
+    tr = amd.GP_Edge_Tracing(init, grad, **kw, _ctx=ctx)
+    b = tr._batch
+    assert b.info()["Lg"] == N and b.info()["S"] == S
+    b.fit_predict(True)
+    b.factor()
+    b.normals([7])
+    b.sample()
+    b.score()
+    costs = np.array(b.read(L.BUF_COSTS))
+    best = np.array(b.read(L.BUF_BEST_IDX))
+    Y = np.array(b.read(L.BUF_SAMPLES))
+    assert costs.shape == (S,) and np.all(np.isfinite(costs)) and np.all(costs > 0)
+    b.sample()
+    assert np.array_equal(np.array(b.read(L.BUF_COSTS)), costs)
+    assert np.array_equal(np.array(b.read(L.BUF_BEST_IDX)), best)
+    assert np.array_equal(np.array(b.read(L.BUF_SAMPLES)), Y)
