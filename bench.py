@@ -17,7 +17,13 @@ import os
 import sys
 import time
 
-import numpy as np
+# The bench keeps six batch objects in flight, each with three HIP streams (loop, RNG look-ahead, converged fits): 18 streams on
+# the runtime's default of FOUR hardware queues per process alias heavily (streams of one queue run in order).  Eight queues:
+# +2-3 % on the headline, +9 % on batches of 256 (profiles/r05_hw_queues.txt; 12 and 16 hurt the single-edge latency).  The HIP
+# runtime reads this variable when it initialises, so it is set before anything that loads it; a value the caller has set wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -854,7 +860,7 @@ def main():
                    "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
                                 "all on the GPU (gpet_final_fit_all); no host workers"},
         "host": {"cpus_usable": usable_cpus(), "cpus_machine": os.cpu_count(), "lbfgs_workers": 0,
-                 "host_threads": depth + 1, "note": "the host only enqueues launches and waits: one driver thread per batch object "
+                 "host_threads": depth + 1, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "note": "the host only enqueues launches and waits: one driver thread per batch object "
                  "in flight (its device loop, then its converged fits)"},
         "secondary": secondary,
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),

@@ -231,6 +231,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   (void)meas.take<double>((size_t)B * 2 * bd.Lg);
   (void)meas.take<double>((size_t)B * 12);
   (void)meas.take<long long>((size_t)B * 2 * bd.obs_cap);
+  int n_init_max = 1;
+  for (int e = 0; e < B; ++e) n_init_max = b->h_edges[e].n_init > n_init_max ? b->h_edges[e].n_init : n_init_max;
+  (void)meas.take<long long>((size_t)B * 2 * (size_t)n_init_max);
   for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image);
   (void)shared_grad;
   (void)shared_kde;
@@ -251,6 +254,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   b->d_fin_out = cv.take<double>((size_t)B * 2 * bd.Lg);
   b->d_fin_par = cv.take<double>((size_t)B * 12);
   b->d_obs = cv.take<long long>((size_t)B * 2 * bd.obs_cap);
+  b->d_init = cv.take<long long>((size_t)B * 2 * (size_t)n_init_max);
   b->h_scalars.resize(B);
   for (int e = 0; e < B; ++e) {
     EdgeDev& E = b->h_edges[e];
@@ -259,6 +263,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     carve_edge(cv, E, !b->share_image);
     E.fin_par = b->d_fin_par + (size_t)e * 12;                 // (batch-contiguous; the per-edge carve is unused)
     E.obs_xy = b->d_obs + (size_t)e * 2 * bd.obs_cap;
+    E.init_xy = b->d_init + (size_t)e * 2 * (size_t)n_init_max;  // (batch-contiguous; the per-edge carve is unused)
     if (b->share_image) {
       E.grad = shared_grad;
       E.grad_kde = shared_kde;
@@ -288,16 +293,21 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     int rcu = upload_images(b, grad, flags);
     if (rcu) return rcu;
   }
-  for (int e = 0; e < B; ++e) {
-    EdgeDev& E = b->h_edges[e];
-    HIPCHK(c, hipMemcpyAsync((void*)E.init_xy, init_xy[e], sizeof(long long) * 2 * E.n_init, hipMemcpyHostToDevice,
-                             c->stream));
-    gpet_scalars s0;
-    memset(&s0, 0, sizeof s0);
-    s0.score_thresh = params[e].score_thresh;
-    s0.done = (0 >= E.algo_thresh) ? 1 : 0;  // gpet.py:829 with no observations yet
-    HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
-  }
+  // (one copy each for the init points and the initial scalars of all edges: 3 x B small copies were most of the constructor)
+  std::vector<long long> h_init((size_t)B * 2 * (size_t)n_init_max, 0);
+  auto pristine_scalars = [&]() {
+    for (int e = 0; e < B; ++e) {
+      gpet_scalars& s0 = b->h_scalars[e];
+      memset(&s0, 0, sizeof s0);
+      s0.score_thresh = params[e].score_thresh;
+      s0.done = (0 >= b->h_edges[e].algo_thresh) ? 1 : 0;  // gpet.py:829 with no observations yet
+    }
+    return hipMemcpyAsync(b->d_scalars, b->h_scalars.data(), sizeof(gpet_scalars) * (size_t)B, hipMemcpyHostToDevice, c->stream);
+  };
+  for (int e = 0; e < B; ++e)
+    memcpy(&h_init[(size_t)e * 2 * (size_t)n_init_max], init_xy[e], sizeof(long long) * 2 * (size_t)b->h_edges[e].n_init);
+  HIPCHK(c, hipMemcpyAsync(b->d_init, h_init.data(), sizeof(long long) * h_init.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, pristine_scalars());
   HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
   if (any_gen_nu) HIPCHK(c, launch_rho_tab(c->stream, b->d_edges, B, N));
   // gradient KDE of every distinct image (gpet.py:127)
@@ -319,15 +329,57 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
         if (x < b->h_edges[e].x_st || x > b->h_edges[e].x_en) ok = false;
       }
     if (ok) {
-      HIPCHK(c, launch_struct_basis(c->stream, b->d_edges, B, b->bd));
+      // Edges of the same grid length, first column, kernel and length scale have the same prior eigenbasis bit for bit
+      // (k_rho_fill forms the lags as fl((x_st+i)/l) - fl((x_st+j)/l), which depends on x_st in the last bits unless l is
+      // a power of two -- so x_st is part of the match; the amplitude is not: the matrix has unit amplitude).  It is computed
+      // for the first edge of every such class only (a batch of 1 024 equal edges: one factorisation instead of 1 024, 7.5 ms
+      // of the constructor) and the others read that edge's copy, which then stays in L2 for the whole batch (k_struct_H
+      // gathers its rows, k_struct_rows streams it: 288 KB per edge at rank 72, Lg 500).  Option "shared_basis" = 0: every
+      // edge computes and keeps its own.
+      std::vector<int> rep_of((size_t)B), reps;
+      for (int e = 0; e < B; ++e) {
+        const EdgeDev& E = b->h_edges[e];
+        int found = -1;
+        if (option("shared_basis"))
+          for (size_t k = reps.size() > 8 ? reps.size() - 8 : 0; k < reps.size() && found < 0; ++k) {  // (batches are homogeneous or nearly so: a short search)
+            const EdgeDev& F = b->h_edges[reps[k]];
+            if (F.Lg == E.Lg && F.x_st == E.x_st && F.kernel_type == E.kernel_type && F.nu_code == E.nu_code && F.nu_gen == E.nu_gen &&
+                F.length_scale == E.length_scale && F.r_cap == E.r_cap)
+              found = reps[k];
+          }
+        if (found < 0) {
+          found = e;
+          reps.push_back(e);
+        }
+        rep_of[(size_t)e] = found;
+      }
+      if ((int)reps.size() == B) {
+        HIPCHK(c, launch_struct_basis(c->stream, b->d_edges, B, b->bd));
+      } else {
+        std::vector<EdgeDev> h_rep(reps.size());
+        for (size_t k = 0; k < reps.size(); ++k) h_rep[k] = b->h_edges[reps[k]];
+        EdgeDev* d_rep = nullptr;
+        HIPCHK(c, hipMalloc(&d_rep, sizeof(EdgeDev) * reps.size()));
+        hipError_t e1 = hipMemcpyAsync(d_rep, h_rep.data(), sizeof(EdgeDev) * reps.size(), hipMemcpyHostToDevice, c->stream);
+        if (e1 == hipSuccess) e1 = launch_struct_basis(c->stream, d_rep, (int)reps.size(), b->bd);
+        if (e1 == hipSuccess) e1 = gpet_wait(c->stream);
+        (void)hipFree(d_rep);
+        HIPCHK(c, e1);
+      }
       int rc2 = fetch_all_scalars(b);
       if (rc2) return rc2;
       int r0_max = 0;
       for (int e = 0; e < B; ++e) {
         EdgeDev& E = b->h_edges[e];
-        const gpet_scalars& s = b->h_scalars[e];
+        const EdgeDev& F = b->h_edges[rep_of[(size_t)e]];
+        const gpet_scalars& s = b->h_scalars[rep_of[(size_t)e]];
         if (s.status != GPET_OK || s.rank < 1 || s.rank >= E.r_cap) ok = false;  // rank capacity reached
         E.r0 = s.rank;
+        if (rep_of[(size_t)e] != e) {
+          E.Q0 = F.Q0;
+          E.lam0 = F.lam0;
+          E.h0 = F.h0;  // (the sign convention's weights in that basis)
+        }
         if (s.rank > r0_max) r0_max = s.rank;
       }
       b->bd.r0_max = r0_max;
@@ -335,36 +387,9 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
       if (b->bd.n_cap <= 128 &&
           ((size_t)b->bd.n_cap * (r0_max | 1) + b->bd.n_cap + b->bd.r_cap) * sizeof(double) > (size_t)STRUCT_H_LDS_MAX)
         ok = false;
-      // edges of the same grid length, first column, kernel and length scale have the same prior eigenbasis bit for bit
-      // (k_rho_fill forms the lags as fl((x_st+i)/l) - fl((x_st+j)/l), which depends on x_st in the last bits unless l is
-      // a power of two -- so x_st is part of the match; the amplitude is not: the matrix has unit amplitude): they all
-      // read the first such edge's copy, which then stays in L2 for the whole batch (k_struct_H gathers its rows,
-      // k_struct_rows streams it: 288 KB per edge at rank 72, Lg 500) -- option "shared_basis" = 0: every edge its own
-      if (ok && option("shared_basis")) {
-        for (int e = 1; e < B; ++e) {
-          EdgeDev& E = b->h_edges[e];
-          for (int j = 0; j < e; ++j) {
-            const EdgeDev& F = b->h_edges[j];
-            if (F.Lg == E.Lg && F.x_st == E.x_st && F.kernel_type == E.kernel_type && F.nu_code == E.nu_code && F.nu_gen == E.nu_gen &&
-                F.length_scale == E.length_scale && F.r0 == E.r0 && F.r_cap == E.r_cap) {
-              E.Q0 = F.Q0;
-              E.lam0 = F.lam0;
-              break;
-            }
-            if (j >= 8) break;  // (batches are homogeneous or nearly so: a short search)
-          }
-        }
-      }
       // back to the pristine scalar state
-      for (int e = 0; e < B; ++e) {
-        EdgeDev& E = b->h_edges[e];
-        E.structured = ok ? 1 : 0;
-        gpet_scalars s0;
-        memset(&s0, 0, sizeof s0);
-        s0.score_thresh = params[e].score_thresh;
-        s0.done = (0 >= E.algo_thresh) ? 1 : 0;
-        HIPCHK(c, hipMemcpyAsync(E.sc, &s0, sizeof s0, hipMemcpyHostToDevice, c->stream));
-      }
+      for (int e = 0; e < B; ++e) b->h_edges[e].structured = ok ? 1 : 0;
+      HIPCHK(c, pristine_scalars());
       HIPCHK(c, hipMemcpyAsync(b->d_edges, b->h_edges.data(), sizeof(EdgeDev) * B, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, gpet_wait(c->stream));
       b->structured = ok;

@@ -53,6 +53,7 @@ struct gpet_batch {
   double* d_fin_out = nullptr;         // [B][2][Lg_max] contiguous results of the converged fits
   double* d_fin_par = nullptr;         // [B][12] contiguous hyper-parameters / transforms of the converged fits
   long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
+  long long* d_init = nullptr;         // [B][n_init_max][2] contiguous init points: one copy writes them all
   std::vector<gpet_scalars> h_scalars;
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
   int rng_mode = 0;                    // 0: MT19937 + polar method = numpy's RandomState stream; 1: Philox4x32-10 + Box-Muller (opt-in)

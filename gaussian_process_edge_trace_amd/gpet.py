@@ -362,11 +362,21 @@ class GP_Edge_Tracing_Batch(object):
         B = len(inits)
         assert len(seeds) == B and (share or (len(ptrs) if on_dev else len(imgs)) == B)
         obs = [np.array([])] * B if obs is None else list(obs)
-        self._ps = [resolve_params(inits[e], shapes[e], kernel_options, noise_y, obs[e], N_samples, score_thresh,
-                                   delta_x, keep_ratio, pixel_thresh, int(seeds[e]), return_std, fix_endpoints)
-                    for e in range(B)]
+        # (edges given the SAME init / observation objects and image shape resolve to the same parameters but for the seed, which
+        #  nothing derived depends on: resolved once per distinct triple -- a batch of 1 024 equal edges spent 8 ms here)
+        self._ps, abi, memo = [], [], {}
+        for e in range(B):
+            key = (id(inits[e]), tuple(shapes[e]), id(obs[e]))
+            hit = memo.get(key)
+            if hit is None:
+                pe = resolve_params(inits[e], shapes[e], kernel_options, noise_y, obs[e], N_samples, score_thresh,
+                                    delta_x, keep_ratio, pixel_thresh, int(seeds[e]), return_std, fix_endpoints)
+                hit = memo[key] = (pe, to_abi_params(pe, factor_cap=factor_cap, z_cols=z_cols))
+            else:
+                pe = dict(hit[0], seed=int(seeds[e]))
+            self._ps.append(pe)
+            abi.append(hit[1])
         self._ctx = _ctx if _ctx is not None else _lib.Context(device, stream)
-        abi = [to_abi_params(p, factor_cap=factor_cap, z_cols=z_cols) for p in self._ps]
         if on_dev:
             self._batch = _lib.Batch(self._ctx, None, abi, [p["init"] for p in self._ps], share_image=share,
                                      device_ptrs=ptrs, shape=grad_shape)

@@ -18,7 +18,9 @@ def main():
     init = truth[[0, -1], :][:, [1, 0]]
     seeds = [1 + 997 * e for e in range(E)]
     for name, opts in (("defaults", {}), ("jlog_max_b=64", {"jlog_max_b": 64}), ("jlog_max_b=0", {"jlog_max_b": 0}),
-                       ("rng4=1", {"rng4": 1}), ("rng_chunked=1", {"rng_chunked": 1}), ("fit_persistent=0", {"fit_persistent": 0})):
+                       ("rng4=1", {"rng4": 1}), ("rng_chunked=1", {"rng_chunked": 1}), ("fit_persistent=0", {"fit_persistent": 0}),
+                       ("rng_inline=2", {"rng_inline": 2}), ("rng_inline=1", {"rng_inline": 1}), ("rng_lookahead=1", {"rng_lookahead": 1}),
+                       ("rng_lookahead=4", {"rng_lookahead": 4})):
         old = {k: L.set_option(k, v) for k, v in opts.items()}
         try:
             ctx = L.Context(0)
