@@ -17,7 +17,7 @@ import os
 import sys
 import time
 
-# The bench keeps six batch objects in flight, each with three HIP streams (loop, RNG look-ahead, converged fits): 18 streams on
+# The bench keeps eight batch objects in flight, each with three HIP streams (loop, RNG look-ahead, converged fits): 24 streams on
 # the runtime's default of FOUR hardware queues per process alias heavily (streams of one queue run in order).  Eight queues:
 # +2-3 % on the headline, +9 % on batches of 256 (profiles/r05_hw_queues.txt; 12 and 16 hurt the single-edge latency).  The HIP
 # runtime reads this variable when it initialises, so it is set before anything that loads it; a value the caller has set wins.
@@ -394,7 +394,7 @@ def main():
                          "traces/s at 1024 x 6, 2048 x 3 or 4096 x 3 objects; one step at a time it was 6.6 k at 1024, 6.9 k at 2048, "
                          "7.1 k at 4096.  The 256-edge figure of config 4 is reported next to it")
     ap.add_argument("--size", type=int, default=500)
-    ap.add_argument("--pipeline-depth", type=int, default=5,
+    ap.add_argument("--pipeline-depth", type=int, default=7,
                     help="whole traces in flight = depth + 1 batch objects, each driven by its own host thread on its own HIP stream (0 = one object, nothing overlapped)")
     ap.add_argument("--cpu-traces", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
