@@ -501,6 +501,18 @@ def main():
         return loop_s, fit_s, iters_, traces_
 
     log("rank %d: batch of %d edges ready%s" % (rank, E, " (pipelined, %d batch objects)" % len(tracers) if pipeline else ""))
+    n_in_flight = len(tracers)
+
+    def release_pipeline_objects():
+        """The latency figures that follow (configs 3 / 4-literal / 5, one edge, the stage profiles) are of ONE object on the GPU: the
+        other pipeline objects are freed first -- their idle streams would share the process's few hardware queues with the object
+        under test, and whether its RNG look-ahead stream then lands on the queue of its own loop is luck (one edge 9.5 or 11.9 ms,
+        one Matern chain 0.85 or 1.2 s: profiles/r05_hw_queues.txt)."""
+        for tr_ in tracers[1:]:
+            tr_._batch.close()
+            tr_._ctx.close()
+        del tracers[1:]
+
     run_steps(max(args.warmup, len(tracers) if args.warmup else 0), False)
     barrier()
     t0 = time.time()
@@ -689,6 +701,7 @@ def main():
         log("secondary: ctor included %.0f traces/s, no pipeline %.0f, 256 edges %.0f, 256 distinct images %.0f"
             % (secondary["ctor_included"]["traces_per_s"], secondary["no_pipeline"]["traces_per_s"],
                secondary["edges_256"]["traces_per_s"], secondary["edges_256_distinct_images"]["traces_per_s"]))
+        release_pipeline_objects()
         secondary["config3"] = secondary_config3(pkg, ctx)
         log("secondary: config 3 GP iteration %.2f ms + scoring %.2f ms" % (secondary["config3"]["gp_iter_ms"], secondary["config3"]["scoring_ms"]))
         secondary["config3_batch"] = secondary_config3(pkg, ctx, n_edges=8)
@@ -707,6 +720,7 @@ def main():
 
     # ---- one step alone (nothing else on the GPU): device time of the LML kernel launches of its converged fits,
     #      hipEvents around every launch on the fit stream (gpet_lml_stats)
+    release_pipeline_objects()
     tracer.reset()
     it_alone = tracer.run_loop()
     tracer._batch.lml_stats(reset=True)
@@ -855,7 +869,7 @@ def main():
         "config": {"workload": "BASELINE config 2 edge (500x500 sinusoidal image, RBF sigma_f=75 l=20, N_samples=1000, "
                                "delta_x=5, pixel_thresh=5) x %d independent edges per GPU and step (config 4's batch of independent edges, sized to fill the GPU), "
                                "shared gradient image%s" % (E, ", RCCL broadcast" if world > 1 else ""),
-                   "edges_per_gpu": E, "steps_in_flight_per_gpu": len(tracers), "image": [N, N],
+                   "edges_per_gpu": E, "steps_in_flight_per_gpu": n_in_flight, "image": [N, N],
                    "seeds": "1 + 997 * ((rank * objects + object) * edges + edge): every (edge, iteration) its own RandomState stream", "iterations_per_trace": iters[:4],
                    "final_fit": "device-resident: standardisation, 13 starts, L-BFGS-B state machines and the batched LML objective "
                                 "all on the GPU (gpet_final_fit_all); no host workers"},
@@ -866,7 +880,7 @@ def main():
         "gp_iter_ms": {"batch_of_%d" % E: sum(stage_ms[k] for k in STAGES[:4]),
                        "single_edge": sum(one_ms[k] for k in STAGES[:4])},
         "stage_ms_batch": stage_ms, "stage_ms_single_edge": one_ms,
-        "time_split_s": {"elapsed": elapsed, "steps_in_flight": len(tracers), "pipelined": pipeline, "pipeline_depth": depth,
+        "time_split_s": {"elapsed": elapsed, "steps_in_flight": n_in_flight, "pipelined": pipeline, "pipeline_depth": depth,
                          "loop_wall_per_thread": loop_s, "fit_wall_per_thread": fit_s,
                          "loop_wall_mean": (sum(loop_walls) / len(loop_walls)) if loop_walls else None,
                          "fit_wall_mean": (sum(fit_walls) / len(fit_walls)) if fit_walls else None,
