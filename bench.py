@@ -386,8 +386,8 @@ def secondary_config5(pkg, ctx, n_chains=8, frames_per_chain=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=16)  # (a multiple of the objects in flight: no half-empty last round)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--edges", type=int, default=1024,
                     help="independent edges per GPU and step (BASELINE config 4 is a batch of independent 500x500 edges).  With "
                          "several steps in flight (--pipeline-depth) the throughput no longer depends on the batch size: 7.3-7.4 k "
