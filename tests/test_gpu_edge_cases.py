@@ -491,3 +491,21 @@ def test_sample_gemm_of_a_narrow_edge_leaves_the_neighbouring_buffers_alone(amd,
     assert np.array_equal(np.array(b.read(L.BUF_COSTS)), costs)
     assert np.array_equal(np.array(b.read(L.BUF_BEST_IDX)), best)
     assert np.array_equal(np.array(b.read(L.BUF_SAMPLES)), Y)
+
+
+def test_batch_with_different_numbers_of_init_points(amd, ctx):
+    """`init` may hold more than the two end points (gpet.py:96-100 takes any (N_inits, 2) array): edges of one batch with two,
+    three and four init points -- the init points of a batch sit in one contiguous device array with the widest edge's stride --
+    each equal to its single-edge run and to the oracle."""
+    grad, truth = _image(96, 4)
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 10, 'length_scale': 7}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=4, keep_ratio=0.1, pixel_thresh=3, fix_endpoints=True)
+    cols = [[0, 95], [0, 40, 95], [0, 30, 60, 95], [0, 95]]
+    inits = [np.array([[c, int(truth[c, 0])] for c in cs]) for cs in cols]
+    seeds = [3, 4, 5, 6]
+    out = amd.GP_Edge_Tracing_Batch(inits, grad, seeds, **kw, _ctx=ctx)()
+    for e, (init, seed) in enumerate(zip(inits, seeds)):
+        single = amd.GP_Edge_Tracing(init, grad, seed=seed, **kw, _ctx=ctx)()
+        assert np.array_equal(out[e], single), "edge %d" % e
+        et_o, _, _ = orc.trace(init, grad, seed=seed, sign_convention="harmonic", **kw)
+        assert np.array_equal(out[e], et_o), "edge %d vs oracle" % e
