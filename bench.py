@@ -21,7 +21,12 @@ import time
 # the runtime's default of FOUR hardware queues per process alias heavily (streams of one queue run in order).  Eight queues:
 # +2-3 % on the headline, +9 % on batches of 256 (profiles/r05_hw_queues.txt; 12 and 16 hurt the single-edge latency).  The HIP
 # runtime reads this variable when it initialises, so it is set before anything that loads it; a value the caller has set wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("GPET_BENCH_HW_QUEUES") == "runtime-default":
+    # (the child run behind secondary.hw_queues_runtime_default: what the HIP runtime does when nobody sets the variable --
+    #  the package itself sets 8 when it loads, gaussian_process_edge_trace_amd/_lib.py, unless the environment has a value)
+    os.environ["GPU_MAX_HW_QUEUES"] = "4"
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -400,6 +405,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (ctor included, 256 edges, "
                     "distinct images, configs 3 and 5)")
+    ap.add_argument("--headline-only", action="store_true", help="print {value, ms_per_step, hip_hw_queues} after the timed steps and stop "
+                    "(the child runs of secondary.hw_queues_runtime_default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -525,6 +532,14 @@ def main():
         elapsed = float(tt.item())
     total_traces = E * world * args.steps
     value = total_traces / elapsed
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"value": value, "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
+                              "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "objects_in_flight": len(tracers)}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- N > 1: BASELINE config 4 as stated (256 edges over the ranks) measured for real: every rank traces its 256 / world
     #      edges -- as 1, 2 or 4 objects in flight, the best of them -- between two barriers; the job is the slowest rank's time
@@ -538,7 +553,7 @@ def main():
             if share % k or share // k < 1:
                 continue
             per = share // k
-            objs = [make_tracer(per, tracers[j]._ctx, sds=[1 + SEED_STRIDE * (rank * share + j * per + e) for e in range(per)]) for j in range(k)]
+            objs = [make_tracer(per, tracers[j % len(tracers)]._ctx, sds=[1 + SEED_STRIDE * (rank * share + j * per + e) for e in range(per)]) for j in range(k)]
             job_ms(objs, pool4, reps=1)  # (warm-up)
             barrier()
             ta = time.time()
@@ -565,10 +580,26 @@ def main():
     # ---- quality of this rank's traces vs ground truth (sanity band, not the metric)
     mse = float(np.mean([pkg.gpet_utils.trace_MSE(tr, truth) for tr in traces]))
 
-    # ---- secondary figures (N = 1 only): what the headline leaves out, each a short run of its own
+    # ---- secondary figures (N = 1 only): what the headline leaves out, each a short run of its own.  Every one runs inside
+    #      its own try: a failure (an allocation, a mode that does not apply) becomes {"error": ...} in its slot and can never
+    #      cost the contract line
     secondary = None
-    if world == 1 and not args.no_secondary:
-        secondary = {}
+    n_sec = 2 * len(tracers)  # steps of a secondary run: two per batch object in flight
+
+    def sync_all(objs):
+        for o in objs:
+            o._ctx.sync()
+
+    def run_secondary(name, fn):
+        import traceback
+        try:
+            secondary[name] = fn()
+        except Exception as ex:  # noqa: BLE001 -- anything: the headline must survive
+            secondary[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            log("secondary %s FAILED: %s\n%s" % (name, ex, traceback.format_exc()))
+        return secondary[name]
+
+    def sec_ctor_included():
         # (a) constructor INCLUDED: a fresh batch object per step (arena, image upload + re-normalisation, gradient KDE,
         #     prior eigenbasis of every edge), then loop + fits, nothing overlapped
         ctx2 = L.Context(dev_index)
@@ -583,140 +614,256 @@ def main():
             fresh._batch.close()
             del fresh
         best = min(t_c)
-        secondary["ctor_included"] = dict(traces_per_s=E / best[0], s_per_step=best[0], ctor_s=best[1], edges=E,
-                                          note="fresh GP_Edge_Tracing_Batch per step, loop + converged fits not overlapped with anything")
+        return dict(traces_per_s=E / best[0], s_per_step=best[0], ctor_s=best[1], edges=E,
+                    note="fresh GP_Edge_Tracing_Batch per step, loop + converged fits not overlapped with anything")
+
+    def sec_no_pipeline():
         # (b) the same without pipelining (ctor excluded): the loop and the fits of ONE batch object back to back
-        fw = []
-        l1, f1, _, _ = timed_steps([tracer], 3, 0, executor, fw)
-        secondary["no_pipeline"] = dict(traces_per_s=3 * E / (l1 + f1), loop_s_per_step=l1 / 3, fit_s_per_step=f1 / 3, edges=E)
+        l1, f1, _, _ = timed_steps([tracer], 3, 0, executor, [])
+        return dict(traces_per_s=3 * E / (l1 + f1), loop_s_per_step=l1 / 3, fit_s_per_step=f1 / 3, edges=E)
+
+    def timed_mode(objs, n_steps):
+        """warm-up (one step per object), then n_steps pipelined steps between syncs: (seconds, traces of the last step)"""
+        sync_all(objs)
+        timed_steps(objs, len(objs), depth, executor, [])
+        sync_all(objs)
+        t1 = time.time()
+        _, _, it_, tr_ = timed_steps(objs, n_steps, depth, executor, [])
+        sync_all(objs)
+        return time.time() - t1, it_, tr_
+
+    def sec_f32_samples():
         # (b2) the opt-in f32 storage of the samples (BASELINE config 2: "fp64 Cholesky + fp32 posterior samples"): the same
         #      pipelined steps with gpet_batch_set_sample_dtype(1); never the headline (parity is stated on f64 samples)
-        for tr_ in tracers:
-            tr_._ctx.sync()
-            tr_._batch.set_sample_dtype("f32")
-        timed_steps(tracers, len(tracers), depth, executor, [])
-        for tr_ in tracers:
-            tr_._ctx.sync()
-        t1 = time.time()
-        n_sec = 2 * len(tracers)  # steps of a secondary run: two per batch object in flight
-        _, _, it_f32, tr_f32 = timed_steps(tracers, n_sec, depth, executor, [])
-        for tr_ in tracers:
-            tr_._ctx.sync()
-        dt_f32 = time.time() - t1
-        for tr_ in tracers:
-            tr_._batch.set_sample_dtype("f64")
-        secondary["f32_samples"] = dict(traces_per_s=n_sec * E / dt_f32, ms_per_step=1e3 * dt_f32 / n_sec, edges=E,
-                                        trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_f32])),
-                                        note="sample GEMM stores f32, scorer/KDE widen; all arithmetic f64; opt-in, "
-                                             "tests/test_gpu_trace.py::test_full_trace_f32_samples_vs_oracle")
+        try:
+            for tr_ in tracers:
+                tr_._ctx.sync()
+                tr_._batch.set_sample_dtype("f32")
+            dt_f32, _, tr_f32 = timed_mode(tracers, n_sec)
+        finally:
+            for tr_ in tracers:
+                tr_._ctx.sync()
+                tr_._batch.set_sample_dtype("f64")
+        return dict(traces_per_s=n_sec * E / dt_f32, ms_per_step=1e3 * dt_f32 / n_sec, edges=E,
+                    trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_f32])),
+                    note="sample GEMM stores f32, scorer/KDE widen; all arithmetic f64; opt-in, "
+                         "tests/test_gpu_trace.py::test_full_trace_f32_samples_vs_oracle")
+
+    def sec_philox():
         # (b3) the opt-in counter-based generator (SURVEY K5: Philox4x32-10 + Box-Muller instead of numpy's RandomState stream):
         #      other numbers than the reference draws, so never the headline
-        for tr_ in tracers:
-            tr_._ctx.sync()
-            tr_._batch.set_rng("philox")
-        timed_steps(tracers, len(tracers), depth, executor, [])
-        for tr_ in tracers:
-            tr_._ctx.sync()
-        t1 = time.time()
-        _, _, it_px, tr_px = timed_steps(tracers, n_sec, depth, executor, [])
-        for tr_ in tracers:
-            tr_._ctx.sync()
-        dt_px = time.time() - t1
-        px_normals_ms = tracer._batch.profile_stage(2, 5)
-        for tr_ in tracers:
-            tr_._batch.set_rng("mt19937")
-        secondary["philox_rng"] = dict(traces_per_s=n_sec * E / dt_px, ms_per_step=1e3 * dt_px / n_sec, edges=E,
-                                       normals_ms_per_ring=px_normals_ms,
-                                       trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_px])),
-                                       note="gpet_batch_set_rng(1): not the reference's random numbers; "
-                                            "tests/test_gpu_stages.py::test_full_trace_philox_mode_vs_oracle")
+        try:
+            for tr_ in tracers:
+                tr_._ctx.sync()
+                tr_._batch.set_rng("philox")
+            dt_px, _, tr_px = timed_mode(tracers, n_sec)
+            px_normals_ms = tracer._batch.profile_stage(2, 5)
+        finally:
+            for tr_ in tracers:
+                tr_._ctx.sync()
+                tr_._batch.set_rng("mt19937")
+        return dict(traces_per_s=n_sec * E / dt_px, ms_per_step=1e3 * dt_px / n_sec, edges=E, normals_ms_per_ring=px_normals_ms,
+                    trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in tr_px])),
+                    note="gpet_batch_set_rng(1): not the reference's random numbers; "
+                         "tests/test_gpu_stages.py::test_full_trace_philox_mode_vs_oracle")
+
+    def alone_ms(obj, reps=5):
+        ts_ = []
+        for _ in range(reps + 1):
+            obj._ctx.sync()
+            ta = time.time()
+            obj.reset()
+            obj.finish(obj.run_loop())
+            obj._ctx.sync()
+            ts_.append(1e3 * (time.time() - ta))
+        return float(np.median(ts_[1:]))
+
+    def close_all(objs):
+        for o in objs:
+            try:
+                o._batch.close()
+            except Exception:  # noqa: BLE001
+                pass
+
+    def sec_edges_256_and_32():
         # (c) BASELINE config 4's batch size: 256 edges per step (pipelined like the headline)
-        small = [make_tracer(256, tr_._ctx) for tr_ in tracers]
-        timed_steps(small, len(small), depth, executor, [])
-        for tr_ in small:
-            tr_._ctx.sync()
-        t1 = time.time()
-        l2, f2, it2, _ = timed_steps(small, 2 * n_sec, depth, executor, [])
-        for tr_ in small:
-            tr_._ctx.sync()
-        dt2 = time.time() - t1
-        secondary["edges_256"] = dict(traces_per_s=2 * n_sec * 256 / dt2, ms_per_step=1e3 * dt2 / (2 * n_sec), iterations=sorted(set(it2)),
-                                      in_flight=len(small))
-        # (c2) config 4 AS STATED is 256 edges over 8 GPUs = 32 edges per GPU: one job, nothing to pipeline with.  One batch
-        #      object alone on the GPU at 256 and at 32 edges (median of five steps, loop + converged fits back to back);
-        #      t(256) / t(32) is the strong-scaling factor 8 GPUs can reach on that job (no collective on the path; the
-        #      broadcast of the 1 MB image is reported as bcast_grad_ms at N > 1)
-        def alone_ms(obj, reps=5):
-            ts_ = []
-            for _ in range(reps + 1):
-                obj._ctx.sync()
-                ta = time.time()
-                obj.reset()
-                obj.finish(obj.run_loop())
-                obj._ctx.sync()
-                ts_.append(1e3 * (time.time() - ta))
-            return float(np.median(ts_[1:]))
-        t256 = alone_ms(small[0])
-        e32 = make_tracer(32, tracers[0]._ctx)
-        t32 = alone_ms(e32)
-        e32s = [e32] + [make_tracer(32, tr_._ctx, sds=seeds_of(k_ + 1)[:32]) for k_, tr_ in enumerate(tracers[1:])]
-        timed_steps(e32s, len(e32s), depth, executor, [])
-        for tr_ in e32s:
-            tr_._ctx.sync()
-        t1 = time.time()
-        timed_steps(e32s, 4 * n_sec, depth, executor, [])
-        for tr_ in e32s:
-            tr_._ctx.sync()
-        dt32 = time.time() - t1
-        secondary["edges_32"] = dict(ms_per_step_alone=t32, traces_per_s_alone=32 / (1e-3 * t32),
-                                     traces_per_s_in_flight=4 * n_sec * 32 / dt32, in_flight=len(e32s),
-                                     edges_256_ms_per_step_alone=t256,
-                                     predicted_strong_scaling_8_gpus=t256 / t32,
-                                     note="BASELINE config 4 as stated: 256 edges / 8 GPUs = 32 per GPU; one batch object alone "
-                                          "(loop + converged fits), median of 5; prediction = t(256 alone) / t(32 alone)")
-        for tr_ in e32s:
-            tr_._batch.close()
-        del e32s, e32
-        for tr_ in small:
-            tr_._batch.close()
-        del small
-        # (d) distinct images and inits: 256 edges, every edge its own noise realisation of the image (own gradient image,
-        #     own gradient KDE) and its own end points -- nothing shared through L2
+        small, e32s = [], []
+        try:
+            small = [make_tracer(256, tr_._ctx) for tr_ in tracers]
+            dt2, it2, _ = timed_mode(small, 2 * n_sec)
+            out256 = dict(traces_per_s=2 * n_sec * 256 / dt2, ms_per_step=1e3 * dt2 / (2 * n_sec), iterations=sorted(set(it2)),
+                          in_flight=len(small))
+            # (c2) config 4 AS STATED is 256 edges over 8 GPUs = 32 edges per GPU: one job, nothing to pipeline with.  One batch
+            #      object alone on the GPU at 256 and at 32 edges (median of five steps, loop + converged fits back to back);
+            #      t(256) / t(32) is the strong-scaling factor 8 GPUs can reach on that job (no collective on the path; the
+            #      broadcast of the 1 MB image is reported as bcast_grad_ms at N > 1)
+            t256 = alone_ms(small[0])
+            e32s = [make_tracer(32, tracers[0]._ctx)]
+            t32 = alone_ms(e32s[0])
+            e32s += [make_tracer(32, tr_._ctx, sds=seeds_of(k_ + 1)[:32]) for k_, tr_ in enumerate(tracers[1:])]
+            dt32, _, _ = timed_mode(e32s, 4 * n_sec)
+            secondary["edges_32"] = dict(ms_per_step_alone=t32, traces_per_s_alone=32 / (1e-3 * t32),
+                                         traces_per_s_in_flight=4 * n_sec * 32 / dt32, in_flight=len(e32s),
+                                         edges_256_ms_per_step_alone=t256, predicted_strong_scaling_8_gpus=t256 / t32,
+                                         note="BASELINE config 4 as stated: 256 edges / 8 GPUs = 32 per GPU; one batch object alone "
+                                              "(loop + converged fits) beside the idle pipeline objects, median of 5; prediction = "
+                                              "t(256 alone) / t(32 alone); config4_literal repeats it with the pipeline objects freed")
+            return out256
+        finally:
+            close_all(e32s)
+            close_all(small)
+
+    def distinct_inputs(n_img, base_seed):
         imgs, inits_d = [], []
-        for e in range(256):
-            im_e, tr_e = synth_image(N, 1000 + e)
+        for e in range(n_img):
+            im_e, tr_e = synth_image(N, base_seed + e)
             imgs.append(pkg.gpet_utils.comp_grad_img(im_e, pkg.gpet_utils.kernel_builder((11, 5)), ctx=ctx))
             inits_d.append(tr_e[[0, -1], :][:, [1, 0]])
-        dist_tr = [make_tracer(256, tr_._ctx, images=imgs, inits=inits_d, sds=seeds[:256]) for tr_ in tracers[:2]]
-        timed_steps(dist_tr, 2, min(depth, 1), executor, [])
-        t1 = time.time()
-        timed_steps(dist_tr, 6, min(depth, 1), executor, [])
-        for tr_ in dist_tr:
-            tr_._ctx.sync()
-        dt3 = time.time() - t1
-        secondary["edges_256_distinct_images"] = dict(traces_per_s=6 * 256 / dt3, ms_per_step=1e3 * dt3 / 6)
-        for tr_ in dist_tr:
-            tr_._batch.close()
-        del dist_tr, imgs
-        log("secondary: ctor included %.0f traces/s, no pipeline %.0f, 256 edges %.0f, 256 distinct images %.0f"
-            % (secondary["ctor_included"]["traces_per_s"], secondary["no_pipeline"]["traces_per_s"],
-               secondary["edges_256"]["traces_per_s"], secondary["edges_256_distinct_images"]["traces_per_s"]))
+        return imgs, inits_d
+
+    def sec_distinct_images():
+        # (d) distinct images and inits: 256 edges, every edge its own noise realisation of the image (own gradient image,
+        #     own gradient KDE) and its own end points -- nothing shared through L2
+        dist_tr = []
+        try:
+            imgs, inits_d = distinct_inputs(256, 1000)
+            dist_tr = [make_tracer(256, tr_._ctx, images=imgs, inits=inits_d, sds=seeds[:256]) for tr_ in tracers[:2]]
+            timed_steps(dist_tr, 2, min(depth, 1), executor, [])
+            t1 = time.time()
+            timed_steps(dist_tr, 6, min(depth, 1), executor, [])
+            sync_all(dist_tr)
+            dt3 = time.time() - t1
+            return dict(traces_per_s=6 * 256 / dt3, ms_per_step=1e3 * dt3 / 6)
+        finally:
+            close_all(dist_tr)
+
+    def sec_fresh_images_pipelined():
+        # (e) a NEW image and new end points for every step, pipelined like the headline: batch objects of 256 edges, one image
+        #     each (256 distinct gradient images per step), every step starts with set_frame (gpet_batch_set_images: upload,
+        #     re-normalisation, gradient KDE of all 256 images; next_frame=False: unrelated images, nothing carried over).  The
+        #     end points stay (a batch object's geometry is fixed at construction): what a server tracing one set of edge
+        #     geometries through fresh images pays per step
+        objs = []
+        try:
+            pools = [distinct_inputs(256, 3000 + 256 * k) for k in range(2)]
+            objs = [make_tracer(256, tr_._ctx, images=pools[0][0], inits=pools[0][1], sds=seeds[:256]) for tr_ in tracers]
+            W = len(objs)
+
+            def worker(w):
+                tr_, t_set = objs[w], 0.0
+                for k in range(4):
+                    ta = time.time()
+                    tr_.set_frame(pools[(k + 1) % 2][0], next_frame=False)
+                    t_set += time.time() - ta
+                    tr_.finish(tr_.run_loop())
+                return t_set
+            list(executor.map(lambda w: (objs[w].reset(), objs[w].finish(objs[w].run_loop())), range(W)))
+            sync_all(objs)
+            t1 = time.time()
+            t_sets = list(executor.map(worker, range(W)))
+            sync_all(objs)
+            dt = time.time() - t1
+            return dict(traces_per_s=4 * W * 256 / dt, ms_per_step=1e3 * dt / (4 * W), in_flight=W, edges=256, steps=4 * W,
+                        set_frame_ms_per_step=1e3 * float(np.mean(t_sets)) / 4,
+                        note="every step: set_frame with 256 new gradient images (host -> device, re-normalisation, gradient KDE), then "
+                             "loop + converged fits; %d objects in flight; compare edges_256_distinct_images (images resident) and "
+                             "edges_256 (one shared image)" % W)
+        finally:
+            close_all(objs)
+
+    def sec_default_kernel():
+        # (f) the reference's DEFAULT kernel: GP_Edge_Tracing(init, grad) with kernel_options=(1, 3, 3) (gpet.py:25,139-151) is
+        #     Matern-5/2 with sigma_f = M // 6, length_scale = edge_length // 2 -> a full-rank posterior covariance, the any-rank
+        #     factor (csrc/gpet_eig.hip).  Same image, S, delta_x, pixel_thresh as the headline.  One edge and a batch of 256.
+        kw = dict(README_KW)
+        kw["kernel_options"] = (1, 3, 3)
+        objs = []
+        try:
+            one_ = pkg.GP_Edge_Tracing_Batch([init], grad, [1], **kw, _ctx=ctx)
+            objs.append(one_)
+            one_()
+            runs = []
+            out_one = None
+            for _ in range(3):
+                one_.reset()
+                ts = time.time()
+                out_one = one_()
+                runs.append(time.time() - ts)
+            it_one = list(one_.timings["iters"])
+            mse_one = float(pkg.gpet_utils.trace_MSE(out_one[0], truth))
+            nb = 64
+            bt_ = pkg.GP_Edge_Tracing_Batch([init] * nb, grad, seeds[:nb], **kw, _ctx=ctx)
+            objs.append(bt_)
+            bt_()
+            tb = []
+            for _ in range(2):
+                bt_.reset()
+                ts = time.time()
+                out_b = bt_()
+                tb.append(time.time() - ts)
+            out = dict(config="kernel_options=(1, 3, 3): Matern nu=2.5, sigma_f=%d, length_scale=%d (gpet.py:139-151); otherwise the headline's edge"
+                              % (N // 6, N // 2),
+                       single_edge_ms_per_trace=1e3 * float(np.median(runs)), single_edge_iterations=it_one,
+                       batch_edges=nb, batch_ms=1e3 * min(tb), batch_traces_per_s=nb / min(tb),
+                       batch_trace_mse_vs_truth=float(np.mean([pkg.gpet_utils.trace_MSE(t_, truth) for t_ in out_b])),
+                       single_trace_mse_vs_truth=mse_one)
+            if not args.no_cpu_baseline:
+                from oracle import gpet_oracle as orc
+                from threadpoolctl import threadpool_limits
+                img_o, edge_o = orc.synth_sinusoid_image(N, 3)
+                g_o = orc.comp_grad_img(img_o, orc.kernel_builder((11, 5)))
+                with threadpool_limits(limits=1):
+                    t0_ = time.time()
+                    _, _, info = orc.trace(edge_o[[0, -1], :][:, [1, 0]], g_o, per_curve=True, seed=1, **kw)
+                    dt_ = time.time() - t0_
+                out["cpu_port"] = dict(s_per_trace=dt_, iterations=info["n_iter"], cores=1,
+                                       note="oracle/gpet_oracle.py, one BLAS thread, one trace, constructor included")
+                out["single_edge_speedup_vs_cpu_port"] = dt_ / float(np.median(runs))
+            return out
+        finally:
+            close_all(objs)
+
+    def sec_hw_queues_runtime_default():
+        # (g) the headline's steps in a CHILD process with the HIP runtime's own default of four hardware queues (this process
+        #     and the package run with eight: GPU_MAX_HW_QUEUES is read once, when the runtime initialises)
+        import subprocess
+        env = dict(os.environ, GPET_BENCH_HW_QUEUES="runtime-default")
+        env.pop("GPU_MAX_HW_QUEUES", None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(8, args.steps)), "--warmup", str(max(8, args.warmup)),
+               "--edges", str(E), "--size", str(N), "--pipeline-depth", str(args.pipeline_depth), "--headline-only"]
+        r_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r_.stdout.splitlines() if ln.startswith("{")]
+        if r_.returncode != 0 or not lines:
+            raise RuntimeError("child bench failed (rc %d): %s" % (r_.returncode, r_.stderr[-400:]))
+        out = json.loads(lines[-1])
+        out["note"] = "the same steps with GPU_MAX_HW_QUEUES = 4 (the HIP runtime's default) in a child process; the headline runs with 8"
+        out["headline_over_this"] = value / out["value"]
+        return out
+
+    if world == 1 and not args.no_secondary:
+        secondary = {}
+        run_secondary("ctor_included", sec_ctor_included)
+        run_secondary("no_pipeline", sec_no_pipeline)
+        run_secondary("f32_samples", sec_f32_samples)
+        run_secondary("philox_rng", sec_philox)
+        run_secondary("edges_256", sec_edges_256_and_32)
+        run_secondary("edges_256_distinct_images", sec_distinct_images)
+        run_secondary("fresh_images_pipelined", sec_fresh_images_pipelined)
+        log("secondary: " + ", ".join("%s %s" % (k, ("%.0f traces/s" % v["traces_per_s"]) if isinstance(v, dict) and "traces_per_s" in v else "(see entry)")
+                                      for k, v in secondary.items()))
         release_pipeline_objects()
-        secondary["config3"] = secondary_config3(pkg, ctx)
-        log("secondary: config 3 GP iteration %.2f ms + scoring %.2f ms" % (secondary["config3"]["gp_iter_ms"], secondary["config3"]["scoring_ms"]))
-        secondary["config3_batch"] = secondary_config3(pkg, ctx, n_edges=8)
-        log("secondary: config 3 x 8 edges: fit + predict + covariance %.2f ms = %.1f TFLOP/s"
-            % (secondary["config3_batch"]["stage_ms"]["fit_predict_cov"], secondary["config3_batch"]["fit_predict_cov_tflops"]))
-        secondary["config5"] = secondary_config5(pkg, ctx)
-        log("secondary: config 5 %.2f frames/s (8 chains), single chain %.3f s per frame"
-            % (secondary["config5"]["frames_per_s"], secondary["config5"]["single_chain_s_per_frame"]))
-        secondary["config4_literal"] = config4_literal(pkg, L, dev_index, make_tracer, seeds)
-        log("secondary: config 4 as stated: 256 edges %s ms, 32-edge share %s ms -> predicted %.2f x on 8 GPUs"
-            % (secondary["config4_literal"]["whole_job_ms"], secondary["config4_literal"]["share_ms"],
-               secondary["config4_literal"]["predicted_speedup_8_gpus"]))
-        secondary["readme_literal"] = readme_literal(pkg, L, dev_index, ctx, init, grad, seeds, with_cpu=not args.no_cpu_baseline)
-        log("secondary: README-literal call (pixel_thresh 2): single edge %.2f ms, batch %.0f traces/s"
-            % (secondary["readme_literal"]["single_edge_ms_per_trace"], secondary["readme_literal"]["batch_traces_per_s"]))
+        run_secondary("hw_queues_runtime_default", sec_hw_queues_runtime_default)
+        run_secondary("default_kernel_500", sec_default_kernel)
+        run_secondary("config3", lambda: secondary_config3(pkg, ctx))
+        run_secondary("config3_batch", lambda: secondary_config3(pkg, ctx, n_edges=8))
+        run_secondary("config5", lambda: secondary_config5(pkg, ctx))
+        run_secondary("config4_literal", lambda: config4_literal(pkg, L, dev_index, make_tracer, seeds))
+        run_secondary("readme_literal", lambda: readme_literal(pkg, L, dev_index, ctx, init, grad, seeds, with_cpu=not args.no_cpu_baseline))
+        for k in ("hw_queues_runtime_default", "default_kernel_500", "config3", "config3_batch", "config5", "config4_literal", "readme_literal"):
+            v = secondary.get(k) or {}
+            keys = [q for q in ("value", "single_edge_ms_per_trace", "batch_traces_per_s", "gp_iter_ms", "scoring_ms", "frames_per_s",
+                                "whole_job_ms", "share_ms", "predicted_speedup_8_gpus", "error") if q in v]
+            log("secondary %s: %s" % (k, ", ".join("%s=%s" % (q, ("%.3f" % v[q]) if isinstance(v[q], float) else v[q]) for q in keys)))
 
     # ---- one step alone (nothing else on the GPU): device time of the LML kernel launches of its converged fits,
     #      hipEvents around every launch on the fit stream (gpet_lml_stats)

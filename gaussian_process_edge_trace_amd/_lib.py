@@ -100,6 +100,8 @@ SYMBOLS = {
     "gpet_final_optimize": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int32)]),
     "gpet_batch_set_sample_dtype": (C.c_int, [_P, C.c_int]),
     "gpet_batch_set_rng": (C.c_int, [_P, C.c_int]),
+    "gpet_batch_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "gpet_batch_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "gpet_trace_iterate": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int)]),
     "gpet_comm_unique_id": (C.c_int, [_P]),
     "gpet_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -127,11 +129,24 @@ def get_option(name):
     return v.value
 
 
-def set_option(name, value):
-    """Process-wide tuning switch of the library (gpet_set_option); returns the previous value (-1 = automatic)."""
+_live_batches = []  # weak references to the Batch objects of this process (set_option(..., live_batches=True))
+
+
+def set_option(name, value, live_batches=True):
+    """Process-wide tuning switch of the library (gpet_set_option); returns the previous value (-1 = automatic).
+    The library gives every batch its own copy of the table when the batch is created (gpet_batch_set_option changes that
+    copy), so a switch set here reaches only batches created afterwards -- unless ``live_batches`` (the default, what tools
+    and tests that flip a switch on an existing object mean): then it is also written into every live Batch of this process."""
     old = get_option(name)
     if load().gpet_set_option(name.encode(), int(value)) < 0:
         raise ValueError("unknown option %r" % (name,))
+    if live_batches:
+        for ref in list(_live_batches):
+            b = ref()
+            if b is None or not getattr(b, "h", None):
+                _live_batches.remove(ref)
+            else:
+                b.set_option(name, value)
     return old
 
 
@@ -156,6 +171,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  gaussian_process_edge_trace_amd has no CPU fallback.")
+    # Deployment setting of the package: eight HIP hardware queues per process instead of the runtime's four.  A tracer drives
+    # three streams per batch object (loop, RNG look-ahead, converged fits) and a server keeps several objects in flight; on four
+    # queues they alias (+2-3 % throughput at 1 024 edges, +9 % at 256 with eight: profiles/r05_hw_queues.txt; 12 and more
+    # hurt the latency of small batches).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the
+    # process: a value already in the environment wins, and a process that touched the GPU before importing this keeps its own.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
@@ -180,6 +201,7 @@ class Context:
             raise GpetError(rc, "gpet_ctx_create failed")
         self.h = h
         self.device = device
+        self._comms = []  # (weak references to the communicators built on this context: close() closes them first)
 
     def check(self, rc):
         if rc != OK:
@@ -212,6 +234,11 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in list(getattr(self, "_comms", [])):  # (their buffers are freed through this context's handle)
+                cm = ref()
+                if cm is not None:
+                    cm.close()
+            self._comms = []
             self.lib.gpet_ctx_destroy(self.h)
             self.h = None
 
@@ -243,6 +270,8 @@ class Comm:
         self.h = h
         self.world, self.rank = int(world), int(rank)
         self._bufs = []
+        import weakref
+        ctx._comms.append(weakref.ref(self))
 
     def block(self, n_units):
         lo, hi = C.c_int64(), C.c_int64()
@@ -289,8 +318,9 @@ class Comm:
 
     def close(self):
         if getattr(self, "h", None):
-            for d in self._bufs:
-                self.lib.gpet_dev_free(self.ctx.h, d)
+            if getattr(self.ctx, "h", None):  # (a context closed first has already closed this communicator: see Context.close)
+                for d in self._bufs:
+                    self.lib.gpet_dev_free(self.ctx.h, d)
             self._bufs = []
             self.lib.gpet_comm_destroy(self.h)
             self.h = None
@@ -338,6 +368,10 @@ class Batch:
                                               C.byref(h)))
         self.h = h
         self.B = B
+        import weakref
+        _live_batches.append(weakref.ref(self))
+        if len(_live_batches) > 4096:  # (drop the references of batches that are gone)
+            _live_batches[:] = [r for r in _live_batches if r() is not None and getattr(r(), "h", None)]
         self._scored = False
         self.share_image = bool(share_image)
         self._keep = (grads, inits)
@@ -487,6 +521,19 @@ class Batch:
         self.ctx.check(self.lib.gpet_final_fit_all(self.h, s, mean.ctypes.data, std.ctypes.data, th.ctypes.data, Lg,
                                                    C.byref(rounds)))
         return mean, std, th[:, :3].copy(), th[:, 3].copy(), rounds.value
+
+    def set_option(self, name, value):
+        """This batch's own copy of a tuning switch (gpet_batch_set_option); returns the previous value (-1 = automatic)."""
+        old = self.get_option(name)
+        if self.lib.gpet_batch_set_option(self.h, name.encode(), int(value)) < 0:
+            raise ValueError("unknown option %r" % (name,))
+        return old
+
+    def get_option(self, name):
+        v = C.c_int()
+        if self.lib.gpet_batch_get_option(self.h, name.encode(), C.byref(v)) != 0:
+            raise ValueError("unknown option %r" % (name,))
+        return v.value
 
     def set_rng(self, rng):
         """Random numbers of the batch: "mt19937" (default: numpy's RandomState stream, the reference's) or "philox"

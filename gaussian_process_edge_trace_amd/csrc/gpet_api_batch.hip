@@ -11,7 +11,7 @@ int nu_to_code(double nu) {
 }
 
 // lays out one edge's buffers; with base == nullptr only measures
-void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
+void carve_edge(Carver& cv, EdgeDev& E, bool own_image, int batch_lg) {
   const size_t Lg = E.Lg, nc = E.n_cap, rc = E.r_cap, S = E.S;
   const size_t px = (size_t)E.M * E.N, gpx = (size_t)(E.M + 2) * (E.N + 2);
   E.init_xy = cv.take<long long>(2 * (size_t)E.n_init);
@@ -44,7 +44,9 @@ void carve_edge(Carver& cv, EdgeDev& E, bool own_image) {
   E.h0 = cv.take<double>(rc);
   E.rho_tab = cv.take<double>((size_t)E.N);
   E.eig = cv.take<EigState>(1);
-  E.Gt = cv.take<double>((rc > 96 || Lg > 1024) ? Lg * rc : 1);  // (transposed copy of G: the multi-workgroup pivoted Cholesky)
+  // (transposed copy of G: the any-rank factor, and the multi-workgroup pivoted Cholesky -- which launch_factor picks per BATCH
+  //  from the widest edge, pchol_multi_applies, and which then writes Gt of EVERY edge of the batch: the condition is the batch's)
+  E.Gt = cv.take<double>((rc > 96 || batch_lg > 1024) ? Lg * rc : 1);
   E.Ap = cv.take<double>(rc > 96 ? 2 * Lg * rc : 1);
   E.ap_tag = cv.take<int>(3);
   E.pcx_d = cv.take<double>(Lg);
@@ -129,6 +131,8 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   if (!b) return fail(c, GPET_ERR_HIP, "out of host memory");
   BatchGuard guard;
   guard.b = b;
+  option_snapshot(&b->opts);  // the process-wide table as it is NOW is this batch's for its lifetime
+  GPET_BATCH_SCOPE(b);
   b->ctx = c;
   b->B = B;
   b->share_image = share_image ? 1 : 0;
@@ -234,7 +238,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   int n_init_max = 1;
   for (int e = 0; e < B; ++e) n_init_max = b->h_edges[e].n_init > n_init_max ? b->h_edges[e].n_init : n_init_max;
   (void)meas.take<long long>((size_t)B * 2 * (size_t)n_init_max);
-  for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image);
+  for (int e = 0; e < B; ++e) carve_edge(meas, tmp[e], !b->share_image, bd.Lg);
   (void)shared_grad;
   (void)shared_kde;
   b->arena_bytes = meas.off + 256;
@@ -260,7 +264,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     EdgeDev& E = b->h_edges[e];
     E.sc = b->d_scalars + e;
     E.fin_out = b->d_fin_out + (size_t)e * 2 * bd.Lg;
-    carve_edge(cv, E, !b->share_image);
+    carve_edge(cv, E, !b->share_image, bd.Lg);
     E.fin_par = b->d_fin_par + (size_t)e * 12;                 // (batch-contiguous; the per-edge carve is unused)
     E.obs_xy = b->d_obs + (size_t)e * 2 * bd.obs_cap;
     E.init_xy = b->d_init + (size_t)e * 2 * (size_t)n_init_max;  // (batch-contiguous; the per-edge carve is unused)
@@ -401,6 +405,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
 }
 
 void gpet_batch_destroy(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
@@ -521,6 +526,7 @@ static int carry_factor_rows_all(gpet_batch* b, const std::vector<int>& iters) {
 }
 
 int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
+  GPET_BATCH_SCOPE(b);
   if (!b || e < 0 || e >= b->B || n_obs < 0 || (n_obs > 0 && !obs_xy)) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
@@ -561,6 +567,7 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
 }
 
 int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
+  GPET_BATCH_SCOPE(b);
   if (!b || e < 0 || e >= b->B || !dst) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -656,6 +663,7 @@ int gpet_batch_read(gpet_batch* b, int e, int which, void* dst, size_t bytes) {
 }
 
 int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t bytes, int rows) {
+  GPET_BATCH_SCOPE(b);
   if (!b || e < 0 || e >= b->B || !src) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -723,7 +731,21 @@ int gpet_batch_write(gpet_batch* b, int e, int which, const void* src, size_t by
   return GPET_OK;
 }
 
+// the batch's own option table (a copy of the process-wide one taken at gpet_batch_create): returns like gpet_set_option
+int gpet_batch_set_option(gpet_batch* b, const char* name, int value) {
+  if (!b) return -1;
+  int prev = 0, idx = -1;
+  for (int i = 0; i < option_count(); ++i)
+    if (name && strcmp(option_def(i).name, name) == 0) idx = i;
+  if (idx < 0 || option_set_in(&b->opts, name, value, &prev) != 0) return -1;
+  return prev < 0 ? option_def(idx).hi + 1 : prev;
+}
+int gpet_batch_get_option(const gpet_batch* b, const char* name, int* value) {
+  return (b && option_get_in(&b->opts, name, value) == 0) ? GPET_OK : GPET_ERR_BAD_ARG;
+}
+
 int gpet_batch_set_rng(gpet_batch* b, int mode) {
+  GPET_BATCH_SCOPE(b);
   if (!b || (mode != 0 && mode != 1)) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -735,6 +757,7 @@ int gpet_batch_set_rng(gpet_batch* b, int mode) {
 }
 
 int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -750,6 +773,7 @@ int gpet_batch_set_sample_dtype(gpet_batch* b, int f32) {
 }
 
 int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
+  GPET_BATCH_SCOPE(b);
   if (!b || e < 0 || e >= b->B) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
@@ -791,11 +815,13 @@ static int batch_reset(gpet_batch* b, bool next_frame) {
 }
 
 int gpet_batch_reset(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   return batch_reset(b, false);
 }
 
 int gpet_batch_set_images(gpet_batch* b, const float* const* grad, unsigned int flags) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !grad) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));

@@ -23,11 +23,17 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r = [] {
     Rccl q;
+    // GPET_RCCL_LIB: the one library to bind instead of the default names (a deployment's own build of RCCL; the tests point
+    // it at a file that does not exist to see GPET_ERR_UNSUPPORTED come back)
+    const char* forced = getenv("GPET_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
-      if ((q.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (forced && *forced) q.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    else
+      for (const char* n : names)
+        if ((q.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
     if (!q.lib) {
-      q.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : "?");
+      const char* m = dlerror();  // (ONE call: dlerror clears the message it returns)
+      q.why = std::string("RCCL not found (dlopen ") + (forced && *forced ? forced : "librccl.so.1") + "): " + (m ? m : "?");
       return q;
     }
 #define GPET_RCCL_SYM(field, name)                                      \
@@ -48,6 +54,7 @@ Rccl& rccl() {
 
 struct gpet_comm {
   gpet_ctx* ctx = nullptr;
+  int device = 0;           // (its own copy: gpet_comm_destroy must not need the context, which the caller may have destroyed first)
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   char* scratch = nullptr;  // device staging of the gather (send block | world receive blocks)
@@ -87,6 +94,7 @@ int gpet_comm_create(gpet_ctx* ctx, const void* id128, int world, int rank, gpet
   gpet_comm* c = new (std::nothrow) gpet_comm();
   if (!c) return GPET_ERR_HIP;
   c->ctx = ctx;
+  c->device = ctx->device;
   c->world = world;
   c->rank = rank;
   if (world > 1 || option("comm_force_rccl")) {  // (a single rank needs no communicator: its collectives are copies)
@@ -117,7 +125,7 @@ int gpet_comm_create(gpet_ctx* ctx, const void* id128, int world, int rank, gpet
 
 void gpet_comm_destroy(gpet_comm* c) {
   if (!c) return;
-  (void)hipSetDevice(c->ctx->device);
+  (void)hipSetDevice(c->device);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->comm) (void)rccl().CommDestroy(c->comm);
   delete c;

@@ -7,7 +7,8 @@
 // mode (gpet_set_option("blocking_sync", 1); default: on when WORLD_SIZE > 1, i.e. under torch.distributed.run) a wait
 // is an event created with hipEventBlockingSync: the thread sleeps until the GPU signals.
 static int opt_blocking_sync() {
-  static int& v = option("blocking_sync");
+  static const int i_ = option_index("blocking_sync");
+  int& v = option_at(i_);
   if (v >= 0) return v;
   static const int by_world = [] {  // (WORLD_SIZE is torch.distributed's variable, not a switch of this library)
     const char* w = getenv("WORLD_SIZE");
@@ -79,12 +80,14 @@ int fin_lattice(const double* x, int n, double* hinv) {
 // lock-step rounds over all running problems: -1 = for problem sets resident at once (<= 1024), 0 = never, 1 = always
 // (where the training sets allow it)
 int& opt_fit_persistent() {
-  static int& v = option("fit_persistent");
+  static const int i_ = option_index("fit_persistent");
+  int& v = option_at(i_);
   return v;
 }
 
 static int& opt_rng_chunked() {
-  static int& v = option("rng_chunked");  // -1: by launch shape
+  static const int i_ = option_index("rng_chunked");
+  int& v = option_at(i_);  // -1: by launch shape
   return v;
 }
 

@@ -7,6 +7,7 @@ static int eval_objective(gpet_batch* b, hipStream_t st, int P, int n_max, const
 extern "C" {
 
 int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double* ys, const double* w, int n) {
+  GPET_BATCH_SCOPE(b);
   if (!b || e < 0 || e >= b->B || !xs || !ys || !w || n < 1) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   EdgeDev& E = b->h_edges[e];
@@ -27,6 +28,7 @@ int gpet_final_set_training(gpet_batch* b, int e, const double* xs, const double
 }
 
 int gpet_batch_read_scalars_all(gpet_batch* b, gpet_scalars* dst) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !dst) return GPET_ERR_BAD_ARG;
   HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
   int rc = fetch_all_scalars(b);
@@ -36,6 +38,7 @@ int gpet_batch_read_scalars_all(gpet_batch* b, gpet_scalars* dst) {
 }
 
 int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int stride_obs) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !dst || !counts || stride_obs < 1) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -56,6 +59,7 @@ int gpet_batch_read_obs_all(gpet_batch* b, int64_t* dst, int32_t* counts, int st
 
 int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* ys, const double* w, const int32_t* n,
                                 int stride) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !xs || !ys || !w || !n || stride < 1) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -94,6 +98,7 @@ int gpet_final_set_training_all(gpet_batch* b, const double* xs, const double* y
 }
 
 int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, double* std_out, int stride) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !par || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -116,6 +121,7 @@ int gpet_final_predict_all(gpet_batch* b, const double* par, double* mean_out, d
 }
 
 int gpet_lml_batch(gpet_batch* b, int P, const int32_t* edge_of, const double* theta, double* f_out, double* g_out) {
+  GPET_BATCH_SCOPE(b);
   if (!b || P < 1 || !edge_of || !theta || !f_out || !g_out) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -342,6 +348,7 @@ static int lb_rounds(gpet_batch* b, int P, int n_max, int lag_cap, const LbCfg& 
 
 int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, double* std_out, double* theta_out,
                        int stride, int32_t* rounds_out) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !seeds || !mean_out || !std_out || stride < b->bd.Lg) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -390,6 +397,7 @@ int gpet_final_fit_all(gpet_batch* b, const uint32_t* seeds, double* mean_out, d
 
 int gpet_final_optimize(gpet_batch* b, int n_starts, const double* starts, const double* bounds, double* theta_out,
                         int32_t* rounds_out) {
+  GPET_BATCH_SCOPE(b);
   if (!b || n_starts < 1 || n_starts > 64 || !starts || !bounds || !theta_out) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -423,6 +431,7 @@ int gpet_final_optimize(gpet_batch* b, int n_starts, const double* starts, const
 }
 
 int gpet_lml_stats(gpet_batch* b, int reset, double* kernel_ms, int64_t* evaluations, int32_t* launches) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   if (kernel_ms) *kernel_ms = b->lml_ms;
   if (evaluations) *evaluations = b->lml_evals;

@@ -105,7 +105,10 @@ struct gpet_batch {
   // -1 = no lattice (caller-supplied x off any grid) -> the vector objective kernels; see fin_lattice()
   std::vector<int> fin_lag;
   bool have_fit = false, have_factor = false, have_normals = false, have_samples = false, have_scores = false;
+  OptionSet opts;  // the batch's own copy of the option table (gpet_options.h): taken at creation, gpet_batch_set_option changes it
 };
+// first statement of every entry point that works on a batch: its option table for the calling thread
+#define GPET_BATCH_SCOPE(b) OptionScope gpet_opt_scope_((b) ? &(b)->opts : nullptr)
 
 // ---- helpers defined in gpet_api_ctx.hip ----------------------------------------------------------------------------------
 hipError_t gpet_wait(hipStream_t st);  // host wait on a stream: spinning or sleeping (option blocking_sync)

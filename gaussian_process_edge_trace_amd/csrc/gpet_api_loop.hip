@@ -4,6 +4,7 @@
 extern "C" {
 
 int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters, int* n_active) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !base_seeds || !n_active || max_iters < 0) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));

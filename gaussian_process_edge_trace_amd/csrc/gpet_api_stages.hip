@@ -6,6 +6,7 @@ extern "C" {
 
 // ---- stages ---------------------------------------------------------------------------
 int gpet_gp_fit_predict(gpet_batch* b, int want_cov) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -17,6 +18,7 @@ int gpet_gp_fit_predict(gpet_batch* b, int want_cov) {
 }
 
 int gpet_gp_factor(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_fit) return fail(c, GPET_ERR_STATE, "gpet_gp_factor before gpet_gp_fit_predict");
@@ -29,6 +31,7 @@ int gpet_gp_factor(gpet_batch* b) {
 }
 
 int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !seeds) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -45,6 +48,7 @@ int gpet_gp_normals(gpet_batch* b, const uint32_t* seeds) {
 }
 
 int gpet_gp_sample(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_fit || !b->have_factor || !b->have_normals)
@@ -58,6 +62,7 @@ int gpet_gp_sample(gpet_batch* b) {
 }
 
 int gpet_score_curves(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_samples) return fail(c, GPET_ERR_STATE, "gpet_score_curves before samples exist");
@@ -70,6 +75,7 @@ int gpet_score_curves(gpet_batch* b) {
 }
 
 int gpet_curve_kde(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_scores) return fail(c, GPET_ERR_STATE, "gpet_curve_kde before gpet_score_curves");
@@ -81,6 +87,7 @@ int gpet_curve_kde(gpet_batch* b) {
 }
 
 int gpet_final_cov(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -93,6 +100,7 @@ int gpet_final_cov(gpet_batch* b) {
 }
 
 int gpet_select_pixels(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   if (!b->have_scores) return fail(c, GPET_ERR_STATE, "gpet_select_pixels before gpet_score_curves");
@@ -106,6 +114,7 @@ int gpet_select_pixels(gpet_batch* b) {
 }
 
 int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
+  GPET_BATCH_SCOPE(b);
   if (!b || !ms_per_rep || reps < 1) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -154,6 +163,7 @@ int gpet_profile_stage(gpet_batch* b, int stage, int reps, float* ms_per_rep) {
 }
 
 int gpet_select_pixels_only(gpet_batch* b) {
+  GPET_BATCH_SCOPE(b);
   if (!b) return GPET_ERR_BAD_ARG;
   gpet_ctx* c = b->ctx;
   HIPCHK(c, hipSetDevice(c->device));

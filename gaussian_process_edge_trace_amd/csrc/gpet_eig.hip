@@ -574,7 +574,8 @@ __global__ void __launch_bounds__(64) k_pcx_fin(EdgeDev* edges, int steps, int n
 // (k_ojw_chol_*: 64-wide panels), one copy.  Only for rows of full rank (Matern); a non-positive pivot falls back to the
 // pivoted Cholesky, whose launches are no-ops otherwise.  T = A Sigma lives in Gt, M' and L' in G, X in Gt and then G.
 int& gpet_opt_oj_warm() {
-  static int& v = option("oj_warm");
+  static const int i_ = option_index("oj_warm");
+  int& v = option_at(i_);
   return v;
 }
 __device__ __forceinline__ const double* ojw_source(const EdgeDev& E, int warm) {
@@ -1738,17 +1739,20 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
 }
 
 int& gpet_opt_oj_tol_exp() {
-  static int& v = option("oj_tol_exp");
+  static const int i_ = option_index("oj_tol_exp");
+  int& v = option_at(i_);
   return v;
 }
 
 int& gpet_opt_oj_persist() {
-  static int& v = option("oj_persist");
+  static const int i_ = option_index("oj_persist");
+  int& v = option_at(i_);
   return v;
 }
 
 int& gpet_opt_oj_max_sweeps() {
-  static int& v = option("oj_max_sweeps");
+  static const int i_ = option_index("oj_max_sweeps");
+  int& v = option_at(i_);
   return v;
 }
 

@@ -11,9 +11,30 @@ struct OptionDef {
   const char* doc;
 };
 
-// the value of option `name` (a reference into the table: reads see later gpet_set_option calls).  An unknown name is a
-// programming error and aborts.
+// A batch object carries its OWN copy of the table, taken when it is created (gpet_batch_create) and changed only through
+// gpet_batch_set_option: every entry point that works on a batch installs that copy for the calling thread (OptionScope), so
+// what a batch does never depends on what another thread sets while it runs.  Without a scope (context-level calls, batch
+// creation before the copy exists) reads go to the process-wide table.
+constexpr int kMaxOptions = 64;
+struct OptionSet {
+  int v[kMaxOptions];
+};
+void option_snapshot(OptionSet* out);  // the process-wide table as it is now
+int option_set_in(OptionSet* s, const char* name, int value, int* previous);
+int option_get_in(const OptionSet* s, const char* name, int* value);
+struct OptionScope {  // installs `s` (may be null: no change) as the calling thread's table for the scope's lifetime
+  explicit OptionScope(OptionSet* s);
+  ~OptionScope();
+  OptionScope(const OptionScope&) = delete;
+  OptionScope& operator=(const OptionScope&) = delete;
+  OptionSet* prev;
+  bool active;
+};
+// the value of option `name` in the calling thread's table (the batch's copy inside an OptionScope, else the process-wide
+// table: reads see later gpet_set_option calls).  An unknown name is a programming error and aborts.
 int& option(const char* name);
+int option_index(const char* name);  // (aborts on an unknown name) -- for call sites that look an option up on every launch
+int& option_at(int index);
 // gpet_set_option / gpet_get_option: 0 on success, -1 for an unknown name
 int option_set(const char* name, int value, int* previous);
 int option_get(const char* name, int* value);

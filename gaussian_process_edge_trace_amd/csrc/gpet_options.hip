@@ -44,8 +44,11 @@ const OptionDef kDefs[] = {
     {"shared_basis", 1, 0, 1, "edges of one geometry share one prior eigenbasis; 0: every edge its own copy"},
 };
 constexpr int kCount = (int)(sizeof(kDefs) / sizeof(kDefs[0]));
-int g_val[kCount];
+static_assert(kCount <= kMaxOptions, "OptionSet holds every option");
+int g_val[kMaxOptions];
 std::once_flag g_once;
+std::mutex g_mu;  // writers of the process-wide table and the snapshots of it
+thread_local OptionSet* tl_set = nullptr;
 
 int clampv(const OptionDef& d, int v) { return v < d.lo ? d.lo : (v > d.hi ? d.hi : v); }
 
@@ -70,20 +73,27 @@ int find(const char* name) {
 
 }  // namespace
 
-int& option(const char* name) {
-  std::call_once(g_once, init_all);
+int option_index(const char* name) {
   const int i = find(name);
   if (i < 0) {
     fprintf(stderr, "libgpet_hip: unknown option '%s'\n", name ? name : "(null)");
     abort();
   }
-  return g_val[i];
+  return i;
 }
+
+int& option_at(int i) {
+  std::call_once(g_once, init_all);
+  return tl_set ? tl_set->v[i] : g_val[i];
+}
+
+int& option(const char* name) { return option_at(option_index(name)); }
 
 int option_set(const char* name, int value, int* previous) {
   std::call_once(g_once, init_all);
   const int i = find(name);
   if (i < 0) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
   if (previous) *previous = g_val[i];
   g_val[i] = clampv(kDefs[i], value);
   return 0;
@@ -93,8 +103,37 @@ int option_get(const char* name, int* value) {
   std::call_once(g_once, init_all);
   const int i = find(name);
   if (i < 0) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
   if (value) *value = g_val[i];
   return 0;
+}
+
+void option_snapshot(OptionSet* out) {
+  std::call_once(g_once, init_all);
+  std::lock_guard<std::mutex> lk(g_mu);
+  memcpy(out->v, g_val, sizeof out->v);
+}
+
+int option_set_in(OptionSet* s, const char* name, int value, int* previous) {
+  const int i = find(name);
+  if (i < 0 || !s) return -1;
+  if (previous) *previous = s->v[i];
+  s->v[i] = clampv(kDefs[i], value);
+  return 0;
+}
+
+int option_get_in(const OptionSet* s, const char* name, int* value) {
+  const int i = find(name);
+  if (i < 0 || !s) return -1;
+  if (value) *value = s->v[i];
+  return 0;
+}
+
+OptionScope::OptionScope(OptionSet* s) : prev(tl_set), active(s != nullptr) {
+  if (active) tl_set = s;
+}
+OptionScope::~OptionScope() {
+  if (active) tl_set = prev;
 }
 
 int option_count() { return kCount; }

@@ -325,7 +325,8 @@ bool normals4_applies(const EdgeDev* h_edges, int B) {
 }
 
 int& gpet_opt_rng4() {
-  static int& v = option("rng4");
+  static const int i_ = option_index("rng4");
+  int& v = option_at(i_);
   return v;
 }
 

@@ -362,11 +362,20 @@ class GP_Edge_Tracing_Batch(object):
         B = len(inits)
         assert len(seeds) == B and (share or (len(ptrs) if on_dev else len(imgs)) == B)
         obs = [np.array([])] * B if obs is None else list(obs)
-        # (edges given the SAME init / observation objects and image shape resolve to the same parameters but for the seed, which
-        #  nothing derived depends on: resolved once per distinct triple -- a batch of 1 024 equal edges spent 8 ms here)
-        self._ps, abi, memo = [], [], {}
+        inits = list(inits)  # (an ndarray of shape (B, n, 2) makes a fresh view per access: materialise the items once)
+        # (edges with the same init points, observations and image shape resolve to the same parameters but for the seed, which
+        #  nothing derived depends on: resolved once per distinct triple -- a batch of 1 024 equal edges spent 8 ms here.  The key
+        #  is the CONTENT: object identities can be reused by temporaries)
+        def content(a):
+            a = np.asarray(a)
+            return (a.shape, a.dtype.str, a.tobytes())
+        self._ps, abi, memo, by_id = [], [], {}, {}
         for e in range(B):
-            key = (id(inits[e]), tuple(shapes[e]), id(obs[e]))
+            ik = (id(inits[e]), id(obs[e]))  # (the items are alive in `inits` / `obs`, so these identities are stable here)
+            ck = by_id.get(ik)
+            if ck is None:
+                ck = by_id[ik] = (content(inits[e]), tuple(shapes[e]), content(obs[e]))
+            key = ck
             hit = memo.get(key)
             if hit is None:
                 pe = resolve_params(inits[e], shapes[e], kernel_options, noise_y, obs[e], N_samples, score_thresh,
@@ -374,6 +383,8 @@ class GP_Edge_Tracing_Batch(object):
                 hit = memo[key] = (pe, to_abi_params(pe, factor_cap=factor_cap, z_cols=z_cols))
             else:
                 pe = dict(hit[0], seed=int(seeds[e]))
+                pe["init"] = hit[0]["init"].copy()
+                pe["obs"] = np.array(hit[0]["obs"], copy=True)
             self._ps.append(pe)
             abi.append(hit[1])
         self._ctx = _ctx if _ctx is not None else _lib.Context(device, stream)

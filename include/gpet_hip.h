@@ -133,6 +133,11 @@ int gpet_abi_version(void);
  * enumerate the table (any out pointer may be NULL; strings are static). */
 int gpet_set_option(const char* name, int value);
 int gpet_get_option(const char* name, int* value);
+/* A batch keeps its OWN copy of the table, taken when it is created: what a batch does is fixed by the options in force at
+ * gpet_batch_create and by these two calls, never by a gpet_set_option another thread makes while it runs (every batch entry
+ * point reads the batch's copy).  Same return conventions as gpet_set_option / gpet_get_option. */
+int gpet_batch_set_option(gpet_batch* b, const char* name, int value);
+int gpet_batch_get_option(const gpet_batch* b, const char* name, int* value);
 int gpet_option_count(void);
 int gpet_option_info(int index, const char** name, int* value, int* def, int* lo, int* hi, const char** doc);
 /* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL

@@ -69,6 +69,20 @@ def test_no_gpu_fails_loudly_without_fallback():
         pkg.gpet_utils.comp_grad_img(np.zeros((8, 8)), np.ones((3, 3)))
 
 
+def test_missing_rccl_is_reported_not_crashed():
+    """A host without RCCL: gpet_comm_unique_id returns GPET_ERR_UNSUPPORTED (round 5 called dlerror() twice and handed
+    std::string a null pointer).  In a child process: the binding is cached per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from gaussian_process_edge_trace_amd import _lib; "
+            "lib = _lib.load(); buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES); "
+            "print('rc', lib.gpet_comm_unique_id(buf))" % ROOT)
+    env = dict(os.environ, GPET_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "rc 6" in out.stdout, out.stdout
+
+
 def test_product_never_imports_the_oracle():
     pkg_dir = os.path.join(ROOT, "gaussian_process_edge_trace_amd")
     for dirpath, _, files in os.walk(pkg_dir):

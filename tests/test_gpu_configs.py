@@ -530,3 +530,48 @@ def test_any_rank_factor_warm_start_falls_back_to_the_pivoted_cholesky(amd, ctx)
     assert b[2] == 0 and a[1] == b[1]
     assert np.array_equal(a[0], b[0])
     assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+
+
+@pytest.mark.parametrize("pchol_multi", [0, 1, 2])
+def test_pivoted_cholesky_over_the_gpu_in_a_batch_of_mixed_widths(amd, ctx, pchol_multi):
+    """The multi-workgroup pivoted Cholesky (k_pcb_block / k_pcx_step) is picked per BATCH from its widest edge and then runs on
+    every edge, writing each edge's transposed copy Gt: a narrower edge beside a > 1 024-column one must own a full Gt (round 5
+    sized it from the edge's own width: out-of-bounds writes over the narrow edge's neighbours).  Generic factor path
+    (struct_path = 0, stage API): every edge's factor reproduces its covariance and equals its single-edge run."""
+    L = amd._lib
+    N, M = 2048, 192
+    grad = np.random.default_rng(0).random((M, N)).astype(np.float32)  # (only the GP stages run: any image does)
+    yc = lambda x: int(round(96 + 60 * np.sin(x / 200.0)))
+    spans = [(0, N - 1), (100, 700)]
+    inits = [np.array([[a, yc(a)], [b, yc(b)]]) for a, b in spans]
+    rng = np.random.default_rng(5)
+    obs = []
+    for (a, b), k in zip(spans, (420, 70)):
+        cols = np.sort(rng.choice(np.arange(a + 1, b), size=k, replace=False))
+        obs.append(np.stack([cols, [yc(c) for c in cols]], axis=1).astype(np.int64))
+    kw = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 40, 'length_scale': 120}, noise_y=1, N_samples=128,
+              score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, fix_endpoints=True)
+    old = {"struct_path": L.set_option("struct_path", 0), "pchol_multi": L.set_option("pchol_multi", pchol_multi)}
+    try:
+        bt = amd.GP_Edge_Tracing_Batch(inits, grad, [1, 2], **kw, obs=obs, _ctx=ctx)
+        b = bt._batch
+        assert b.info()["structured"] == 0
+        for e in range(2):
+            b.set_obs(e, obs[e])
+        b.fit_predict(want_cov=True)
+        b.factor()
+        for e in range(2):
+            one = amd.GP_Edge_Tracing(inits[e], grad, seed=1 + e, **kw, obs=obs[e], _ctx=ctx)._batch
+            one.set_obs(0, obs[e])
+            one.fit_predict(want_cov=True)
+            one.factor()
+            A, cov = b.read(L.BUF_FACTOR, e), b.read(L.BUF_COV, e)
+            assert b.scalars(e).status == 0 and b.scalars(e).rank == one.scalars().rank
+            np.testing.assert_allclose(A.T @ A, cov, rtol=0, atol=1e-9 * np.abs(cov).max(), err_msg="edge %d" % e)
+            np.testing.assert_array_equal(cov, one.read(L.BUF_COV))
+            np.testing.assert_allclose(A, one.read(L.BUF_FACTOR), rtol=0, atol=1e-9 * np.abs(A).max(), err_msg="edge %d vs single" % e)
+            one.close()
+        b.close()
+    finally:
+        for k, v in old.items():
+            L.set_option(k, v)
