@@ -103,16 +103,26 @@ static int upload_images(gpet_batch* b, const float* const* grad, unsigned int f
   gpet_ctx* c = b->ctx;
   const size_t px = (size_t)b->bd.M * b->bd.N;
   const int n_img = b->share_image ? 1 : b->B;
-  const hipMemcpyKind up = (flags & GPET_GRAD_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  for (int g = 0; g < n_img; ++g) {
+  const bool on_dev = (flags & GPET_GRAD_ON_DEVICE) != 0;
+  for (int g = 0; g < n_img; ++g)
     if (!grad[g]) return fail(c, GPET_ERR_BAD_ARG, "gradient image %d is a null pointer", g);
-    const unsigned int mm0[2] = {0xFFFFFFFFu, 0u};
-    HIPCHK(c, hipMemcpyAsync(b->d_raw, grad[g], px * sizeof(float), up, c->stream));
-    HIPCHK(c, hipMemcpyAsync(b->d_minmax, mm0, sizeof mm0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_minmax(c->stream, b->d_raw, px, b->d_minmax));
-    HIPCHK(c, launch_normalise(c->stream, b->d_raw, px, b->d_minmax, (float*)b->h_edges[g].grad));
-    HIPCHK(c, gpet_wait(c->stream));  // (the host copy of mm0 / a pageable source must stay valid)
+  // every image its own (min, max) slot, all of them reset by ONE copy; the images then follow each other on the stream --
+  // staging copy -> min / max -> normalise -- with a single wait at the end (round 5 waited after every image: 0.8 ms per
+  // image of a 256-image set_frame, most of it the waits).  A device image (GPET_GRAD_ON_DEVICE) is read where it lies.
+  b->h_mm0.assign((size_t)2 * n_img, 0u);
+  for (int g = 0; g < n_img; ++g) b->h_mm0[2 * (size_t)g] = 0xFFFFFFFFu;
+  HIPCHK(c, hipMemcpyAsync(b->d_minmax, b->h_mm0.data(), sizeof(unsigned int) * 2 * n_img, hipMemcpyHostToDevice, c->stream));
+  for (int g = 0; g < n_img; ++g) {
+    unsigned int* mm = b->d_minmax + 2 * (size_t)g;
+    const float* src = grad[g];
+    if (!on_dev) {
+      HIPCHK(c, hipMemcpyAsync(b->d_raw, grad[g], px * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      src = b->d_raw;
+    }
+    HIPCHK(c, launch_minmax(c->stream, src, px, mm));
+    HIPCHK(c, launch_normalise(c->stream, src, px, mm, (float*)b->h_edges[g].grad));
   }
+  HIPCHK(c, gpet_wait(c->stream));  // (pageable sources and h_mm0 must stay valid until the copies have run)
   return GPET_OK;
 }
 
@@ -275,7 +285,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   }
   HIPCHK(c, hipMalloc(&b->d_edges, sizeof(EdgeDev) * B));
   HIPCHK(c, hipMalloc(&b->d_seeds, sizeof(unsigned int) * B));
-  HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2));
+  HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2 * (size_t)B));
   {
     // (the stream the normals run ahead of the loop on: default priority -- lowest / highest were measured, +-0)
     HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
@@ -291,6 +301,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_gemm[i], hipEventDisableTiming));
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_pix[i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&b->ev_head, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
   HIPCHK(c, hipMalloc(&b->d_raw, px * sizeof(float)));
   {
@@ -435,6 +446,7 @@ void gpet_batch_destroy(gpet_batch* b) {
   for (int i = 0; i < 16; ++i)
     if (b->ev_pix[i]) (void)hipEventDestroy(b->ev_pix[i]);
   if (b->ev_main) (void)hipEventDestroy(b->ev_main);
+  if (b->ev_head) (void)hipEventDestroy(b->ev_head);
   if (b->d_edge_of) (void)hipFree(b->d_edge_of);
   if (b->d_theta) (void)hipFree(b->d_theta);
   if (b->d_f) (void)hipFree(b->d_f);

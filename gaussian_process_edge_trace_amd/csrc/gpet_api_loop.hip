@@ -102,11 +102,34 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         int n = ring - (j - cur);
         if (n > look) n = look;
         if (cur - 1 >= first) HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_gemm[(cur - 1) % 16], 0));
-        {
-          int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, j, n, loop_z_store(b));
+        // The HEAD of a trace of 2..32 edges (round 6).  A stream is sequential -- one workgroup walks 1.27 M MT19937 words in
+        // ~3 ms -- and the first iteration of a trace has nothing to hide that behind: the loop of a 32-edge batch stood still
+        // for ~2.5 ms before its first sample GEMM.  So the first `head` iterations are generated CHUNKED (jump-ahead: a launch
+        // of <= 32 streams is cut into chunks on many workgroups, ~0.7 ms), one launch per iteration on the side stream, while
+        // the sequential launch of the iterations after them runs beside them on the (idle until the converged fits) fit stream.
+        int head = 0;
+        if (j == 0 && cur == 0 && B_l >= 2 && B_l <= 32 && b->rng_mode == 0) {
+          head = option("rng_head");
+          if (head < 0) head = 4;
+          if (head > n - 1) head = n - 1;
+          if (head < 0) head = 0;
+        }
+        for (int q = 0; q < head; ++q) {
+          int rcn = normals_auto(b, b->side, edges_l, B_l, seeds_l, 1, j + q, 1, loop_z_store(b));
+          if (rcn) return rcn;
+          HIPCHK(c, hipEventRecord(b->ev_norm[(j + q) % 16], b->side));
+        }
+        hipStream_t rest = head > 0 ? b->fit : b->side;
+        if (head > 0) HIPCHK(c, hipStreamWaitEvent(b->fit, b->ev_main, 0));  // (the seeds and the edge table are on the device)
+        if (n > head) {
+          int rcn = normals_auto(b, rest, edges_l, B_l, seeds_l, 1, j + head, n - head, loop_z_store(b));
           if (rcn) return rcn;
         }
-        for (int q = j; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], b->side));
+        for (int q = j + head; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], rest));
+        if (head > 0) {  // later refills run on the side stream: after everything the head put on the fit stream
+          HIPCHK(c, hipEventRecord(b->ev_head, b->fit));
+          HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_head, 0));
+        }
         b->norm_issued = j + n;
       }
       const int look_now = look;  // (after the GEMM instead of beside the eigen-solver was measured: +-0)

@@ -392,7 +392,7 @@ class GP_Edge_Tracing_Batch(object):
             self._batch = _lib.Batch(self._ctx, None, abi, [p["init"] for p in self._ps], share_image=share,
                                      device_ptrs=ptrs, shape=grad_shape)
         else:
-            g32 = [np.asarray(g).astype(np.float32) for g in imgs]
+            g32 = [np.ascontiguousarray(g, dtype=np.float32) for g in imgs]
             self._batch = _lib.Batch(self._ctx, g32, abi, [p["init"] for p in self._ps], share_image=share)
         if sample_dtype is not None:
             self._batch.set_sample_dtype(sample_dtype)
@@ -428,7 +428,7 @@ class GP_Edge_Tracing_Batch(object):
                                    else [grad_device_ptrs], next_frame=next_frame)
         else:
             imgs = list(grad_imgs) if isinstance(grad_imgs, (list, tuple)) else [grad_imgs]
-            self._batch.set_images([np.asarray(g).astype(np.float32) for g in imgs], next_frame=next_frame)
+            self._batch.set_images([np.ascontiguousarray(g, dtype=np.float32) for g in imgs], next_frame=next_frame)  # (no copy of f32 input)
         obs = [np.array([])] * self.B if obs is None else list(obs)
         for e, p in enumerate(self._ps):
             p["obs"] = np.asarray(obs[e]).reshape(-1, 2).astype(np.int64)

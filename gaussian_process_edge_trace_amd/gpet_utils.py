@@ -2,8 +2,11 @@
 
 ``comp_grad_img`` / ``normalise`` run on the GPU through libgpet_hip.so (a1); ``kernel_builder``
 is host-side setup (a 11x5 table).  ``construct_test_img`` is this package's own generator of the
-reference's synthetic test image recipe (gpet_utils.py:163-253) -- noise from numpy's Generator
-because scikit-image is not a dependency here.  Metrics restate gpet_utils.py:256-313.
+reference's synthetic test image recipe (gpet_utils.py:163-253).  Called like the reference (no ``seed``) it returns the
+reference's own image bit for bit: scikit-image 0.18's ``random_noise(..., seed=1)`` (gpet_utils.py:251) is
+``np.random.seed(1); image + np.random.normal(0, sqrt(var), shape)`` clipped to [0, 1] -- numpy's frozen legacy stream, which
+needs no scikit-image (pinned by tests/golden/readme_image.npz, made by the unmodified reference under skimage 0.18.3).  With an
+explicit ``seed`` the noise comes from numpy's Generator: independent images for batches.  Metrics restate gpet_utils.py:256-313.
 """
 from __future__ import annotations
 
@@ -58,8 +61,10 @@ def comp_grad_img(img, kernel, norm=True, astyp=np.float32, ctx=None):
     return out.astype(astyp)
 
 
-def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity, gaps=False, seed=1):
-    """Synthetic step-edge image + ground-truth edge (yx), recipe of gpet_utils.py:163-253."""
+def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity, gaps=False, seed=None):
+    """Synthetic step-edge image + ground-truth edge (yx), recipe of gpet_utils.py:163-253.  ``seed=None`` (the reference's
+    signature has no seed): the reference's own noise, ``random_noise(..., seed=1)`` of scikit-image 0.18 = numpy's legacy
+    ``RandomState(1).normal``; an integer: numpy ``Generator(seed)`` noise (this package's extension)."""
     M, N = size
     img = np.zeros((M, N))
     x = np.linspace(-np.pi, np.pi, N)
@@ -88,8 +93,11 @@ def construct_test_img(size, amplitude, curvature, noise_level, ltype, intensity
         img[:, N // 2:(N // 2 + 10)] = 0
         img[:, N - 100:N - 90] = 0
         img[:, N // 4:(N // 4 + 20)] = 0
-    rng = np.random.default_rng(seed)
-    img = np.clip(img + rng.normal(0.0, math.sqrt(noise_level), img.shape), 0.0, 1.0)
+    if seed is None:  # gpet_utils.py:251 under scikit-image 0.18: np.random.seed(1); np.random.normal(mean, var ** 0.5, shape)
+        noise = np.random.RandomState(1).normal(0.0, noise_level ** 0.5, img.shape)
+    else:
+        noise = np.random.default_rng(seed).normal(0.0, math.sqrt(noise_level), img.shape)
+    img = np.clip(img + noise, 0.0, 1.0)
     edge = np.stack([wave, cols], axis=1)
     if wave2 is not None:  # both edges, one after the other (2N rows), as the reference returns them
         edge = np.concatenate([edge, np.stack([wave2, cols], axis=1)], axis=0)

@@ -43,6 +43,26 @@ def _fit_hook(self, X, y):
 
 sklearn_gpr.GaussianProcessRegressor.fit = _fit_hook
 
+# The signs of the reference's SVD rows.  numpy's legacy multivariate_normal (sklearn_gpr.py:464) looks numpy.linalg.svd up when
+# it is called, so a recorder in its place sees every factorisation of a trace: per call the bit "sum_j row_k[j] / (j + 1) >= 0"
+# of every row sqrt(s_k) v_k -- the library fixes that sum non-negative (include/gpet_hip.h, gpet_gp_factor), so these bits are
+# exactly what turns the device's rows into LAPACK's: a device test flips the N(0, 1) column k where the bit is 0 and must then
+# reproduce the reference's own samples, observation sets and trace.
+_svd_bits = None
+_orig_svd = np.linalg.svd
+
+
+def _svd_hook(a, *args, **kw):
+    out = _orig_svd(a, *args, **kw)
+    if _svd_bits is not None and getattr(a, "ndim", 0) == 2 and a.shape[0] == a.shape[1] and not args and not kw:
+        _, sv, vt = out
+        rows = np.sqrt(sv)[:, None] * vt
+        _svd_bits.append((rows @ (1.0 / np.arange(1, rows.shape[1] + 1)) >= 0))
+    return out
+
+
+np.linalg.svd = _svd_hook
+
 
 def make_image(N, seed):
     img, edge = orc.synth_sinusoid_image(N, seed)
@@ -51,7 +71,12 @@ def make_image(N, seed):
     return img, edge, kern, grad
 
 
-def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, keep_factor_rows=None):
+def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, keep_factor_rows=None, light=False, pixels=True):
+    """``light`` (images above 500 px): nothing of image size is stored -- the image is the oracle generator's
+    (``in_img_seed``; the device's comp_grad_img of it equals the reference's bit for bit, tests/test_gpu_stages.py) and the
+    training-set matrices K / L (n^2) are left out; ``pixels=False`` skips the pixel selection (more observations than
+    algo_thresh: the reference's loop would not run it)."""
+    global _svd_bits
     img, edge, kern, grad = make_image(N, img_seed)
     init = edge[[0, -1], :][:, [1, 0]]
     if ctor_kw.pop("_swap_init", False):
@@ -66,9 +91,17 @@ def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, k
                ref_grad_kde=tr.grad_kde.astype(np.float32), kde_standin=1)
     if N <= 128:
         out["in_img"] = img
+    if light:
+        for k in ("ref_grad", "ref_grad64", "ref_grad_kde"):
+            out.pop(k)
+        out["ref_grad_probe"] = grad[::97, ::89].copy()      # (a few hundred pixels of each: the regenerated images must hit them)
+        out["ref_grad_kde_probe"] = tr.grad_kde[::97, ::89].astype(np.float32)
     # ---- a2..a6: one not-converged GP iteration
     _captured.clear()
+    _svd_bits = []
     Y = tr.fit_predict_GP(obs, converged=False, seed=gp_seed)
+    out["ref_svd_sign_bits"] = np.packbits(_svd_bits[-1])  # (of the factorisation sample_y itself made)
+    _svd_bits = None
     gp = _captured[-1]
     xg = tr.x_grid[:, None].astype(np.float64)
     mean, cov = gp.predict(xg, return_cov=True)
@@ -78,7 +111,11 @@ def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, k
     Z = np.random.RandomState(gp_seed).standard_normal((tr.N_samples, tr.edge_length))
     K = gp._K_train_dbg.copy()
     K[np.diag_indices_from(K)] += gp.alpha
-    out.update(ref_X_train=gp.X_train_[:, 0], ref_y_train=gp.y_train_, ref_K=K, ref_L=gp.L_,
+    if light:
+        out.update(ref_L_diag=np.diag(gp.L_).copy(), ref_L_lastrow=gp.L_[-1].copy())
+    else:
+        out.update(ref_K=K, ref_L=gp.L_)
+    out.update(ref_X_train=gp.X_train_[:, 0], ref_y_train=gp.y_train_,
                ref_alpha=gp.alpha_, ref_y_train_mean=gp._y_train_mean, ref_y_train_std=gp._y_train_std,
                ref_amp=tr.constant_kernel.constant_value, ref_mean=mean, ref_std=std, ref_svals=s,
                ref_cov_diag=np.diag(cov).copy(), ref_cov_row0=cov[0].copy(), ref_cov_rowmid=cov[cov.shape[0] // 2].copy())
@@ -95,20 +132,24 @@ def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, k
     costs = np.asarray([tr.cost_funct(np.stack((tr.x_grid, Y[:, i]), axis=-1)) for i in range(Y.shape[1])])
     out.update(ref_costs=costs, ref_best_idxs=np.argsort(costs)[:tr.N_keep], ref_best_costs=bcost,
                ref_best_curve0=bc[:, 0, :])
-    if keep_samples is not None:
+    if keep_samples is not None and not light:
         # the fixture keeps only a few of the samples: store the kept curves themselves (y only; x = the grid), so that
         # the curve-KDE stage can be fed through the get_best_pixels(curves, costs, pre_fobs) seam
         assert np.array_equal(bc[:, :, 0], np.repeat(tr.x_grid[:, None], bc.shape[1], axis=1))
         out["ref_best_curves_y"] = bc[:, :, 1].copy()
     # ---- f1: KDE stand-in + pixel selection (reference compute_new_obs on stored inputs)
-    kde_arr = tr.kernel_density_estimate(bc, bcost)
-    pix = np.argwhere(kde_arr > tr.kde_thresh)
-    if tr.fix_endpoints:
-        pix = pix[(pix[:, 1] > tr.x_st) & (pix[:, 1] < tr.x_en)]
-    thresh_in = tr.score_thresh
-    fobs = tr.compute_new_obs(pix, kde_arr, obs[:, [1, 0]].reshape(-1, 2))
-    out.update(ref_kde_arr=kde_arr.astype(np.float32), in_score_thresh=thresh_in,
-               ref_score_thresh_out=tr.score_thresh, ref_fobs=fobs)
+    if pixels:
+        kde_arr = tr.kernel_density_estimate(bc, bcost)
+        pix = np.argwhere(kde_arr > tr.kde_thresh)
+        if tr.fix_endpoints:
+            pix = pix[(pix[:, 1] > tr.x_st) & (pix[:, 1] < tr.x_en)]
+        thresh_in = tr.score_thresh
+        fobs = tr.compute_new_obs(pix, kde_arr, obs[:, [1, 0]].reshape(-1, 2))
+        out.update(in_score_thresh=thresh_in, ref_score_thresh_out=tr.score_thresh, ref_fobs=fobs)
+        if light:
+            out["ref_kde_probe"] = kde_arr[::97, ::89].astype(np.float32)
+        else:
+            out["ref_kde_arr"] = kde_arr.astype(np.float32)
     # ---- ctor-derived scalars
     out.update(ref_scalars=np.array([tr.x_st, tr.x_en, tr.N_samples, tr.N_keep, tr.N_subints, tr.algo_thresh,
                                      tr.delta_x, tr.pixel_thresh, tr.edge_length], dtype=np.int64),
@@ -119,13 +160,16 @@ def stage_fixture(name, N, img_seed, ctor_kw, obs, gp_seed, keep_samples=None, k
 
 
 def trace_fixture(name, N, img_seed, ctor_kw):
+    global _svd_bits
     img, edge, kern, grad = make_image(N, img_seed)
     init = edge[[0, -1], :][:, [1, 0]]
     kw = dict(ctor_kw)
     kw["return_std"] = False
     tr = gpet.GP_Edge_Tracing(init, grad, **kw)
     _captured.clear()
+    _svd_bits = []
     et, (all_samples, all_obs, iter_curves) = tr(return_lines=True)
+    bits, _svd_bits = _svd_bits, None
     gp = _captured[-1]
     kw["return_std"] = True
     tr2 = gpet.GP_Edge_Tracing(init, grad, **kw)
@@ -144,8 +188,64 @@ def trace_fixture(name, N, img_seed, ctor_kw):
         out["ref_obs_%02d" % i] = np.asarray(o).reshape(-1, 2)
     for i, c in enumerate(iter_curves[:-1]):
         out["ref_optimal_curve_%02d" % i] = c[:, 1]
+    assert len(bits) == len(all_obs) - 2, (len(bits), len(all_obs))  # one factorisation per loop iteration (all_obs: start + per iteration + the final append)
+    for i, b_ in enumerate(bits):
+        out["ref_svd_sign_bits_%02d" % i] = np.packbits(b_)  # iteration i: observation set ref_obs_i -> ref_obs_(i+1)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "iters", out["ref_n_iter"], "edge", et.shape)
+
+
+def readme_fixture(name="readme_trace"):
+    """The README's demo (README.md:46-85) AS WRITTEN on the reference's own image (tests/golden/readme_image.npz, made by the
+    unmodified construct_test_img under scikit-image 0.18.3: make_readme_image.py): the positional call binds seed = 1 to
+    pixel_thresh (clamped to 2), return_std = True to seed (= 1) and fix_endpoints to return_std (quirk Q6)."""
+    global _svd_bits
+    ri = np.load(os.path.join(HERE, "readme_image.npz"))
+    test_img, true_edge = ri["ref_img"], ri["ref_true_edge"]
+    kernel = gpet_utils.kernel_builder(size=(11, 5), unit=False)
+    grad_img = gpet_utils.comp_grad_img(test_img, kernel)
+    assert np.array_equal(grad_img, ri["ref_grad_py39"])  # scipy 1.7.1 (python3.9) and 1.15.3 (here) convolve alike
+    kernel_params = {'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}
+    delta_x, score_thresh, N_samples, noise_y, seed, keep_ratio = 5, 1, 1000, 1, 1, 0.1
+    init = true_edge[[0, -1], :][:, [1, 0]]
+    obs = np.array([])
+    fix_endpoints, return_std = True, True
+    noisy_trace = gpet.GP_Edge_Tracing(init, grad_img, kernel_params, noise_y, obs, N_samples, score_thresh,
+                                       delta_x, keep_ratio, seed, return_std, fix_endpoints)
+    _captured.clear()
+    edge_pred, edge_credint = noisy_trace(False, False, False, False)
+    gp = _captured[-1]
+    again = gpet.GP_Edge_Tracing(init, grad_img, kernel_params, noise_y, obs, N_samples, score_thresh,
+                                 delta_x, keep_ratio, seed, return_std, fix_endpoints)
+    # (return_std is True in this binding, so return_lines is not honoured, gpet.py:902-908: the observation sets are recorded
+    #  where the loop receives them, at the get_best_pixels seam of the instance)
+    all_obs = [np.zeros((0, 2), dtype=np.int64)]
+    seam = again.get_best_pixels
+
+    def recording_seam(*a, **k):
+        fobs = seam(*a, **k)
+        all_obs.append(np.asarray(fobs).reshape(-1, 2).copy())
+        return fobs
+    again.get_best_pixels = recording_seam
+    _svd_bits = []
+    et2, ci2 = again(False, False, False, False)
+    bits, _svd_bits = _svd_bits, None
+    assert np.array_equal(et2, edge_pred)
+    out = dict(in_init=init, ref_edge_trace=edge_pred, ref_ci_lower=edge_credint[0], ref_ci_upper=edge_credint[1],
+               ref_n_iter=len(all_obs) - 1, ref_final_theta=gp.kernel_.theta, ref_final_lml=gp.log_marginal_likelihood_value_,
+               ref_bound=np.array([noisy_trace.pixel_thresh, noisy_trace.seed, int(noisy_trace.return_std), int(noisy_trace.fix_endpoints),
+                                   noisy_trace.algo_thresh], dtype=np.int64),
+               ref_metrics=np.array([gpet_utils.trace_MSE(edge_pred, true_edge), gpet_utils.trace_relarea(edge_pred, true_edge),
+                                     gpet_utils.trace_dicecoef(edge_pred, true_edge)], dtype=np.float64),
+               published_metrics=np.array([12.604, 0.00339, 0.9953]),  # Figures/noisy_trace_results.png (real KDEpy)
+               kde_standin=1)
+    for i, o in enumerate(all_obs):
+        out["ref_obs_%02d" % i] = np.asarray(o).reshape(-1, 2)
+    for i, b_ in enumerate(bits):
+        out["ref_svd_sign_bits_%02d" % i] = np.packbits(b_)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "iterations", out["ref_n_iter"], "bound (pixel_thresh, seed, return_std, fix_endpoints, algo_thresh)", out["ref_bound"],
+          "MSE / rel. area / DICE", out["ref_metrics"], "published", out["published_metrics"])
 
 
 def _quality_one(args):
@@ -254,3 +354,27 @@ if __name__ == "__main__":
         trace_fixture("trace_rbf500", 500, 1, dict(readme))
     if want("quality_rbf500"):
         quality_fixture("quality_rbf500", dict(readme))
+    if want("readme_trace"):
+        readme_fixture()
+    if want("stage_rbf2048_n1500"):
+        # BASELINE config 3's shape (tests/test_gpu_configs.py::test_config3_large_n_gp_iteration builds the same inputs):
+        # 2048^2 image, 1498 user-supplied observations (+ 2 inits = 1500 training points), N_samples = 4000
+        N3 = 2048
+        _, edge3 = orc.synth_sinusoid_image(N3, 0)
+        rng3 = np.random.default_rng(0)
+        cols3 = np.sort(rng3.choice(np.arange(1, N3 - 1), size=1498, replace=False))
+        obs3 = np.stack([cols3, edge3[cols3, 0] + rng3.integers(-2, 3, size=cols3.size)], axis=1).astype(np.int64)
+        stage_fixture("stage_rbf2048_n1500", N3, 0, dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1,
+                                                         N_samples=4000, score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5,
+                                                         seed=1, fix_endpoints=True),
+                      obs3, 7, keep_samples=48, keep_factor_rows=96, light=True, pixels=False)
+    if want("stage_mat1024"):
+        # BASELINE config 5's frame shape: 1024^2, Matern-5/2 sigma_f = 154, l = 41, warm start = every 16th pixel of the previous
+        # (here: the true) trace -- a full-rank covariance, the any-rank factor
+        N5 = 1024
+        _, edge5 = orc.synth_sinusoid_image(N5, 100)
+        obs5 = edge5[16:-16:16][:, [1, 0]].astype(np.int64)
+        stage_fixture("stage_mat1024", N5, 100, dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41},
+                                                     noise_y=1, N_samples=1000, score_thresh=1, delta_x=8, keep_ratio=0.1,
+                                                     pixel_thresh=5, seed=3, fix_endpoints=True),
+                      obs5, 9, keep_samples=48, keep_factor_rows=128, light=True, pixels=True)

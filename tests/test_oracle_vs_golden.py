@@ -211,3 +211,78 @@ def test_oracle_f32_sample_mode(golden):
     et64, _, i64 = orc.trace(g["in_init"], grad, **kw)
     et32, _, i32 = orc.trace(g["in_init"], grad, sample_dtype="f32", **kw)
     assert i32["n_iter"] == i64["n_iter"] and np.array_equal(et32, et64)
+
+
+# ---- round 6: the reference's own demo image, the README-literal trace of it, and the two large stage fixtures -------------
+README_LITERAL = dict(kernel_options={'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}, noise_y=1, obs=np.array([]), N_samples=1000,
+                      score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=1, seed=True, return_std=True)  # Q6: README.md:75-76 as bound
+CTOR_BIG = {
+    "stage_rbf2048_n1500": dict(kernel_options={'kernel': 'RBF', 'sigma_f': 300, 'length_scale': 80}, noise_y=1, N_samples=4000,
+                                score_thresh=1, delta_x=5, keep_ratio=0.1, pixel_thresh=5, seed=1, fix_endpoints=True),
+    "stage_mat1024": dict(kernel_options={'kernel': 'Matern', 'nu': 2.5, 'sigma_f': 154, 'length_scale': 41}, noise_y=1, N_samples=1000,
+                          score_thresh=1, delta_x=8, keep_ratio=0.1, pixel_thresh=5, seed=3, fix_endpoints=True),
+}
+
+
+def test_readme_image_is_the_reference_generators(golden):
+    """tests/golden/readme_image.npz = the UNMODIFIED construct_test_img under scikit-image 0.18.3 (make_readme_image.py).  The
+    package's generator called like the reference (no seed) returns that image bit for bit -- skimage's random_noise(seed=1)
+    is numpy's frozen legacy stream -- for every ltype; and the oracle's convolution of it equals the gradient image the
+    unmodified comp_grad_img produced under ANOTHER scipy (1.7.1)."""
+    import hashlib
+    from gaussian_process_edge_trace_amd import gpet_utils as U
+    g = golden("readme_image")
+    img, edge = U.construct_test_img(size=(500, 500), amplitude=200, curvature=4, noise_level=0.05, ltype='sinusoidal',
+                                     intensity=0.3, gaps=True)
+    assert img.dtype == np.float64 and np.array_equal(img, g["ref_img"]) and np.array_equal(edge, g["ref_true_edge"])
+    for args, want in zip(g["other_args"], g["other_sha256"]):
+        size, amp, curv, var, ltype, inten, gaps = eval(str(args))  # (a tuple literal written by make_readme_image.py)
+        im, ed = U.construct_test_img(size, amp, curv, var, ltype, inten, gaps=gaps)
+        got = hashlib.sha256(np.ascontiguousarray(im).tobytes()).hexdigest() + ":" + hashlib.sha256(np.ascontiguousarray(ed.astype(np.int64)).tobytes()).hexdigest()
+        assert got == str(want), args
+    assert np.array_equal(orc.comp_grad_img(g["ref_img"], orc.kernel_builder((11, 5))), g["ref_grad_py39"])
+
+
+def test_readme_literal_trace_of_the_reference_image(golden):
+    """The README call as written (quirk Q6) on the reference's own image: the oracle under LAPACK's signs reproduces the
+    reference's observation sets of all 29 iterations and its trace; the metrics are the reference's to the digit."""
+    from gaussian_process_edge_trace_amd import gpet_utils as U
+    g, ri = golden("readme_trace"), golden("readme_image")
+    p = orc.resolve_params(g["in_init"], ri["ref_grad_py39"], **README_LITERAL)
+    assert [p["pixel_thresh"], p["seed"], int(p["return_std"]), int(p["fix_endpoints"]), p["algo_thresh"]] == list(g["ref_bound"])
+    rec = []
+    et, ci, info = orc.trace(g["in_init"], ri["ref_grad_py39"], record=rec, **README_LITERAL)
+    assert info["n_iter"] == int(g["ref_n_iter"]) == 29
+    for i, r in enumerate(rec):
+        assert np.array_equal(r["obs_out"], g["ref_obs_%02d" % (i + 1)]), i
+    assert np.array_equal(et, g["ref_edge_trace"])
+    np.testing.assert_allclose(ci[0], g["ref_ci_lower"], rtol=1e-6, atol=1e-6)
+    te = ri["ref_true_edge"]
+    assert [U.trace_MSE(et, te), U.trace_relarea(et, te), U.trace_dicecoef(et, te)] == list(g["ref_metrics"])
+
+
+@pytest.mark.parametrize("name", ["stage_mat1024", "stage_rbf2048_n1500"])
+def test_large_stage_fixtures(golden, name):
+    """BASELINE config 5's frame and config 3's shape from the unmodified reference: the oracle's fit / predict, the factor
+    under LAPACK's signs, the samples and their costs."""
+    g = golden(name)
+    N = int(g["ref_scalars"][8])
+    img, edge = orc.synth_sinusoid_image(N, int(g["in_img_seed"]))
+    grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+    assert np.array_equal(grad[::97, ::89], g["ref_grad_probe"])
+    kw = CTOR_BIG[name]
+    p = orc.resolve_params(g["in_init"], grad, **kw)
+    assert [p["x_st"], p["x_en"], p["N_samples"], p["N_keep"], p["N_subints"], p["algo_thresh"], p["delta_x"], p["pixel_thresh"],
+            p["edge_length"]] == list(g["ref_scalars"])
+    Y, info = orc.fit_predict_samples(p["init"], g["in_obs"], p, int(g["in_gp_seed"]), want_all=True)
+    fit, pred = info["fit"], info["pred"]
+    np.testing.assert_allclose(fit["alpha"], g["ref_alpha"], rtol=1e-6, atol=1e-9 * np.abs(g["ref_alpha"]).max())
+    np.testing.assert_allclose(np.diag(fit["L"]), g["ref_L_diag"], rtol=1e-10)
+    np.testing.assert_allclose(pred["mean"], g["ref_mean"], rtol=1e-9)
+    np.testing.assert_allclose(pred["std"], g["ref_std"], rtol=1e-6, atol=1e-9)
+    ns = g["ref_samples_head"].shape[1]
+    assert np.array_equal(Y[:, :ns], g["ref_samples_head"])  # (LAPACK's signs, this host: the reference's own samples)
+    grad64 = orc.normalise(grad, (0, 1), np.float64)
+    costs = orc.costs_batch(grad64, p["x_grid"], Y)
+    np.testing.assert_allclose(costs, g["ref_costs"], rtol=1e-12)
+    assert np.array_equal(np.argsort(costs, kind="stable")[:p["N_keep"]], g["ref_best_idxs"])
