@@ -288,7 +288,26 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   HIPCHK(c, hipMalloc(&b->d_minmax, sizeof(unsigned int) * 2 * (size_t)B));
   {
     // (the stream the normals run ahead of the loop on: default priority -- lowest / highest were measured, +-0)
-    HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+    // Option side_own_queue: the HIP runtime maps a process's streams onto a pool of GPU_MAX_HW_QUEUES hardware queues, and a
+    // batch whose look-ahead stream lands on the queue of its own loop runs the two IN ORDER -- the loop then stands still for
+    // every 3 ms generator launch (a 32-edge loop 11.8 or 15.9 ms by luck, in a process that has created other contexts
+    // before).  A stream created with a CU mask gets a hardware queue of its own from the runtime: with all CUs enabled it is
+    // an ordinary stream that shares its queue with nobody.
+    bool made = false;
+    // (-1: batches up to 64 edges, the ones whose normals run ahead on this stream; eight more hardware queues under the eight
+    //  1 024-edge objects of the bench cost 3.5 % of its throughput -- their generator runs on the loop's own stream anyway)
+    const int own_q = option("side_own_queue");
+    if (own_q > 0 || (own_q < 0 && B <= 64)) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) {
+        const unsigned int words = (unsigned int)((prop.multiProcessorCount + 31) / 32);
+        std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+        if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+        made = hipExtStreamCreateWithCUMask(&b->side, words, mask.data()) == hipSuccess;
+        if (!made) (void)hipGetLastError();
+      }
+    }
+    if (!made) HIPCHK(c, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
   }
   {
     int pr_least = 0, pr_greatest = 0;
@@ -564,6 +583,8 @@ int gpet_batch_set_obs(gpet_batch* b, int e, const int64_t* obs_xy, int n_obs) {
     if (rc3) return rc3;
   }
   b->iters_issued = 0;   // (all edges of a batch are restarted together)
+  if ((int)b->h_nobs_prev.size() != b->B) b->h_nobs_prev.assign(b->B, 0);
+  b->h_nobs_prev[e] = n_obs;  // (the loop's group sizes follow the growth of the observation sets from here)
   b->norm_issued = 0;
   if (b->structured)
     for (int i = 0; i < n_obs; ++i)
@@ -797,6 +818,7 @@ int gpet_batch_clear_injected_factor(gpet_batch* b, int e) {
 
 static int batch_reset(gpet_batch* b, bool next_frame) {
   gpet_ctx* c = b->ctx;
+  b->h_nobs_prev.assign(b->B, 0);
   b->iters_issued = 0;
   b->norm_issued = 0;
   HIPCHK(c, hipSetDevice(c->device));

@@ -107,7 +107,7 @@ hipError_t launch_normals_seq(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, i
 // most of the GPU idle and the streams are long -- every stream cut into chunks that many workgroups generate at once
 // (MT19937 jump-ahead, launch_normals_chunked).  The same numbers either way.
 int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l, int add_iter,
-                        int iter_abs, int n_ahead, int z_store) {
+                        int iter_abs, int n_ahead, int z_store, bool allow_chunked) {
   gpet_ctx* c = b->ctx;
   if (b->rng_mode == 1) {  // opt-in Philox mode (gpet_batch_set_rng)
     HIPCHK(c, launch_normals_philox(st, edges_l, B_l, b->bd, seeds_l, add_iter, iter_abs, n_ahead, z_store));
@@ -117,7 +117,9 @@ int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const
   const int nc = mtj_chunks((long long)b->bd.S * b->bd.Lg);
   const int opt = opt_rng_chunked();
   const bool force4 = gpet_opt_rng4() > 0 && b->bd.rng4;  // (tests: the register-resident generator on any launch shape)
-  const bool chunked = !force4 && nc >= 2 && (opt > 0 || (opt < 0 && streams <= 32 && nc >= 4));
+  // (the chunked form works in the batch's ONE jump workspace: a launch that runs beside another chunked launch of the same batch
+  //  -- the tail of a small batch's first normals on the fit stream, gpet_trace_iterate -- must take the sequential kernel)
+  const bool chunked = allow_chunked && !force4 && nc >= 2 && (opt > 0 || (opt < 0 && streams <= 32 && nc >= 4));
   if (!chunked) {
     HIPCHK(c, launch_normals_seq(b, st, edges_l, B_l, seeds_l, add_iter, iter_abs, n_ahead, z_store));
     return GPET_OK;

@@ -55,6 +55,7 @@ struct gpet_batch {
   long long* d_obs = nullptr;          // [B][obs_cap_max][2] contiguous observations: one copy reads them all
   long long* d_init = nullptr;         // [B][n_init_max][2] contiguous init points: one copy writes them all
   std::vector<gpet_scalars> h_scalars;
+  std::vector<int> h_nobs_prev;        // observations per edge at the last group boundary of the loop (adaptive group sizes)
   int iters_issued = 0;                // iterations enqueued since the last reset (== sc->iter of active edges)
   int rng_mode = 0;                    // 0: MT19937 + polar method = numpy's RandomState stream; 1: Philox4x32-10 + Box-Muller (opt-in)
   hipStream_t side = nullptr;          // RNG stream: normals of upcoming iterations run ahead of the loop
@@ -137,7 +138,7 @@ int& opt_fit_persistent();
 hipError_t launch_normals_seq(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l, int add_iter,
                               int iter_abs, int n_ahead, int z_store);
 int normals_auto(gpet_batch* b, hipStream_t st, EdgeDev* edges_l, int B_l, const unsigned int* seeds_l, int add_iter, int iter_abs,
-                 int n_ahead, int z_store);
+                 int n_ahead, int z_store, bool allow_chunked = true);
 // ---- gpet_api_batch.hip ---------------------------------------------------------------------------------------------------
 int fetch_all_scalars(gpet_batch* b);
 int check_device_status(gpet_batch* b);

@@ -95,7 +95,12 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         for (int q = cur; q < cur + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], c->stream));
         b->norm_issued = cur + n;
       }
-      if (!rng_inline && deep && b->norm_issued - cur <= look / 2) {
+      // (refill when fewer than `rng_refill_at` iterations are left in the ring.  Round 5 refilled at look / 2 = 4: four iterations of
+      //  a 32-edge batch take 2.4 ms, the sequential launch that refills the ring 3 ms -- every refill stalled the loop, and by how
+      //  much depended on when the launch got going: 13.5 or 16.7 ms per loop from one run to the next.  At 6 the launch has a
+      //  3.6 ms lead.)
+      const int refill_at = option("rng_refill_at") < 0 ? (look > 2 ? look - 2 : look / 2) : option("rng_refill_at");
+      if (!rng_inline && deep && b->norm_issued - cur <= refill_at) {
         // small batch: the streams of the next `n` iterations in ONE launch (blockIdx.x = iteration), side by side.
         // Their ring slots were last read by the sample GEMMs of iterations <= cur - 1 (outstanding + n <= ring).
         const int j = b->norm_issued;
@@ -122,7 +127,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
         hipStream_t rest = head > 0 ? b->fit : b->side;
         if (head > 0) HIPCHK(c, hipStreamWaitEvent(b->fit, b->ev_main, 0));  // (the seeds and the edge table are on the device)
         if (n > head) {
-          int rcn = normals_auto(b, rest, edges_l, B_l, seeds_l, 1, j + head, n - head, loop_z_store(b));
+          int rcn = normals_auto(b, rest, edges_l, B_l, seeds_l, 1, j + head, n - head, loop_z_store(b), head == 0);
           if (rcn) return rcn;
         }
         for (int q = j + head; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], rest));
@@ -178,6 +183,27 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     remaining -= n_it;
     if (active == 0) break;
     group = active == b->B ? (group < 4 ? group : 4) : 2;
+    // Small batches (round 6): a latency chain, where an iteration enqueued for edges that have finished costs its ~16 empty
+    // launches (~90 us) and a group boundary a host round trip of about the same -- the fixed 8 / 4 / 2 / 2 ladder spent 0.5 ms
+    // of a 6.6 ms single-edge loop on the two.  The observation sets grow at a steady rate (pixel_thresh or a few more per
+    // iteration), so the next group is what the slowest running edge still needs at the rate of the group
+    // just finished: usually ONE more group that ends on the last iteration.
+    if (b->B <= 64 && option("loop_adaptive_groups")) {
+      if ((int)b->h_nobs_prev.size() != b->B) b->h_nobs_prev.assign(b->B, 0);
+      int need = 1;
+      for (int e = 0; e < b->B; ++e) {
+        const gpet_scalars& s_ = b->h_scalars[e];
+        if (!s_.done) {
+          const int got = s_.n_obs - b->h_nobs_prev[e];
+          const double rate = got > 0 ? (double)got / (double)n_it : 1.0;
+          const int left = b->h_edges[e].algo_thresh - s_.n_obs;
+          int est = (int)ceil((double)(left > 0 ? left : 1) / rate);
+          if (est > need) need = est;
+        }
+        b->h_nobs_prev[e] = s_.n_obs;
+      }
+      group = need < 1 ? 1 : (need > 8 ? 8 : need);
+    }
   }
   return GPET_OK;
 }

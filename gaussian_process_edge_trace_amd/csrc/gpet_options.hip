@@ -17,6 +17,9 @@ const OptionDef kDefs[] = {
     {"rng_chunked", -1, -1, 1, "one MT19937 stream on many workgroups by jump-ahead: -1 = launches of <= 32 streams of >= 4 chunks, 0 = never, 1 = always"},
     {"rng_lookahead", -1, -1, 15, "iterations the normals may run ahead of the device loop on the side stream; -1: 8 up to 64 edges, else 1"},
     {"rng_head", -1, -1, 8, "batches of 2..32 edges: leading iterations of a trace whose normals are generated chunked (jump-ahead, one launch per iteration) beside the sequential launch of the following ones; -1: 4, 0: off"},
+    {"loop_adaptive_groups", 1, 0, 1, "device loop of batches up to 64 edges: after the first group of 8 iterations the next group is what the slowest running edge still needs at its last rate of new observations; 0: the fixed 8 / 4 / 2 / 2 ladder"},
+    {"rng_refill_at", -1, -1, 15, "small batches: the side stream refills the normals ring when at most this many generated iterations are left ahead of the loop; -1: look-ahead - 2 (round 5: look-ahead / 2)"},
+    {"side_own_queue", -1, -1, 1, "a batch's RNG look-ahead stream is created with an all-CUs mask (hipExtStreamCreateWithCUMask): the runtime then gives it a hardware queue of its own instead of one from the process's shared pool, so it can never end up in order behind the batch's own loop (read when a batch is created); -1: batches up to 64 edges"},
     {"rng_inline", -1, -1, 2, "where the loop's normals are generated: 0 = side stream, 1 = one iteration per launch on the loop's stream, 2 = all iterations of a group in one launch on the loop's stream; -1: 2 above 64 edges, else 0"},
     {"z_store_full", 0, 0, 1, "1: the structured loop stores all z_cols normals of a sample row instead of the r0 (rounded to 4) its factors multiply"},
     {"fit_persistent", -1, -1, 1, "converged fits as one workgroup per (edge, restart) problem: -1 = problem sets resident at once (<= 1024), 0 = lock-step rounds, 1 = always"},
@@ -27,7 +30,7 @@ const OptionDef kDefs[] = {
     {"jacobi_warm", 1, 0, 1, "structured loop: the eigen-decomposition of an iteration starts from the previous iteration's eigenvectors (k_jacobi_prerot) instead of the identity"},
     {"jacobi_wreg", 6, 0, 8, "k_jacobi_seat: 7 x this many rows of the eigenvector matrix in the worker waves' registers instead of LDS (0, 4, 6, 8)"},
     {"jacobi_logw", 1, 0, 1, "batches that have a rotation log (<= jlog_max_b edges): eigenvectors by a separate pass over the logged rotations"},
-    {"wpass_lds", 1, 0, 1, "rotation-log pass (k_jacobi_wpass): 1 = eight rows of W per workgroup share every tile of the log through LDS (k_jacobi_wpass_lds); 0 = every wave streams the log itself (the round-5 kernel, the same bits)"},
+    {"wpass_lds", 0, 0, 1, "rotation-log pass (k_jacobi_wpass): 1 = eight rows of W per workgroup share every tile of the log through LDS (k_jacobi_wpass_lds: 68 against 80 us per launch of 32 edges, the same bits -- but the 32-edge loop then takes 13.6 instead of 11.8 ms: its 512-thread, 49 KB workgroups wait for CUs the look-ahead generator occupies); 0 = every wave streams the log itself"},
     {"jlog_max_b", 32, 0, 4096, "largest batch that gets a rotation log (read when a batch is created): measured per step of a batch alone -- 32 edges 21.5 against 23.1 ms, 64 edges 27.1 either way, 1 024 edges slower (3.15 against 1.73 ms per launch)"},
     {"oj_warm", 1, 0, 1, "any-rank factor: rows of full rank start from the previous iteration's rows (k_ojw_*: A Sigma A^T, its Cholesky factor, one product) instead of the pivoted Cholesky (across the frames of a sequence only where the caller asks: gpet_batch_set_images with GPET_IMAGES_NEXT_FRAME)"},
     {"oj_warm_fail", 0, 0, 1, "testing: the warm start's Cholesky reports a non-positive pivot, so that the factor falls back to the pivoted Cholesky"},
