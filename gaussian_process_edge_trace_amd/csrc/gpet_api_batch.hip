@@ -294,10 +294,7 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
     // before).  A stream created with a CU mask gets a hardware queue of its own from the runtime: with all CUs enabled it is
     // an ordinary stream that shares its queue with nobody.
     bool made = false;
-    // (-1: batches up to 64 edges, the ones whose normals run ahead on this stream; eight more hardware queues under the eight
-    //  1 024-edge objects of the bench cost 3.5 % of its throughput -- their generator runs on the loop's own stream anyway)
-    const int own_q = option("side_own_queue");
-    if (own_q > 0 || (own_q < 0 && B <= 64)) {
+    if (option("side_own_queue")) {  // (off by default: measured, see the option's description)
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) {
         const unsigned int words = (unsigned int)((prop.multiProcessorCount + 31) / 32);

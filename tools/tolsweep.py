@@ -14,9 +14,10 @@ for step in (16, 64, 0):
     tr = amd.GP_Edge_Tracing(init, grad, obs=warm, **kw, _ctx=ctx); b = tr._batch
     b.set_obs(0, warm); b.fit_predict(True)
     cov=b.read(L.BUF_COV); F,_,_=orc.mvn_factor_svd(cov,"harmonic")
-    for ex in (11, 9, 7, 5):
+    for ex in (11, 9, 8, 7, 6, 5):
         L.set_option("oj_tol_exp", ex)
         b.factor(); s=b.scalars(); A=b.read(L.BUF_FACTOR)
         ms=b.profile_stage(1,2)
-        print("obs step %d tol 1e-%d: %d sweeps, %.1f ms, max sample diff vs LAPACK %.3g px, recon %.2g" % (step, ex, int(s.lml), ms, np.abs(Z@A-Z@F).max()*s.y_s, np.abs(A.T@A-cov).max()/np.abs(cov).max()), flush=True)
+        Gm = A @ A.T; dd = np.sqrt(np.diag(Gm)); orth = np.abs(Gm / dd[:, None] / dd[None, :] - np.eye(len(dd))).max()
+        print("obs step %d tol 1e-%d: %d sweeps, %.1f ms, max sample diff vs LAPACK %.3g px, recon %.2g, max |cos(row_p, row_q)| %.2g" % (step, ex, int(s.lml), ms, np.abs(Z@A-Z@F).max()*s.y_s, np.abs(A.T@A-cov).max()/np.abs(cov).max(), orth), flush=True)
     L.set_option("oj_tol_exp", 11)
