@@ -195,6 +195,43 @@ def trace_fixture(name, N, img_seed, ctor_kw):
     print(name, "iters", out["ref_n_iter"], "edge", et.shape)
 
 
+def _replay_one(args):
+    """(image seed, RNG seed, ctor kwargs, N) -> what a replay needs of one reference trace: the observation set after every
+    iteration, the SVD sign bits of every iteration, the final trace."""
+    global _svd_bits
+    img_seed, seed, kw, N = args
+    img, edge, kern, grad = make_image(N, img_seed)
+    init = edge[[0, -1], :][:, [1, 0]]
+    kw = dict(kw, seed=seed, return_std=False)
+    tr = gpet.GP_Edge_Tracing(init, grad, **kw)
+    _svd_bits = []
+    et, (all_samples, all_obs, iter_curves) = tr(return_lines=True)
+    bits, _svd_bits = _svd_bits, None
+    n_iter = len(all_obs) - 2
+    assert len(bits) == n_iter
+    obs = [np.asarray(o).reshape(-1, 2).astype(np.int16) for o in all_obs[:-1]]
+    return dict(img_seed=img_seed, seed=seed, n_iter=n_iter, edge_trace=et.astype(np.int16), obs=obs,
+                bits=[np.packbits(b_) for b_ in bits])
+
+
+def replay_fixture(name, N, kw, img_seeds, seeds, workers=4):
+    """Many reference traces of one configuration, each reduced to what the GPU replay needs (observation sets as int16, one sign
+    bit per factor row and iteration, the final trace): ~10 KB per trace."""
+    import multiprocessing as mp
+    jobs = [(a, b, kw, N) for a in img_seeds for b in seeds]
+    with mp.get_context("fork").Pool(workers) as pool:
+        rows = pool.map(_replay_one, jobs, chunksize=1)
+    out = dict(in_N=N, in_img_seeds=np.array([r["img_seed"] for r in rows]), in_seeds=np.array([r["seed"] for r in rows]),
+               ref_n_iter=np.array([r["n_iter"] for r in rows]), kde_standin=1)
+    for t, r in enumerate(rows):
+        out["ref_edge_trace_%02d" % t] = r["edge_trace"]
+        out["ref_obs_counts_%02d" % t] = np.array([o.shape[0] for o in r["obs"]], dtype=np.int16)
+        out["ref_obs_all_%02d" % t] = np.concatenate(r["obs"], axis=0) if sum(o.shape[0] for o in r["obs"]) else np.zeros((0, 2), np.int16)
+        out["ref_svd_sign_bits_%02d" % t] = np.stack(r["bits"], axis=0)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, len(rows), "traces, iterations", out["ref_n_iter"].tolist())
+
+
 def readme_fixture(name="readme_trace"):
     """The README's demo (README.md:46-85) AS WRITTEN on the reference's own image (tests/golden/readme_image.npz, made by the
     unmodified construct_test_img under scikit-image 0.18.3: make_readme_image.py): the positional call binds seed = 1 to
@@ -356,6 +393,15 @@ if __name__ == "__main__":
         quality_fixture("quality_rbf500", dict(readme))
     if want("readme_trace"):
         readme_fixture()
+    if want("replay_rbf500"):
+        # twelve more reference traces of the README configuration (pixel_thresh = 5): two images x six RNG seeds 997 apart
+        replay_fixture("replay_rbf500", 500, dict(readme), (1, 3), [1000 + 997 * k for k in range(6)])
+    if want("replay_default500"):
+        # the reference's DEFAULT kernel (kernel_options = (1, 3, 3): Matern-5/2, sigma_f = M // 6, l = edge_length // 2,
+        # gpet.py:25,139-151) at the README's size: full-rank covariances, the any-rank factor of the device
+        dflt = dict(readme)
+        dflt["kernel_options"] = (1, 3, 3)
+        replay_fixture("replay_default500", 500, dflt, (1,), [1, 998], workers=2)
     if want("stage_rbf2048_n1500"):
         # BASELINE config 3's shape (tests/test_gpu_configs.py::test_config3_large_n_gp_iteration builds the same inputs):
         # 2048^2 image, 1498 user-supplied observations (+ 2 inits = 1500 training points), N_samples = 4000

@@ -286,3 +286,23 @@ def test_large_stage_fixtures(golden, name):
     costs = orc.costs_batch(grad64, p["x_grid"], Y)
     np.testing.assert_allclose(costs, g["ref_costs"], rtol=1e-12)
     assert np.array_equal(np.argsort(costs, kind="stable")[:p["N_keep"]], g["ref_best_idxs"])
+
+
+def test_replay_fixtures_are_the_oracles_traces(golden):
+    """Spot check of the many-trace replay fixtures against the oracle under LAPACK's signs (the first README-configuration trace
+    and the first default-kernel trace: observation sets after every iteration and the final trace)."""
+    for name, ko in (("replay_rbf500", {'kernel': 'RBF', 'sigma_f': 75, 'length_scale': 20}), ("replay_default500", (1, 3, 3))):
+        g = golden(name)
+        N, t = int(g["in_N"]), 0
+        img, edge = orc.synth_sinusoid_image(N, int(g["in_img_seeds"][t]))
+        grad = orc.comp_grad_img(img, orc.kernel_builder((11, 5)))
+        rec = []
+        kw = dict(CTOR["stage_rbf500"], kernel_options=ko, seed=int(g["in_seeds"][t]))
+        et, _, info = orc.trace(edge[[0, -1], :][:, [1, 0]], grad, record=rec, **kw)
+        assert info["n_iter"] == int(g["ref_n_iter"][t])
+        counts = g["ref_obs_counts_%02d" % t].astype(int)
+        allobs = g["ref_obs_all_%02d" % t].astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        for i, r in enumerate(rec):
+            assert np.array_equal(r["obs_out"], allobs[offs[i + 1]:offs[i + 2]]), (name, i)
+        assert np.array_equal(et, g["ref_edge_trace_%02d" % t].astype(int))
