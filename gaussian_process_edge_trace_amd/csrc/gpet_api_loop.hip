@@ -165,9 +165,14 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
       const int rank_max = b->structured ? b->bd.r0_max : 0;
       HIPCHK(c, launch_sample(c->stream, edges_l, B_l, b->bd, rank_max));
       HIPCHK(c, hipEventRecord(b->ev_gemm[cur % 16], c->stream));
-      HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
       // loop form: the density stays raw and band-limited in HBM; the pixel kernels normalise on the fly
-      HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
+      const int tail_opt = option("loop_fused_tail");
+      if ((tail_opt > 0 || (tail_opt < 0 && b->B <= 64)) && score_tail_applies(b->bd)) {
+        HIPCHK(c, launch_score_kde_fused_tail(c->stream, edges_l, B_l, b->bd));  // (small batches: three launches fewer per iteration)
+      } else {
+        HIPCHK(c, launch_score(c->stream, edges_l, B_l, b->bd));
+        HIPCHK(c, launch_kde(c->stream, edges_l, B_l, b->bd, 0, ~0u, 1));
+      }
       HIPCHK(c, launch_pixels(c->stream, edges_l, B_l, b->bd, 1));
       HIPCHK(c, hipEventRecord(b->ev_pix[cur % 16], c->stream));
       b->iters_issued += 1;

@@ -20,6 +20,7 @@ const OptionDef kDefs[] = {
     {"loop_adaptive_groups", 1, 0, 1, "device loop of batches up to 64 edges: after the first group of 8 iterations the next group is what the slowest running edge still needs at its last rate of new observations; 0: the fixed 8 / 4 / 2 / 2 ladder"},
     {"rng_refill_at", -1, -1, 15, "small batches: the side stream refills the normals ring when at most this many generated iterations are left ahead of the loop; -1: look-ahead - 2 (round 5: look-ahead / 2)"},
     {"side_own_queue", 0, 0, 1, "1: a batch's RNG look-ahead stream is created with an all-CUs mask (hipExtStreamCreateWithCUMask), which makes the runtime give it a hardware queue of its own instead of one from the process's shared pool (read when a batch is created).  Off: in a process that creates contexts repeatedly it removes the occasional 32-edge loop whose look-ahead stream shares its own loop's queue (16 instead of 12 ms), but every such queue is one more for the hardware scheduler -- with the bench's eight objects in flight a 32-edge batch then takes 32 instead of 16 ms and the headline loses 3.5 %"},
+    {"loop_fused_tail", -1, -1, 1, "device loop: k_score_combine + k_topk_sort + k_kde_prep as one launch per iteration (k_score_tail, the same bits); -1: batches up to 64 edges (latency chains), 1: always where the shape allows, 0: never"},
     {"rng_inline", -1, -1, 2, "where the loop's normals are generated: 0 = side stream, 1 = one iteration per launch on the loop's stream, 2 = all iterations of a group in one launch on the loop's stream; -1: 2 above 64 edges, else 0"},
     {"z_store_full", 0, 0, 1, "1: the structured loop stores all z_cols normals of a sample row instead of the r0 (rounded to 4) its factors multiply"},
     {"fit_persistent", -1, -1, 1, "converged fits as one workgroup per (edge, restart) problem: -1 = problem sets resident at once (<= 1024), 0 = lock-step rounds, 1 = always"},
