@@ -2,6 +2,9 @@
 // Wavefront = 64 lanes everywhere.  blockIdx.y selects the edge of the batch.
 #include "gpet_kernels.h"
 #include "gpet_options.h"
+#ifndef LB_FN
+#define LB_FN inline __attribute__((always_inline))  // (see gpet_lbfgsb_dev.h; -DLB_FN="__attribute__((noinline))" builds round 5's form)
+#endif
 #include "gpet_lbfgsb_dev.h"
 
 #include <atomic>

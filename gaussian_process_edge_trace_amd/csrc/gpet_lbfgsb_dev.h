@@ -5,6 +5,15 @@
 #pragma once
 #include "gpet_kernels.h"
 
+// LB_FN: how the state machine's functions are compiled into the including unit.  Default: not inlined (the round-based driver
+// k_lb_advance, gpet_lbfgsb.hip).  gpet_kernels.hip defines it as inline for k_lml16_fit (round 6): inside that kernel a call costs
+// the spill and reload of the objective's live registers around it and leaves every field of the problem in LDS; inlined, the
+// optimiser keeps the scalars of the step in registers.  (The two modes already differ in the objective's last bits: the tests
+// compare them to tolerance, tests/test_gpu_trace.py::test_final_fit_one_workgroup_per_problem_equals_rounds.)
+#ifndef LB_FN
+#define LB_FN __attribute__((noinline))
+#endif
+
 namespace gpet {
 
 #define LB_M 10
@@ -41,7 +50,7 @@ static __device__ __forceinline__ void lb_bounds(double* lo, double* hi) {
   hi[2] = log(1.0);
 }
 
-static __device__ __attribute__((noinline)) double lb_projgr(const double* x, const double* g, const double* l, const double* u) {
+static __device__ LB_FN double lb_projgr(const double* x, const double* g, const double* l, const double* u) {
   double s = 0.0;
   for (int i = 0; i < 3; ++i) {
     double gi = g[i];
@@ -53,7 +62,7 @@ static __device__ __attribute__((noinline)) double lb_projgr(const double* x, co
 }
 
 // B = theta I updated by the stored pairs, oldest first
-static __device__ __attribute__((noinline)) void lb_dense_B(const LbProb& p, double B[3][3]) {
+static __device__ LB_FN void lb_dense_B(const LbProb& p, double B[3][3]) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) B[i][j] = (i == j) ? p.theta : 0.0;
   for (int k = 0; k < p.ncorr; ++k) {
@@ -70,7 +79,7 @@ static __device__ __attribute__((noinline)) void lb_dense_B(const LbProb& p, dou
 
 // generalised Cauchy point (algorithm CP of Byrd et al.): first local minimiser of the quadratic model along the
 // projected steepest-descent path.  free[i] = variable i is not at a bound at xcp.
-static __device__ __attribute__((noinline)) void lb_cauchy(const double* x, const double* g, const double* l, const double* u, const double B[3][3],
+static __device__ LB_FN void lb_cauchy(const double* x, const double* g, const double* l, const double* u, const double B[3][3],
                           double sbgnrm, double* xcp, int* free_) {
   for (int i = 0; i < 3; ++i) {
     xcp[i] = x[i];
@@ -160,7 +169,7 @@ static __device__ __attribute__((noinline)) void lb_cauchy(const double* x, cons
 }
 
 // x = A^-1 b for an m x m system, m <= 3, LU with partial pivoting (what numpy.linalg.solve / LAPACK gesv does)
-static __device__ __attribute__((noinline)) void lb_solve(int m, double A[3][3], double* b, double* x) {
+static __device__ LB_FN void lb_solve(int m, double A[3][3], double* b, double* x) {
   int perm[3] = {0, 1, 2};
   for (int c = 0; c < m; ++c) {
     int pv = c;
@@ -189,7 +198,7 @@ static __device__ __attribute__((noinline)) void lb_solve(int m, double A[3][3],
 }
 
 // subspace minimisation over the free variables at the Cauchy point, with the projection / backtracking of L-BFGS-B 3.0
-static __device__ __attribute__((noinline)) void lb_subsm(const double* x, const double* g, const double* xcp, const int* free_, const double* l,
+static __device__ LB_FN void lb_subsm(const double* x, const double* g, const double* xcp, const int* free_, const double* l,
                          const double* u, const double B[3][3], double* xn) {
   int idx[3], m = 0;
   for (int i = 0; i < 3; ++i) {
@@ -253,7 +262,7 @@ static __device__ __attribute__((noinline)) void lb_subsm(const double* x, const
 }
 
 // MINPACK-2 dcstep: safeguarded cubic / quadratic step of the More-Thuente line search
-static __device__ __attribute__((noinline)) void lb_dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
+static __device__ LB_FN void lb_dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
                           double fp, double dp, int& brackt, double stpmin, double stpmax) {
   const double sgnd = dp * (dx / fabs(dx));
   double stpf;
@@ -329,7 +338,7 @@ static __device__ __attribute__((noinline)) void lb_dcstep(double& stx, double& 
 }
 
 // MINPACK-2 dcsrch, one return per objective evaluation.  Returns 0: evaluate at the new p.stp; 1: converged; 2: warning
-static __device__ __attribute__((noinline)) int lb_ls_step(LbProb& p, double f, double g) {
+static __device__ LB_FN int lb_ls_step(LbProb& p, double f, double g) {
   const double stpmin = 0.0, stpmax = p.stpmx;
   double stp = p.stp;
   const double ftest = p.finit + stp * p.gtest;
@@ -373,7 +382,7 @@ static __device__ __attribute__((noinline)) int lb_ls_step(LbProb& p, double f, 
   return 0;
 }
 
-static __device__ __attribute__((noinline)) void lb_emit_trial(LbProb& p) {
+static __device__ LB_FN void lb_emit_trial(LbProb& p) {
   p.ifun += 1;
   p.nfev += 1;
   for (int i = 0; i < 3; ++i) p.xe[i] = (p.stp == 1.0) ? p.z[i] : p.stp * p.d[i] + p.xold[i];
@@ -381,7 +390,7 @@ static __device__ __attribute__((noinline)) void lb_emit_trial(LbProb& p) {
 }
 
 // search direction of a new iteration + the first trial point of its line search (or termination)
-static __device__ __attribute__((noinline)) void lb_begin_iteration(LbProb& p, const double* l, const double* u) {
+static __device__ LB_FN void lb_begin_iteration(LbProb& p, const double* l, const double* u) {
   for (;;) {
     double B[3][3];
     lb_dense_B(p, B);
@@ -452,7 +461,7 @@ static __device__ __attribute__((noinline)) void lb_begin_iteration(LbProb& p, c
 }
 
 // consume the objective value at p.xe and move to the next trial point
-static __device__ __attribute__((noinline)) void lb_advance(LbProb& p, double f, const double* g, const double* l, const double* u) {
+static __device__ LB_FN void lb_advance(LbProb& p, double f, const double* g, const double* l, const double* u) {
   if (p.task == LB_TASK_FIRST) {
     p.f = f;
     for (int i = 0; i < 3; ++i) p.g[i] = g[i];
