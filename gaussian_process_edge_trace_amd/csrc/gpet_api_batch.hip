@@ -317,7 +317,6 @@ int gpet_batch_create2(gpet_ctx* c, int B, int M, int N, const float* const* gra
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_gemm[i], hipEventDisableTiming));
   for (int i = 0; i < 16; ++i) HIPCHK(c, hipEventCreateWithFlags(&b->ev_pix[i], hipEventDisableTiming));
   HIPCHK(c, hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming));
-  HIPCHK(c, hipEventCreateWithFlags(&b->ev_head, hipEventDisableTiming));
   // upload: gradient image(s) re-normalised on the device (gpet.py:97), inits, initial scalars
   HIPCHK(c, hipMalloc(&b->d_raw, px * sizeof(float)));
   {
@@ -462,7 +461,6 @@ void gpet_batch_destroy(gpet_batch* b) {
   for (int i = 0; i < 16; ++i)
     if (b->ev_pix[i]) (void)hipEventDestroy(b->ev_pix[i]);
   if (b->ev_main) (void)hipEventDestroy(b->ev_main);
-  if (b->ev_head) (void)hipEventDestroy(b->ev_head);
   if (b->d_edge_of) (void)hipFree(b->d_edge_of);
   if (b->d_theta) (void)hipFree(b->d_theta);
   if (b->d_f) (void)hipFree(b->d_f);

@@ -69,7 +69,6 @@ struct gpet_batch {
   hipEvent_t ev_pix[16] = {};          // pixel selection of iteration k done: the `done` flags of iteration k + 1 are final
   int norm_issued = 0;                 // iterations whose normals have been enqueued on `side`
   hipEvent_t ev_main = nullptr;
-  hipEvent_t ev_head = nullptr;        // the head of a small batch's normals on the fit stream has been enqueued (gpet_trace_iterate)
   unsigned int* d_minmax = nullptr;    // [2 B]: (min, max) of every gradient image being uploaded
   std::vector<unsigned int> h_mm0;     // their reset values (kept alive for the asynchronous copy)
   float* d_raw = nullptr;  // [M*N] staging of a user gradient image before its re-normalisation (gpet.py:97)

@@ -33,6 +33,7 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
   // it still starts one workgroup per edge and tile to find that out: 2.2 ms per iteration for 1024 finished edges, and
   // the last iterations of a batch run with a handful of edges left.
   int remaining = max_iters, group = 8, active = b->B;
+  bool fit_used = false;  // the head of a small batch's normals put a launch on the fit stream (this call)
   bool flags_known = false;
   *n_active = b->B;
   if (max_iters == 0) {
@@ -131,10 +132,9 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
           if (rcn) return rcn;
         }
         for (int q = j + head; q < j + n; ++q) HIPCHK(c, hipEventRecord(b->ev_norm[q % 16], rest));
-        if (head > 0) {  // later refills run on the side stream: after everything the head put on the fit stream
-          HIPCHK(c, hipEventRecord(b->ev_head, b->fit));
-          HIPCHK(c, hipStreamWaitEvent(b->side, b->ev_head, 0));
-        }
+        // (later refills run on the side stream BESIDE this tail -- different ring slots, and the tail is the sequential kernel,
+        //  which has no workspace; the host waits for the fit stream too at the end of the group)
+        if (head > 0) fit_used = true;
         b->norm_issued = j + n;
       }
       const int look_now = look;  // (after the GEMM instead of beside the eigen-solver was measured: +-0)
@@ -179,6 +179,10 @@ int gpet_trace_iterate(gpet_batch* b, const uint32_t* base_seeds, int max_iters,
     }
     b->have_fit = b->have_factor = b->have_normals = b->have_samples = b->have_scores = true;
     HIPCHK(c, gpet_wait(b->side));  // (its launches read the compacted tables too)
+    if (fit_used) {
+      HIPCHK(c, gpet_wait(b->fit));
+      fit_used = false;
+    }
     int rc = check_device_status(b);
     if (rc) return rc;
     active = 0;
