@@ -1246,7 +1246,7 @@ __device__ __forceinline__ bool oj_wait_slot(EigState* st, unsigned int need_don
 }
 
 template <bool ARGS>
-__global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges, int nblk, int max_sweeps, double tol2) {
+__global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges, int nblk, int max_sweeps, double tol2, int half_stage) {
   OjEdge D;
   if (ARGS) {
     D = args.e[blockIdx.y];
@@ -1273,7 +1273,12 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
   OjSeat seat;  // (the inner sweep's per-lane addresses: once per kernel)
   oj_seat_init(seat, lane);
   const int nch = (Lg + 15) >> 4;
-  const int ldx = ((Lg + 31) & ~31) + 2;
+  // half_stage (round 6; every edge of the launch has an even width, the launcher checks): the panel is staged one 512-column half
+  // at a time -- [16][514] doubles = 66 KB instead of 131 KB at 1 024 columns, TWO workgroups per CU.  Both halves arrive in
+  // registers anyway (the 32 loads of a thread); the Gram matrix takes them through LDS one after the other, in the order of the
+  // one-pass form (the same bits), and the row update does the half that is still in LDS first, then the other half again.
+  const bool two_half = half_stage != 0 && Lg > 512;
+  const int ldx = half_stage ? 514 : ((Lg + 31) & ~31) + 2;
   const int kmax = nch * 16;
   const unsigned int nslots = (unsigned int)(nblk / 2), per_sweep = nslots * (unsigned int)(nblk - 1);
   unsigned int nbar = 0;  // (slots served by this workgroup)
@@ -1323,24 +1328,24 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[jj] = (v4f64e){0.0, 0.0, 0.0, 0.0};
         const double* xr = s_X + lr * ldx + lg;
-        auto gram_chunks = [&](int c_lo, int c_hi) {  // 16-column chunks c_lo + w + 4 u + 16 k < c_hi of this wave
+        auto gram_chunks = [&](int c_lo, int c_hi, int coff) {  // 16-column chunks c_lo + w + 4 u + 16 k < c_hi of this wave; LDS holds chunk c at c - coff
           for (int ch0 = c_lo + w; ch0 < c_hi; ch0 += 16) {
             double x[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < c_hi) ? xr[(ch0 + 4 * u) * 16 + 4 * jj] : 0.0;
+              for (int jj = 0; jj < 4; ++jj) x[u][jj] = (ch0 + 4 * u < c_hi) ? xr[(ch0 + 4 * u - coff) * 16 + 4 * jj] : 0.0;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][jj], x[u][jj], acc[jj], 0, 0, 0);
           }
         };
+        typedef double oj_d2 __attribute__((ext_vector_type(2)));
+        typedef unsigned int oj_u4 __attribute__((ext_vector_type(4)));
         if ((Lg & 1) == 0) {
-          typedef double oj_d2 __attribute__((ext_vector_type(2)));
-          typedef unsigned int oj_u4 __attribute__((ext_vector_type(4)));
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)D.G, 0, (int)((size_t)D.r_cap * (size_t)Lg * sizeof(double)), 0x00020000);
           oj_u4 qv[2][16];
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)D.G, 0, (int)((size_t)D.r_cap * (size_t)Lg * sizeof(double)), 0x00020000);
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1352,14 +1357,15 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (h == 1 && Lg <= 512) break;  // (uniform)
+            if (h == 1 && two_half) __syncthreads();  // (the Gram products of half 0 have read their columns)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int k = 2 * tid + 512 * h;
-              if (k < kmax) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + k]) = __builtin_bit_cast(oj_d2, qv[h][r]);
+              const int k = 2 * tid + 512 * h, kl = two_half ? 2 * tid : k;
+              if (k < kmax) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + kl]) = __builtin_bit_cast(oj_d2, qv[h][r]);
             }
             __syncthreads();
             OJ_T(0)
-            gram_chunks(32 * h, nch < 32 * h + 32 ? nch : 32 * h + 32);
+            gram_chunks(32 * h, nch < 32 * h + 32 ? nch : 32 * h + 32, two_half ? 32 * h : 0);
             OJ_T(1)
           }
         } else {
@@ -1385,7 +1391,7 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
             }
           __syncthreads();
           OJ_T(0)
-          gram_chunks(0, nch);
+          gram_chunks(0, nch, 0);
           OJ_T(1)
         }
 #pragma unroll
@@ -1429,26 +1435,50 @@ __global__ void __launch_bounds__(256) k_oj_persist(OjArgs args, EdgeDev* edges,
           const double* xs[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) xs[jj] = s_X + oj_krow(jj, lg) * ldx + lr;
-          for (int ct0 = w; ct0 < nch; ct0 += 16) {
-            double xv[4][4];
+          auto update_chunks = [&](int c_lo, int c_hi, int coff) {  // chunks c_lo + w + 4 u + 16 k < c_hi; LDS holds chunk c at c - coff
+            for (int ct0 = c_lo + w; ct0 < c_hi; ct0 += 16) {
+              double xv[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+              for (int u = 0; u < 4; ++u)
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) xv[u][jj] = (ct0 + 4 * u < nch) ? xs[jj][(ct0 + 4 * u) * 16] : 0.0;
-            v4f64e acc[4];
+                for (int jj = 0; jj < 4; ++jj) xv[u][jj] = (ct0 + 4 * u < c_hi) ? xs[jj][(ct0 + 4 * u - coff) * 16] : 0.0;
+              v4f64e acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = (v4f64e){0.0, 0.0, 0.0, 0.0};
+              for (int u = 0; u < 4; ++u) acc[u] = (v4f64e){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+              for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-              for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv[u][jj], acc[u], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[jj], xv[u][jj], acc[u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int c = (ct0 + 4 * u) * 16 + lr;
+              for (int u = 0; u < 4; ++u) {
+                const int c = (ct0 + 4 * u) * 16 + lr;
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (vo[i] && ct0 + 4 * u < nch && c < Lg) __hip_atomic_store(xo[i] + c, acc[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 4; ++i)
+                  if (vo[i] && ct0 + 4 * u < c_hi && c < Lg) __hip_atomic_store(xo[i] + c, acc[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
+          };
+          // (ONE copy of the update loop: two_half runs it twice -- the half the Gram products left in LDS first; then the first half
+          //  again from memory (this workgroup owns the 16 rows for the slot: columns [0, 512) are as they were; from its XCD's L2,
+          //  where the staging left them).  Kept in registers through the inner sweep instead the kernel needed 320 registers,
+          //  requested before the first update 284, with two inlined copies of the loop 260 -- two workgroups per CU allow 256)
+          for (int pass = 0; pass < (two_half ? 2 : 1); ++pass) {
+            if (pass == 1) {
+              const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)D.G, 0, (int)((size_t)D.r_cap * (size_t)Lg * sizeof(double)), 0x00020000);
+              oj_u4 q0[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int gi = oj_row(bI, bJ, r), k = 2 * tid;
+                const unsigned int off = (gi < rank && k < Lg) ? (unsigned int)(((size_t)gi * Lg + k) * sizeof(double)) : 0xFFFFFFF0u;
+                q0[r] = __builtin_amdgcn_raw_buffer_load_b128(rs2, off, 0, 16);
+              }
+              __syncthreads();
+#pragma unroll
+              for (int r = 0; r < 16; ++r) *reinterpret_cast<oj_d2*>(&s_X[r * ldx + 2 * tid]) = __builtin_bit_cast(oj_d2, q0[r]);
+              __syncthreads();
+            }
+            const int c_lo = (two_half && pass == 0) ? 32 : 0, c_hi = (two_half && pass == 1) ? 32 : nch;
+            update_chunks(c_lo, c_hi, two_half ? c_lo : 0);
           }
         }
       }
@@ -1686,6 +1716,20 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   const bool staged_lds_ok = bd.Lg <= OJ_STAGE_MAX && option("oj_stage");
   const bool staged = staged_lds_ok && (long long)(nblk / 2) * B <= 256;
   const size_t stage_lds = (size_t)OJ_M * (((bd.Lg + 31) & ~31) + 2) * sizeof(double);
+  // k_oj_persist with the panel staged one 512-column half at a time (even widths above 512 columns): 66 KB instead of 131 KB,
+  // two workgroups per CU -- a batch of eight 1 024-column edges (config 5's chains) holds all its 512 pair slots at once
+  // (only where the whole panels cannot all be resident -- one workgroup per CU: a single 1 024-column edge, 64 slots, is 3-4 % slower
+  //  with the second read of the first half: 11.6 against 11.2 ms warm; eight edges, 512 slots: 20.9 against 22.6 ms -- the rounds of
+  //  a big batch are bound by what the 64 MB of panels pull from beyond the L2s, not by occupancy: profiles/r06_oj_half_stage.txt)
+  int n_cus = 256;
+  {
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || n_cus < 1) n_cus = 256;
+    (void)hipGetLastError();
+  }
+  const int half_opt = option("oj_half_stage");
+  const int half_stage = (bd.lg_even && bd.Lg > 512 && (half_opt > 0 || (half_opt < 0 && (long long)(nblk / 2) * B > n_cus))) ? 1 : 0;
+  const size_t persist_lds = half_stage ? (size_t)OJ_M * 514 * sizeof(double) : stage_lds;
   if (staged) {
     static int attr_done[64] = {};
     int dev = 0;
@@ -1701,16 +1745,22 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   // grid is sized to what the device holds at once and a workgroup serves several slots per round when the batch has more
   // slots than that; beyond four slots per workgroup and round the round launches' two register-fed workgroups per CU
   // win); option "oj_persist" = 0: launches
-  static int persist_cap[64] = {};  // workgroups of k_oj_persist the device holds at once (occupancy x CUs), per device
+  static int persist_cap[64] = {};  // workgroups of k_oj_persist the device holds at once (occupancy x CUs), per device ...
+  static size_t persist_cap_lds[64] = {};  // ... for this much dynamic LDS (the occupancy is asked again when the size changes)
+  static bool persist_attr[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (staged_lds_ok && gpet_opt_oj_persist() && dev >= 0 && dev < 64 && !persist_cap[dev]) {
-    (void)hipFuncSetAttribute((const void*)k_oj_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_oj_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+  if (staged_lds_ok && gpet_opt_oj_persist() && dev >= 0 && dev < 64 && (!persist_cap[dev] || persist_cap_lds[dev] != persist_lds)) {
+    if (!persist_attr[dev]) {
+      (void)hipFuncSetAttribute((const void*)k_oj_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_oj_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+      persist_attr[dev] = true;
+    }
     int occ = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_oj_persist<false>, 256, stage_lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_oj_persist<false>, 256, persist_lds) != hipSuccess || occ < 1) occ = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 64;
     persist_cap[dev] = occ * cus;
+    persist_cap_lds[dev] = persist_lds;
     (void)hipGetLastError();
   }
   const int cap = (dev >= 0 && dev < 64 && persist_cap[dev] > 0) ? persist_cap[dev] : 64;
@@ -1718,8 +1768,8 @@ hipError_t launch_factor_big(hipStream_t st, EdgeDev* d_edges, int B, const Batc
   if (staged_lds_ok && gpet_opt_oj_persist() && slots_all <= 4LL * cap) {
     int wpe = nblk / 2;  // workgroups per edge
     if (slots_all > cap) wpe = cap / B > 0 ? cap / B : 1;
-    if (use_args) hipLaunchKernelGGL((k_oj_persist<true>), dim3(wpe, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
-    else hipLaunchKernelGGL((k_oj_persist<false>), dim3(wpe, B), dim3(256), stage_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2);
+    if (use_args) hipLaunchKernelGGL((k_oj_persist<true>), dim3(wpe, B), dim3(256), persist_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2, half_stage);
+    else hipLaunchKernelGGL((k_oj_persist<false>), dim3(wpe, B), dim3(256), persist_lds, st, oj_args, d_edges, nblk, max_sweeps, tol2, half_stage);
   } else
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     for (int round = 0; round < nblk - 1; ++round) {

@@ -37,6 +37,7 @@ const OptionDef kDefs[] = {
     {"oj_warm_fail", 0, 0, 1, "testing: the warm start's Cholesky reports a non-positive pivot, so that the factor falls back to the pivoted Cholesky"},
     {"oj_persist", 1, 0, 1, "any-rank Jacobi: rounds and sweeps in one launch, pair slots handed out by ticket (k_oj_persist); 0: one launch per round"},
     {"oj_stage", 1, 0, 1, "any-rank Jacobi: a pair's 16 rows staged in LDS; 0: operands from global memory"},
+    {"oj_half_stage", -1, -1, 1, "any-rank Jacobi (k_oj_persist), even widths above 512 columns: a pair's 16-row panel staged in LDS one 512-column half at a time (66 KB, two workgroups per CU, the first half read a second time for the row update) instead of whole (131 KB at 1 024 columns, one per CU); the same bits; -1: where a round has more pair slots than the GPU has CUs"},
     {"oj_args", 1, 0, 1, "any-rank factor: per-edge pointers of small batches in the kernel arguments; 0: through the edge table"},
     {"oj_tol_exp", 8, 4, 15, "any-rank Jacobi stops after a sweep whose pairs were all orthogonal to 10^-x relative"},
     {"oj_max_sweeps", 16, 1, 64, "sweep budget of the any-rank Jacobi"},

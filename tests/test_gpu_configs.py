@@ -581,3 +581,29 @@ def test_pivoted_cholesky_over_the_gpu_in_a_batch_of_mixed_widths(amd, ctx, pcho
     finally:
         for k, v in old.items():
             L.set_option(k, v)
+
+
+def test_any_rank_jacobi_half_panel_staging_is_bit_identical(amd, ctx):
+    """k_oj_persist stages a pair's 16-row panel whole (131 KB of LDS at 1 024 columns: one workgroup per CU) or one 512-column
+    half at a time (66 KB: two per CU; the automatic choice once a round has more pair slots than the GPU has CUs -- config 5's
+    eight chains).  The Gram matrix accumulates its chunks in the same order either way and the row update is chunk-wise: the
+    factor rows must be the same BITS, on a single edge (whole by default) and on a batch of five (half by default)."""
+    L = amd._lib
+    init, grad, warm, kw = _matern_frame(amd, ctx)
+    kw = {k: v for k, v in kw.items() if k != "seed"}  # (the batch form takes one seed per edge)
+    for nb in (1, 5):
+        rows = {}
+        for half in (0, 1):
+            old = L.set_option("oj_half_stage", half)
+            try:
+                bt = amd.GP_Edge_Tracing_Batch([init] * nb, grad, [3 + e for e in range(nb)], obs=[warm] * nb, **kw, _ctx=ctx)
+                b = bt._batch
+                b.fit_predict(want_cov=True)
+                b.factor()
+                rows[half] = [np.array(b.read(L.BUF_FACTOR, e)) for e in range(nb)]
+                assert all(b.scalars(e).status == 0 and b.scalars(e).rank == 1024 for e in range(nb))
+                b.close()
+            finally:
+                L.set_option("oj_half_stage", -1 if old == 2 else old)
+        for e in range(nb):
+            assert np.array_equal(rows[0][e], rows[1][e]), (nb, e)
